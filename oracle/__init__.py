@@ -1,0 +1,207 @@
+"""ORACLE / TEST INFRASTRUCTURE -- not product code.
+
+ctypes loaders for
+  * ``COracle``  -- oracle/libmw_oracle.so, the C restatement (mw_oracle.c), and
+  * ``RefOracle`` -- oracle/_ref/libmw_ref.so, the reference's own Fortran hot path
+    compiled from /root/reference by oracle/Makefile (build container only; the
+    prebuilt .so travels to the GPU box).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package.  The product (mc_water_ls_mw_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+C_LIB = os.path.join(HERE, "libmw_oracle.so")
+REF_LIB = os.path.join(HERE, "_ref", "libmw_ref.so")
+MAXNEIGH = 50          # molint.F90:79
+MAX_IVECT = 4096
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_lp = ctypes.POINTER(ctypes.c_longlong)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def build(ref=True):
+    """Compile the C restatement and, when /root/reference is present, the reference .so."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+    if ref and os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+class COracle:
+    """The C restatement.  Stateless functions over explicit arrays."""
+
+    def __init__(self):
+        if not os.path.exists(C_LIB):
+            build(ref=False)
+        L = ctypes.CDLL(C_LIB)
+        L.mwo_model_energy.restype = ctypes.c_double
+        L.mwo_local_energy.restype = ctypes.c_double
+        self.L = L
+
+    def constants(self):
+        out = np.zeros(8)
+        self.L.mwo_constants(_d(out))
+        return out
+
+    def ivects(self, h):
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        iv = np.zeros((MAX_IVECT, 3))
+        n = self.L.mwo_compute_ivects(_d(h), _d(iv), MAX_IVECT)
+        if n < 0:
+            raise RuntimeError("too many image vectors")
+        return np.ascontiguousarray(iv[:n])
+
+    def neighbours(self, xyz, ivect, maxneigh=MAXNEIGH):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        n = len(xyz)
+        nn = np.zeros(n, dtype=np.int32)
+        jn = np.zeros((n, maxneigh), dtype=np.int32)
+        vn = np.zeros((n, maxneigh), dtype=np.int32)
+        rc = self.L.mwo_compute_neighbours(n, _d(xyz), _d(ivect), len(ivect), maxneigh, _i(nn), _i(jn), _i(vn))
+        if rc < 0:
+            raise RuntimeError("neighbour list overflow (nn > maxneigh)")
+        return nn, jn, vn
+
+    def model_energy(self, xyz, ivect, nn, jn, vn, counts=False):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        c = np.zeros(2, dtype=np.int64)
+        e = self.L.mwo_model_energy(len(xyz), _d(xyz), _d(ivect), jn.shape[1], _i(nn), _i(jn), _i(vn),
+                                    c.ctypes.data_as(_lp))
+        return (e, c) if counts else e
+
+    def local_energy(self, imol, xyz, ivect, nn, jn, vn, counts=False):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        c = np.zeros(2, dtype=np.int64)
+        e = self.L.mwo_local_energy(int(imol), len(xyz), _d(xyz), _d(ivect), jn.shape[1], _i(nn), _i(jn), _i(vn),
+                                    c.ctypes.data_as(_lp))
+        return (e, c) if counts else e
+
+    def local_energy_all(self, xyz, ivect, nn, jn, vn, counts=False):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        e = np.zeros(len(xyz))
+        c = np.zeros(2, dtype=np.int64)
+        self.L.mwo_local_energy_all(len(xyz), _d(xyz), _d(ivect), jn.shape[1], _i(nn), _i(jn), _i(vn), _d(e),
+                                    c.ctypes.data_as(_lp))
+        return (e, c) if counts else e
+
+    def trial_moves(self, imol, trial, xyz, ivect, nn, jn, vn):
+        xyz = np.array(xyz, dtype=np.float64, order="C")
+        imol = np.ascontiguousarray(imol, dtype=np.int32)
+        trial = np.ascontiguousarray(trial, dtype=np.float64)
+        eo = np.zeros(len(imol))
+        en = np.zeros(len(imol))
+        self.L.mwo_trial_moves(len(imol), _i(imol), _d(trial), len(xyz), _d(xyz), _d(ivect), jn.shape[1],
+                               _i(nn), _i(jn), _i(vn), _d(eo), _d(en))
+        return eo, en
+
+
+class RefOracle:
+    """The reference's compiled Fortran (module energy), one system at a time.
+
+    The Fortran modules hold global state, so this is a singleton per process:
+    ``load(h_list, xyz_list)`` calls energy_init for ``len(h_list)`` lattices.
+    """
+
+    _lib = None
+
+    @staticmethod
+    def available():
+        return os.path.exists(REF_LIB)
+
+    def __init__(self):
+        if RefOracle._lib is None:
+            if not os.path.exists(REF_LIB):
+                raise FileNotFoundError(REF_LIB + " (run `make -C oracle ref` in the build container)")
+            L = ctypes.CDLL(REF_LIB)
+            L.ref_model_energy.restype = ctypes.c_double
+            L.ref_local_energy.restype = ctypes.c_double
+            L.ref_time_model_energy.restype = ctypes.c_double
+            L.ref_time_local_energy.restype = ctypes.c_double
+            RefOracle._lib = L
+            RefOracle._loaded = False
+        self.L = RefOracle._lib
+        self.n = 0
+        self.nlat = 0
+
+    def load(self, h_list, xyz_list):
+        if RefOracle._loaded:
+            self.L.ref_finalize()
+        h = np.ascontiguousarray(np.stack(h_list), dtype=np.float64)
+        x = np.ascontiguousarray(np.stack(xyz_list), dtype=np.float64)
+        self.nlat, self.n = x.shape[0], x.shape[1]
+        self.L.ref_init(self.n, self.nlat, _d(h), _d(x))
+        RefOracle._loaded = True
+
+    def constants(self):
+        out = np.zeros(8)
+        self.L.ref_constants(_d(out))
+        return out
+
+    def set_positions(self, ils, xyz):
+        x = np.ascontiguousarray(xyz, dtype=np.float64)
+        self.L.ref_set_positions(ils, _d(x))
+
+    def set_position(self, ils, imol, r):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        self.L.ref_set_position(ils, int(imol), _d(r))
+
+    def set_cell(self, ils, h):
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        self.L.ref_set_cell(ils, _d(h))
+
+    def ivects(self, ils):
+        iv = np.zeros((MAX_IVECT, 3))
+        n = self.L.ref_compute_ivects(ils, _d(iv), MAX_IVECT)
+        return np.ascontiguousarray(iv[:n])
+
+    def compute_neighbours(self, ils):
+        self.L.ref_compute_neighbours(ils)
+
+    def neighbours(self, ils):
+        nn = np.zeros(self.n, dtype=np.int32)
+        jn = np.zeros((self.n, MAXNEIGH), dtype=np.int32)
+        vn = np.zeros((self.n, MAXNEIGH), dtype=np.int32)
+        self.L.ref_get_neighbours(ils, _i(nn), _i(jn), _i(vn))
+        return nn, jn, vn
+
+    def model_energy(self, ils):
+        return self.L.ref_model_energy(ils)
+
+    def local_energy(self, imol, ils):
+        return self.L.ref_local_energy(int(imol), ils)
+
+    def local_energy_all(self, ils):
+        e = np.zeros(self.n)
+        self.L.ref_local_energy_all(ils, _d(e))
+        return e
+
+    def trial_moves(self, ils, imol, trial):
+        imol = np.ascontiguousarray(imol, dtype=np.int32)
+        trial = np.ascontiguousarray(trial, dtype=np.float64)
+        eo = np.zeros(len(imol))
+        en = np.zeros(len(imol))
+        self.L.ref_trial_moves(ils, len(imol), _i(imol), _d(trial), _d(eo), _d(en))
+        return eo, en
+
+    def time_model_energy(self, ils, nrep):
+        return self.L.ref_time_model_energy(ils, nrep)
+
+    def time_local_energy(self, ils, nrep, imol):
+        imol = np.ascontiguousarray(imol, dtype=np.int32)
+        return self.L.ref_time_local_energy(ils, nrep, len(imol), _i(imol))

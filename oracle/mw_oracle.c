@@ -1,0 +1,268 @@
+/* ORACLE / TEST INFRASTRUCTURE -- not product code.  See mw_oracle.h.
+ *
+ * Each function cites the lines of /root/reference/molint.F90 it restates.
+ * The arithmetic keeps the reference's operation order (and this file is
+ * built with -ffp-contract=off) so that agreement with the compiled
+ * reference is at the 1e-15 level, far inside the 1e-10 parity bar.
+ */
+#include "mw_oracle.h"
+#include <math.h>
+#include <stddef.h>
+
+#define MWO_MAXNEIGH_HARD 256
+
+/* molint.F90:64-74, constants.f90:42-43 */
+static const double ANG_TO_BOHR = 1.0 / 0.5291772108;
+#define MW_SIGMA   (2.3925 * ANG_TO_BOHR)
+#define MW_EPSILON (6.189 / 627.509469)
+static const double MW_LAMBDA = 23.15;
+static const double SW_BIGA   = 7.049556277;
+static const double SW_B      = 0.6022245584;
+static const double SW_GAMMA  = 1.2;
+static const double SW_A      = 1.8;
+/* molint.F90:74: the literal has no _dp suffix, so the reference holds the
+ * single-precision value widened to double. */
+#define COS0 ((double)(-0.33331324756f))
+
+void mwo_constants(double out[8])
+{
+    out[0] = MW_SIGMA; out[1] = MW_EPSILON; out[2] = MW_LAMBDA; out[3] = SW_BIGA;
+    out[4] = SW_B;     out[5] = SW_GAMMA;   out[6] = SW_A;      out[7] = COS0;
+}
+
+/* molint.F90:174-217 */
+int mwo_compute_ivects(const double h[9], double *ivect, int max_ivect)
+{
+    const double sigma = MW_SIGMA;
+    const double *h1 = h, *h2 = h + 3, *h3 = h + 6;
+    /* :189-191 */
+    int im = (int)floor(SW_A * sigma / sqrt(h1[0]*h1[0] + h1[1]*h1[1] + h1[2]*h1[2])) + 1;
+    int jm = (int)floor(SW_A * sigma / sqrt(h2[0]*h2[0] + h2[1]*h2[1] + h2[2]*h2[2])) + 1;
+    int km = (int)floor(SW_A * sigma / sqrt(h3[0]*h3[0] + h3[1]*h3[1] + h3[2]*h3[2])) + 1;
+    int nivect = (2*im + 1) * (2*jm + 1) * (2*km + 1);       /* :193 */
+    if (nivect > max_ivect) return -1;
+
+    ivect[0] = ivect[1] = ivect[2] = 0.0;                    /* :197 central cell first */
+    int k = 1;
+    for (int ic = -im; ic <= im; ++ic) {                     /* :200-213 */
+        double sx[3] = { (double)ic * h1[0], (double)ic * h1[1], (double)ic * h1[2] };
+        for (int jc = -jm; jc <= jm; ++jc) {
+            double sy[3] = { (double)jc * h2[0], (double)jc * h2[1], (double)jc * h2[2] };
+            for (int kc = -km; kc <= km; ++kc) {
+                double sz[3] = { (double)kc * h3[0], (double)kc * h3[1], (double)kc * h3[2] };
+                if (ic == 0 && jc == 0 && kc == 0) continue; /* :207 */
+                for (int d = 0; d < 3; ++d) ivect[3*k + d] = (sx[d] + sy[d]) + sz[d]; /* :208 */
+                ++k;
+            }
+        }
+    }
+    return nivect;
+}
+
+/* molint.F90:501-559 */
+int mwo_compute_neighbours(int n, const double *xyz, const double *ivect, int nivect,
+                           int maxneigh, int *nn, int *jn, int *vn)
+{
+    const double rn = SW_A * MW_SIGMA * 1.18;                /* :516 */
+    const double rn2 = rn * rn;                              /* :537 */
+    int maxnn = 0, overflow = 0;
+    for (int i = 0; i < n; ++i) {                            /* :520 */
+        const double *ri = xyz + 3*i;
+        int cnt = 0;
+        for (int j = 0; j < n; ++j) {                        /* :525 */
+            const double *rj = xyz + 3*j;
+            double v[3] = { rj[0] - ri[0], rj[1] - ri[1], rj[2] - ri[2] };  /* :529 */
+            for (int k = 0; k < nivect; ++k) {               /* :531 */
+                if (k == 0 && j == i) continue;              /* :532 */
+                double t0 = v[0] + ivect[3*k], t1 = v[1] + ivect[3*k+1], t2 = v[2] + ivect[3*k+2]; /* :534 */
+                double r2 = t0*t0 + t1*t1 + t2*t2;           /* :535 */
+                if (r2 < rn2) {                              /* :537-542 */
+                    if (cnt < maxneigh) {
+                        jn[(size_t)maxneigh*i + cnt] = j + 1;
+                        vn[(size_t)maxneigh*i + cnt] = k + 1;
+                    } else {
+                        overflow = 1;
+                    }
+                    ++cnt;
+                }
+            }
+        }
+        nn[i] = cnt < maxneigh ? cnt : maxneigh;
+        for (int s = nn[i]; s < maxneigh; ++s) { jn[(size_t)maxneigh*i + s] = 0; vn[(size_t)maxneigh*i + s] = 0; }
+        if (cnt > maxnn) maxnn = cnt;
+    }
+    return overflow ? -1 : maxnn;
+}
+
+/* molint.F90:407-499 */
+double mwo_model_energy(int n, const double *xyz, const double *ivect,
+                        int maxneigh, const int *nn, const int *jn, const int *vn,
+                        long long counts[2])
+{
+    const double sigma = MW_SIGMA, eps = MW_EPSILON;
+    const double rcsq = sigma * SW_A * sigma * SW_A;         /* :432 */
+    const double sig_a = sigma * SW_A;
+    const double Aeps = SW_BIGA * eps, lam_eps = MW_LAMBDA * eps, gam_sig = SW_GAMMA * sigma;
+    double Evdw = 0.0;
+    long long npair = 0, ntrip = 0;
+
+    for (int i = 0; i < n; ++i) {                            /* :438 */
+        const double *ri = xyz + 3*i;
+        const int *jl = jn + (size_t)maxneigh*i, *vl = vn + (size_t)maxneigh*i;
+        for (int ln = 0; ln < nn[i]; ++ln) {                 /* :442 */
+            const double *rj = xyz + 3*(jl[ln] - 1);
+            const double *iv = ivect + 3*(vl[ln] - 1);
+            double a0 = (rj[0] + iv[0]) - ri[0];             /* :447,450 */
+            double a1 = (rj[1] + iv[1]) - ri[1];
+            double a2 = (rj[2] + iv[2]) - ri[2];
+            double r2_ij = a0*a0 + a1*a1 + a2*a2;            /* :451 */
+            if (r2_ij < rcsq) {                              /* :454 */
+                double r1_ij = sqrt(r2_ij);                  /* :456 */
+                double exp2 = exp(sigma / (r1_ij - sig_a));  /* :459 */
+                double q = sigma * sigma / r2_ij;
+                double tmpE = Aeps * (SW_B * (q*q) - 1.0);   /* :460 */
+                tmpE = tmpE * exp2;                          /* :461 */
+                exp2 = exp(gam_sig / (r1_ij - sig_a));       /* :462 */
+                Evdw = Evdw + 0.5 * tmpE;                    /* :464 */
+                ++npair;
+                for (int ln2 = ln + 1; ln2 < nn[i]; ++ln2) { /* :467 */
+                    const double *rk = xyz + 3*(jl[ln2] - 1);
+                    const double *kv = ivect + 3*(vl[ln2] - 1);
+                    double b0 = (rk[0] + kv[0]) - ri[0];     /* :472,474 */
+                    double b1 = (rk[1] + kv[1]) - ri[1];
+                    double b2 = (rk[2] + kv[2]) - ri[2];
+                    double r2_ik = b0*b0 + b1*b1 + b2*b2;    /* :475 */
+                    if (r2_ik < rcsq) {                      /* :477 */
+                        double r1_ik = sqrt(r2_ik);
+                        double ctheta = (a0*b0 + a1*b1 + a2*b2) / (r1_ik * r1_ij);  /* :480 */
+                        double d = ctheta - COS0;
+                        double csq = d * d;                  /* :481 */
+                        double exp1 = exp(gam_sig / (r1_ik - sig_a));               /* :482 */
+                        Evdw = Evdw + lam_eps * exp1 * exp2 * csq;                  /* :483 */
+                        ++ntrip;
+                    }
+                }
+            }
+        }
+    }
+    if (counts) { counts[0] = npair; counts[1] = ntrip; }
+    return Evdw;                                             /* :495 */
+}
+
+/* molint.F90:220-404 */
+double mwo_local_energy(int imol, int n, const double *xyz, const double *ivect,
+                        int maxneigh, const int *nn, const int *jn, const int *vn,
+                        long long counts[2])
+{
+    (void)n;
+    const double sigma = MW_SIGMA, eps = MW_EPSILON;
+    const double rcsq = sigma * SW_A * sigma * SW_A;         /* :255 */
+    const double sig_a = sigma * SW_A;
+    const double Aeps = SW_BIGA * eps, gam_sig = SW_GAMMA * sigma;
+    double sqlist[2*MWO_MAXNEIGH_HARD], cthetalist[2*MWO_MAXNEIGH_HARD];
+    double Evdw = 0.0, Etb = 0.0;
+    long long npair = 0, ntrip = 0;
+
+    const int i = imol - 1;
+    const double *ri = xyz + 3*i;                            /* :258 */
+    const int nni = nn[i];
+    const int *jl = jn + (size_t)maxneigh*i, *vl = vn + (size_t)maxneigh*i;
+
+    for (int ln = 0; ln < nni; ++ln) {                       /* :260 */
+        double iEtb = 0.0;
+        const int j = jl[ln] - 1;                            /* :264-265 */
+        const double *jiv = ivect + 3*(vl[ln] - 1);          /* :268 */
+        const double *rj0 = xyz + 3*j;
+        double rj[3] = { rj0[0] + jiv[0], rj0[1] + jiv[1], rj0[2] + jiv[2] };  /* :269 */
+        double a0 = rj[0] - ri[0], a1 = rj[1] - ri[1], a2 = rj[2] - ri[2];     /* :272 */
+        double r2_ij = a0*a0 + a1*a1 + a2*a2;                /* :273 */
+
+        if (r2_ij < rcsq) {                                  /* :276 */
+            double ir1_ij = 1.0 / sqrt(r2_ij);               /* :278 */
+            double r1_ij = ir1_ij * r2_ij;                   /* :286 */
+            double isr1_ij = 1.0 / (r1_ij - sig_a);          /* :288 */
+            double exp2 = exp(sigma * isr1_ij);              /* :291 */
+            double exp3 = exp(gam_sig * isr1_ij);            /* :292 */
+            double q = sigma * sigma * ir1_ij * ir1_ij;
+            double tmpE = Aeps * (SW_B * (q*q) - 1.0);       /* :294 */
+            tmpE = tmpE * exp2;                              /* :295 */
+            Evdw = Evdw + tmpE;                              /* :297 */
+            ++npair;
+
+            int vlen = 0;
+            /* j--i--k: the remaining entries of imol's own list, :302-318 */
+            for (int ln2 = ln + 1; ln2 < nni; ++ln2) {
+                const double *rk0 = xyz + 3*(jl[ln2] - 1);
+                const double *kv = ivect + 3*(vl[ln2] - 1);
+                double b0 = (rk0[0] + kv[0]) - ri[0];        /* :307,309 */
+                double b1 = (rk0[1] + kv[1]) - ri[1];
+                double b2 = (rk0[2] + kv[2]) - ri[2];
+                int s = ln2 - ln - 1;                        /* :312 (0-based) */
+                sqlist[s] = b0*b0 + b1*b1 + b2*b2;           /* :310,314 */
+                cthetalist[s] = (a0*b0 + a1*b1 + a2*b2) * ir1_ij;   /* :316 */
+            }
+            /* i--j--k: every entry of jmol's list, shifted by j's image, :320-343 */
+            double c0 = -a0, c1 = -a1, c2 = -a2;             /* :320 */
+            const int nnj = nn[j];
+            const int *jl2 = jn + (size_t)maxneigh*j, *vl2 = vn + (size_t)maxneigh*j;
+            for (int ln2 = 0; ln2 < nnj; ++ln2) {            /* :324 */
+                const double *rk0 = xyz + 3*(jl2[ln2] - 1);
+                const double *kv = ivect + 3*(vl2[ln2] - 1);
+                double b0 = ((rk0[0] + kv[0]) + jiv[0]) - rj[0];   /* :332,334 */
+                double b1 = ((rk0[1] + kv[1]) + jiv[1]) - rj[1];
+                double b2 = ((rk0[2] + kv[2]) + jiv[2]) - rj[2];
+                int s = nni - (ln + 1) + ln2;                /* :337 (0-based) */
+                sqlist[s] = b0*b0 + b1*b1 + b2*b2;           /* :335,339 */
+                cthetalist[s] = (c0*b0 + c1*b1 + c2*b2) * ir1_ij;   /* :341 */
+            }
+            vlen = nni - (ln + 1) + nnj;                     /* :346 */
+
+            /* :354-386; an out-of-range slot contributes exactly 0 (G2) */
+            for (int s = 0; s < vlen; ++s) {
+                if (sqlist[s] < rcsq) {                      /* :361 */
+                    double vinv = 1.0 / sqrt(sqlist[s]);     /* :355 */
+                    double vexp = vinv * sqlist[s] - sig_a;  /* :363 */
+                    vexp = gam_sig / vexp;                   /* :364 */
+                    double ct = cthetalist[s] * vinv;        /* :365 */
+                    if (ct < 0.99) {                         /* :367 */
+                        double d = ct - COS0;
+                        iEtb = iEtb + (d * d) * exp(vexp);   /* :368,385 */
+                        ++ntrip;
+                    }
+                }
+            }
+            iEtb = iEtb * exp3;                              /* :387 */
+        }
+        Etb = Etb + iEtb;                                    /* :392 */
+    }
+    Evdw = Evdw + MW_LAMBDA * eps * Etb;                     /* :397 */
+    if (counts) { counts[0] = npair; counts[1] = ntrip; }
+    return Evdw;                                             /* :400 */
+}
+
+void mwo_local_energy_all(int n, const double *xyz, const double *ivect,
+                          int maxneigh, const int *nn, const int *jn, const int *vn,
+                          double *e_out, long long counts[2])
+{
+    long long c[2], tot[2] = { 0, 0 };
+    for (int i = 1; i <= n; ++i) {
+        e_out[i - 1] = mwo_local_energy(i, n, xyz, ivect, maxneigh, nn, jn, vn, c);
+        tot[0] += c[0]; tot[1] += c[1];
+    }
+    if (counts) { counts[0] = tot[0]; counts[1] = tot[1]; }
+}
+
+void mwo_trial_moves(int nmoves, const int *imol, const double *trial,
+                     int n, double *xyz, const double *ivect,
+                     int maxneigh, const int *nn, const int *jn, const int *vn,
+                     double *e_old, double *e_new)
+{
+    for (int m = 0; m < nmoves; ++m) {
+        double *r = xyz + 3*(imol[m] - 1);
+        double keep[3] = { r[0], r[1], r[2] };
+        e_old[m] = mwo_local_energy(imol[m], n, xyz, ivect, maxneigh, nn, jn, vn, NULL);   /* mc_moves.F90:1010 */
+        r[0] = trial[3*m]; r[1] = trial[3*m+1]; r[2] = trial[3*m+2];                        /* mc_moves.F90:1079 */
+        e_new[m] = mwo_local_energy(imol[m], n, xyz, ivect, maxneigh, nn, jn, vn, NULL);   /* mc_moves.F90:1083 */
+        r[0] = keep[0]; r[1] = keep[1]; r[2] = keep[2];                                     /* mc_moves.F90:1186 */
+    }
+}

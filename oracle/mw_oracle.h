@@ -1,0 +1,68 @@
+/* ORACLE / TEST INFRASTRUCTURE -- not product code.
+ *
+ * CPU restatement (plain C, double precision, scalar) of the mW energy hot
+ * path of keb721/mc_water_ls_mw, module `energy` (molint.F90).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; the
+ * product (mc_water_ls_mw_amd/csrc, libmw_hip.so) never does.
+ *
+ * Parity status: PINNED -- checked against oracle/_ref/libmw_ref.so (the
+ * reference's own Fortran compiled with amdflang) and against the golden
+ * vectors under tests/golden/ that were generated from it
+ * (tests/golden/make_golden.py); see tests/test_oracle_golden.py.
+ *
+ * Conventions follow the reference: molecule and image indices are 1-based,
+ * the list arrays are jn[slot + maxneigh*(imol-1)] (Fortran jn(slot,imol)),
+ * positions are xyz[3*(imol-1)+d] (Fortran ljr(d,1,imol,ils)), the cell is
+ * h[3*(k-1)+d] = hmatrix(d,k) (column k = cell vector k), lengths in bohr,
+ * energies in Hartree.
+ */
+#ifndef MW_ORACLE_H
+#define MW_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* molint.F90:63-74 -> out = sigma, epsilon, lambda, A, B, gamma, a, cos0 */
+void mwo_constants(double out[8]);
+
+/* molint.F90:174-217.  Writes at most max_ivect vectors (3 doubles each,
+ * central cell first) and returns nivect, or -1 if max_ivect is too small. */
+int mwo_compute_ivects(const double h[9], double *ivect, int max_ivect);
+
+/* molint.F90:501-559 (without its internal compute_ivects call: pass the
+ * vectors in).  Returns the largest nn, or -1 if any atom exceeds maxneigh
+ * (the reference silently overflows there). */
+int mwo_compute_neighbours(int n, const double *xyz, const double *ivect, int nivect,
+                           int maxneigh, int *nn, int *jn, int *vn);
+
+/* molint.F90:407-499.  counts (may be NULL): [0] directed in-range pairs,
+ * [1] in-range i-centred triplets. */
+double mwo_model_energy(int n, const double *xyz, const double *ivect,
+                        int maxneigh, const int *nn, const int *jn, const int *vn,
+                        long long counts[2]);
+
+/* molint.F90:220-404, with the intended semantics for out-of-range slots
+ * (contribute exactly 0).  imol is 1-based.  counts (may be
+ * NULL): [0] in-range pairs, [1] in-range triplet slots with cos(theta) < 0.99. */
+double mwo_local_energy(int imol, int n, const double *xyz, const double *ivect,
+                        int maxneigh, const int *nn, const int *jn, const int *vn,
+                        long long counts[2]);
+
+/* Convenience loops used by the tests and by bench.py's cpu_baseline ("port"). */
+void mwo_local_energy_all(int n, const double *xyz, const double *ivect,
+                          int maxneigh, const int *nn, const int *jn, const int *vn,
+                          double *e_out, long long counts[2]);
+
+/* Trial moves as mc_water_translation performs them (mc_moves.F90:1010,
+ * 1079-1083, 1186): e_old with the stored position, e_new with atom imol[m]
+ * at trial[3m..3m+2]; the position is restored after each move. */
+void mwo_trial_moves(int nmoves, const int *imol, const double *trial,
+                     int n, double *xyz, const double *ivect,
+                     int maxneigh, const int *nn, const int *jn, const int *vn,
+                     double *e_old, double *e_new);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
