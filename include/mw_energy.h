@@ -1,0 +1,136 @@
+/* mw_energy.h -- C ABI of libmw_hip.so, the MI355X (gfx950) mW energy engine.
+ *
+ * This is the drop-in boundary for the hot path of keb721/mc_water_ls_mw:
+ * the Fortran `module energy` (molint.F90:10-37).  Every entry point cites the
+ * reference routine it stands behind; the replacement Fortran module
+ * (mc_water_ls_mw_amd/fortran/energy_hip.F90) binds these with ISO_C_BINDING
+ * and keeps the reference's public names, so mc_moves.F90 / main.f90 compile
+ * against it unchanged.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types cross this boundary
+ *   - every function returns 0 on success, nonzero on failure; the message is
+ *     then available from mw_last_error().  There is NO CPU fallback: without
+ *     a usable gfx950 device mw_init fails.
+ *   - indices are 1-based exactly as the Fortran host passes them: box
+ *     (lattice) `ils` in 1..nboxes, molecule `imol` in 1..nwater, image 1 = the
+ *     central cell.
+ *   - lengths in bohr, energies in Hartree, double precision throughout.
+ *   - the host owns ljr / hmatrix / model_energy; inputs are
+ *     copied during the call, no pointer handed out outlives mw_finalize().
+ *   - a "box" is one lattice of one walker.  The reference has 1 or 2 per
+ *     process (userparams::num_lattices); the engine accepts any number so that
+ *     many independent walkers share a launch (the *_batch / *_launch entries).
+ *   - calls are synchronous unless named *_launch; one host thread per context.
+ */
+#ifndef MW_ENERGY_H
+#define MW_ENERGY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MW_MAXNEIGH_LIMIT 64   /* the per-atom in-range mask is one 64-bit word        */
+#define MW_MAX_IVECT      1024 /* 10 bits of a packed list entry hold the image number */
+
+/* ---- lifetime: energy_init / energy_deinit (molint.F90:91-153, 155-171) ---------- */
+
+/* Allocate device state for `nboxes` boxes of `nwater` molecules each with
+ * `maxneigh` list slots per molecule (reference: 50, molint.F90:79).  `device`
+ * is the HIP device ordinal (the local rank in a one-process-per-GPU farm). */
+int mw_init(int device, int nwater, int nboxes, int maxneigh);
+int mw_finalize(void);
+int mw_is_initialised(void);
+
+/* Message of the last failing call on this thread ("" if none). */
+const char *mw_last_error(void);
+
+/* Model constants as the engine holds them (molint.F90:63-74):
+ * out = sigma, epsilon, lambda, A, B, gamma, a, cos0. */
+int mw_constants(double out[8]);
+
+/* ---- implicit inputs of the Fortran module: model::hmatrix, model::ljr ----------- */
+
+/* compute_ivects(ils) (molint.F90:174-217): take hmatrix(:,:,ils) (column-major,
+ * 9 doubles, column k = cell vector k), rebuild the image vectors and mirror
+ * them on the device.  *nivect_out (may be NULL) receives nivect(ils). */
+int mw_set_cell(int ils, const double h[9], int *nivect_out);
+/* Copy out ivect(:,1:nivect,ils) (3 doubles each); returns nivect via *nivect_out. */
+int mw_get_ivects(int ils, double *out, int max_vectors, int *nivect_out);
+
+/* Mirror all positions of box ils: xyz = &ljr(1,1,1,ils), nwater x 3 AoS. */
+int mw_upload_positions(int ils, const double *xyz);
+int mw_download_positions(int ils, double *xyz);
+/* Mirror one molecule (trial move, silent revert: mc_moves.F90:1079,1186). */
+int mw_patch_position(int ils, int imol, const double r[3]);
+
+/* ---- compute_neighbours(ils) (molint.F90:501-559) -------------------------------- */
+
+/* Rebuild the Verlet list of box ils from the mirrored positions and image
+ * vectors: every (jmol, image) with |r_j + ivect - r_i|^2 < (1.18 rc)^2 except
+ * (j = i, central image), ordered j ascending then image ascending -- the same
+ * set in the same order as the reference.  Fails (nonzero) if any molecule has
+ * more than maxneigh entries (the reference overflows silently).
+ * min_nn / max_nn may be NULL. */
+int mw_build_neighbours(int ils, int *min_nn, int *max_nn);
+int mw_build_neighbours_batch(int first_ils, int count, int *min_nn, int *max_nn);
+/* Copy the list out in the reference's layout: nn(1:nwater), jn/vn(1:maxneigh,
+ * 1:nwater) (slot fastest), 1-based, unused slots 0.  Any pointer may be NULL. */
+int mw_get_neighbours(int ils, int *nn, int *jn, int *vn);
+
+/* ---- compute_model_energy(ils) (molint.F90:407-499) ------------------------------ */
+
+int mw_model_energy(int ils, double *e);
+/* Same for boxes first_ils .. first_ils+count-1 in one launch. */
+int mw_model_energy_batch(int first_ils, int count, double *e_out);
+/* In-range interaction counts of the last model-energy evaluation of box ils
+ * as the reference enumerates them: directed pairs (molint.F90:454) and
+ * i-centred triplets (molint.F90:477). */
+int mw_model_energy_counts(int ils, long long *npairs, long long *ntriplets);
+
+/* ---- compute_local_real_energy(imol, ils) (molint.F90:220-404) ------------------- */
+
+/* Local energy of molecule imol from the mirrored positions. */
+int mw_local_energy(int ils, int imol, double *e);
+/* The drop-in form: first mirror up to two host positions (the molecule being
+ * queried and the one queried just before it, whose host position may have
+ * been silently reverted), then evaluate -- one launch.  imol_prev <= 0 or
+ * r_prev == NULL skips the second patch. */
+int mw_local_energy_patched(int ils, int imol, const double r_imol[3],
+                            int imol_prev, const double r_prev[3], double *e);
+
+/* Batched single-move path: request m is (ils[m], imol[m]) and, if trial_xyz
+ * is not NULL, molecule imol[m] is evaluated AT trial_xyz[3m..3m+2] without
+ * changing the mirrored positions (what the old/new pair of
+ * mc_water_translation needs, mc_moves.F90:1010,1083). */
+int mw_local_energy_batch(int n, const int *ils, const int *imol,
+                          const double *trial_xyz, double *e_out);
+/* e_old[m] with the mirrored position, e_new[m] at the trial position. */
+int mw_delta_energy_batch(int n, const int *ils, const int *imol,
+                          const double *trial_xyz, double *e_old, double *e_new);
+
+/* ---- device-resident batch pipeline (what bench.py times) ------------------------ */
+/* Requests are staged once; launches are asynchronous on the engine's stream;
+ * results stay on the device until fetched. */
+int mw_moves_upload(int n, const int *ils, const int *imol, const double *trial_xyz);
+int mw_moves_launch(void);                       /* old + new local energies of every staged move */
+int mw_moves_fetch(double *e_old, double *e_new);
+int mw_model_energy_launch(int first_ils, int count);
+int mw_model_energy_fetch(int first_ils, int count, double *e_out);
+int mw_build_neighbours_launch(int first_ils, int count);
+int mw_sync(void);
+
+/* HIP-event timers on the engine's stream: slot in 0..15. */
+int mw_timer_start(int slot);
+int mw_timer_stop(int slot);
+int mw_timer_elapsed_ms(int slot, float *ms);    /* synchronises on the stop event */
+
+/* Device facts for bench.py: name, CU count, total global memory bytes. */
+int mw_device_info(char *name, int name_len, int *compute_units, long long *global_mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MW_ENERGY_H */

@@ -1,0 +1,52 @@
+"""Build libmw_hip.so (the C-ABI engine) in-tree with hipcc for gfx950.
+
+    python -m mc_water_ls_mw_amd.build [--force]
+
+hipcc cross-compiles gfx950 without a GPU, so this also runs in the build
+container.  The .so stays inside the package directory (git-ignored, but it
+travels to the GPU box with the gpurun snapshot).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libmw_hip.so")
+SOURCES = [os.path.join(CSRC, "mw_api.hip")]
+DEPS = SOURCES + [os.path.join(CSRC, "mw_kernels.hip.h"),
+                  os.path.join(os.path.dirname(PKG), "include", "mw_energy.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm is required to build libmw_hip.so)")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in DEPS)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-o", LIB, *SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB)

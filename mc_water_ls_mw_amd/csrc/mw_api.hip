@@ -1,0 +1,563 @@
+// mw_api.hip -- the C ABI of libmw_hip.so (include/mw_energy.h): context, device
+// mirrors of the host's model::ljr / model::hmatrix, launch logic.
+//
+// Host-side state mirrors what the reference's `module energy` keeps
+// (molint.F90:41-45,79-81): nivect/ivect per box, the neighbour list, and the
+// energies of the last evaluation.  There is no CPU compute path here: every
+// energy and every list comes from the gfx950 kernels in mw_kernels.hip.h.
+#include "mw_kernels.hip.h"
+#include "../../include/mw_energy.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIPCHK(call)                                                                             \
+    do {                                                                                         \
+        hipError_t err__ = (call);                                                               \
+        if (err__ != hipSuccess)                                                                 \
+            return fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int kTimerSlots = 16;
+constexpr int kLdsBudget = 160 * 1024 - 2048;   // leave room for the static reduction arrays
+
+struct Ctx {
+    bool live = false;
+    int device = 0, N = 0, nbox = 0, S = 0, ivcap = 0;
+    int cu = 0, nsplit_max = 0;
+    hipStream_t stream = nullptr;
+    double* d_pos = nullptr;
+    double* d_ivect = nullptr;
+    int* d_nivect = nullptr;
+    uint32_t* d_list = nullptr;
+    int* d_nn = nullptr;
+    int* d_stats = nullptr;
+    double* d_partial = nullptr;
+    unsigned long long* d_cpartial = nullptr;
+    double* d_energy = nullptr;
+    unsigned long long* d_counts = nullptr;
+    // staged moves
+    int mcap = 0, mn = 0;
+    int *d_mbox = nullptr, *d_mimol = nullptr;
+    double *d_mtrial = nullptr, *d_meold = nullptr, *d_menew = nullptr;
+    // pinned, device-visible scratch for single results
+    double* h_pin = nullptr;
+    double* d_pin = nullptr;
+    // host mirrors
+    std::vector<double> h_ivect;   // nbox * ivcap * 3
+    std::vector<int> h_nivect;     // nbox
+    hipEvent_t ev[kTimerSlots][2] = {};
+};
+
+Ctx g;
+
+bool lds_fits(int N, int ivcap) { return (size_t)(3 * (size_t)N + 3 * (size_t)ivcap) * sizeof(double) <= (size_t)kLdsBudget; }
+
+int check_live() { return g.live ? 0 : fail("mw: engine not initialised (call mw_init / energy_init first)"); }
+int check_box(int ils) { return (ils >= 1 && ils <= g.nbox) ? 0 : fail("mw: box index %d outside 1..%d", ils, g.nbox); }
+int check_range(int first, int count)
+{
+    return (first >= 1 && count >= 1 && first + count - 1 <= g.nbox)
+               ? 0 : fail("mw: box range %d..%d outside 1..%d", first, first + count - 1, g.nbox);
+}
+int check_mol(int imol) { return (imol >= 1 && imol <= g.N) ? 0 : fail("mw: molecule index %d outside 1..%d", imol, g.N); }
+
+// Image vectors exactly as compute_ivects builds them (molint.F90:174-217):
+// central cell first, then icell, jcell, kcell loops (kcell fastest), (sx+sy)+sz.
+int host_ivects(const double h[9], std::vector<double>& out)
+{
+    const double* h1 = h; const double* h2 = h + 3; const double* h3 = h + 6;
+    const double rc = mw::kSmallA * mw::kSigma;
+    const int im = (int)std::floor(rc / std::sqrt(h1[0] * h1[0] + h1[1] * h1[1] + h1[2] * h1[2])) + 1;   // :189
+    const int jm = (int)std::floor(rc / std::sqrt(h2[0] * h2[0] + h2[1] * h2[1] + h2[2] * h2[2])) + 1;
+    const int km = (int)std::floor(rc / std::sqrt(h3[0] * h3[0] + h3[1] * h3[1] + h3[2] * h3[2])) + 1;
+    const long long n = (long long)(2 * im + 1) * (2 * jm + 1) * (2 * km + 1);                            // :193
+    if (n > MW_MAX_IVECT) return -1;
+    out.assign((size_t)n * 3, 0.0);                                                                       // :197
+    size_t k = 1;
+    for (int ic = -im; ic <= im; ++ic) {
+        const double sx[3] = {(double)ic * h1[0], (double)ic * h1[1], (double)ic * h1[2]};               // :201
+        for (int jc = -jm; jc <= jm; ++jc) {
+            const double sy[3] = {(double)jc * h2[0], (double)jc * h2[1], (double)jc * h2[2]};           // :203
+            for (int kc = -km; kc <= km; ++kc) {
+                if (ic == 0 && jc == 0 && kc == 0) continue;                                             // :207
+                const double sz[3] = {(double)kc * h3[0], (double)kc * h3[1], (double)kc * h3[2]};       // :205
+                for (int d = 0; d < 3; ++d) {
+                    volatile double s = sx[d] + sy[d];   // keep (sx+sy)+sz unfused and in this order     :208
+                    out[3 * k + d] = s + sz[d];
+                }
+                ++k;
+            }
+        }
+    }
+    return (int)n;
+}
+
+int grow_ivcap(int need)
+{
+    int cap = g.ivcap;
+    while (cap < need) cap *= 2;
+    if (cap > MW_MAX_IVECT) cap = MW_MAX_IVECT;
+    std::vector<double> nh((size_t)g.nbox * cap * 3, 0.0);
+    for (int b = 0; b < g.nbox; ++b)
+        std::memcpy(&nh[(size_t)b * cap * 3], &g.h_ivect[(size_t)b * g.ivcap * 3], sizeof(double) * 3 * g.ivcap);
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipFree(g.d_ivect));
+    HIPCHK(hipMalloc(&g.d_ivect, nh.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(g.d_ivect, nh.data(), nh.size() * sizeof(double), hipMemcpyHostToDevice));
+    g.h_ivect.swap(nh);
+    g.ivcap = cap;
+    return 0;
+}
+
+int ensure_moves(int n)
+{
+    if (n <= g.mcap) return 0;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    if (g.d_mbox) { hipFree(g.d_mbox); hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); }
+    int cap = 1024;
+    while (cap < n) cap *= 2;
+    HIPCHK(hipMalloc(&g.d_mbox, sizeof(int) * cap));
+    HIPCHK(hipMalloc(&g.d_mimol, sizeof(int) * cap));
+    HIPCHK(hipMalloc(&g.d_mtrial, sizeof(double) * 3 * cap));
+    HIPCHK(hipMalloc(&g.d_meold, sizeof(double) * cap));
+    HIPCHK(hipMalloc(&g.d_menew, sizeof(double) * cap));
+    g.mcap = cap;
+    return 0;
+}
+
+// Launch geometry of the full-box kernel for `count` boxes.
+struct Geo { bool lds; int block, nsplit, chunk; size_t shmem; };
+Geo model_geo(int count)
+{
+    Geo ge;
+    ge.lds = lds_fits(g.N, g.ivcap);
+    if (ge.lds) {
+        // one workgroup stages the whole box; split a box over several workgroups only
+        // when there are too few boxes to occupy the 256 CUs
+        ge.block = 1024;
+        int want = (2 * g.cu + count - 1) / count;
+        int maxsplit = (g.N + ge.block - 1) / ge.block;
+        ge.nsplit = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
+        ge.shmem = (size_t)(3 * (size_t)g.N + 3 * (size_t)g.ivcap) * sizeof(double);
+    } else {
+        ge.block = 256;
+        ge.nsplit = (g.N + ge.block - 1) / ge.block;
+        ge.shmem = (size_t)(3 * (size_t)g.ivcap) * sizeof(double);
+    }
+    if (ge.nsplit > g.nsplit_max) ge.nsplit = g.nsplit_max;
+    ge.chunk = (g.N + ge.nsplit - 1) / ge.nsplit;
+    return ge;
+}
+
+int launch_model_energy(int first, int count)
+{
+    const Geo ge = model_geo(count);
+    dim3 grid(ge.nsplit, count);
+    const int box0 = first - 1;
+    if (ge.lds)
+        hipLaunchKernelGGL((mw::k_model_energy<true, 1024>), grid, dim3(1024), ge.shmem, g.stream, g.d_pos, g.d_ivect,
+                           g.d_nivect, g.d_list, g.d_nn, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
+    else
+        hipLaunchKernelGGL((mw::k_model_energy<false, 256>), grid, dim3(256), ge.shmem, g.stream, g.d_pos, g.d_ivect,
+                           g.d_nivect, g.d_list, g.d_nn, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
+    HIPCHK(hipGetLastError());
+    // the partials of box b live at [b*nsplit .. b*nsplit+nsplit): same nsplit in both kernels
+    hipLaunchKernelGGL(mw::k_sum_partials, dim3((count + 255) / 256), dim3(256), 0, g.stream, g.d_partial, g.d_cpartial,
+                       g.d_energy, g.d_counts, box0, count, ge.nsplit);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_build(int first, int count)
+{
+    const int box0 = first - 1;
+    // stats: {min, max} per box
+    std::vector<int> init((size_t)count * 2);
+    for (int b = 0; b < count; ++b) { init[2 * b] = 0x7fffffff; init[2 * b + 1] = 0; }
+    HIPCHK(hipMemcpyAsync(g.d_stats + 2 * box0, init.data(), sizeof(int) * 2 * count, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));   // `init` is pageable: make sure it was consumed
+    dim3 grid((g.N + 255) / 256, count);
+    hipLaunchKernelGGL(mw::k_build_neighbours, grid, dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_nivect, g.d_list,
+                       g.d_nn, g.d_stats, g.N, g.S, g.ivcap, box0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int finish_build(int first, int count, int* min_nn, int* max_nn)
+{
+    std::vector<int> st((size_t)count * 2);
+    HIPCHK(hipMemcpyAsync(st.data(), g.d_stats + 2 * (first - 1), sizeof(int) * 2 * count, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    int mn = 0x7fffffff, mx = 0, worst = -1;
+    for (int b = 0; b < count; ++b) {
+        if (st[2 * b] < mn) mn = st[2 * b];
+        if (st[2 * b + 1] > mx) { mx = st[2 * b + 1]; worst = first + b; }
+    }
+    if (min_nn) *min_nn = mn;
+    if (max_nn) *max_nn = mx;
+    if (mx > g.S)
+        return fail("mw: neighbour list overflow in box %d: a molecule has %d entries, maxneigh = %d", worst, mx, g.S);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mw_last_error(void) { return g_err.c_str(); }
+
+int mw_is_initialised(void) { return g.live ? 1 : 0; }
+
+int mw_constants(double out[8])
+{
+    out[0] = mw::kSigma; out[1] = mw::kEpsilon; out[2] = mw::kLambda; out[3] = mw::kBigA;
+    out[4] = mw::kBigB;  out[5] = mw::kGamma;   out[6] = mw::kSmallA; out[7] = mw::kCos0;
+    return 0;
+}
+
+int mw_init(int device, int nwater, int nboxes, int maxneigh)
+{
+    if (g.live) return fail("mw_init: already initialised (call mw_finalize first)");
+    if (nwater < 1 || nboxes < 1) return fail("mw_init: nwater = %d, nboxes = %d must be positive", nwater, nboxes);
+    if (nwater > (1 << mw::kJBits)) return fail("mw_init: nwater = %d exceeds the %d-bit packed index", nwater, mw::kJBits);
+    if (maxneigh < 1 || maxneigh > MW_MAXNEIGH_LIMIT)
+        return fail("mw_init: maxneigh = %d outside 1..%d", maxneigh, MW_MAXNEIGH_LIMIT);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail("mw_init: no HIP device available (%s); this engine has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail("mw_init: device %d outside 0..%d", device, ndev - 1);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail("mw_init: device %d is %s; libmw_hip.so carries gfx950 code only", device, prop.gcnArchName);
+
+    g = Ctx();
+    g.device = device; g.N = nwater; g.nbox = nboxes; g.S = maxneigh; g.ivcap = 32;
+    g.cu = prop.multiProcessorCount;
+    g.nsplit_max = (nwater + 255) / 256;
+    HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    const size_t nb = (size_t)nboxes, N = (size_t)nwater;
+    HIPCHK(hipMalloc(&g.d_pos, nb * N * 3 * sizeof(double)));
+    HIPCHK(hipMalloc(&g.d_ivect, nb * g.ivcap * 3 * sizeof(double)));
+    HIPCHK(hipMalloc(&g.d_nivect, nb * sizeof(int)));
+    HIPCHK(hipMalloc(&g.d_list, nb * N * (size_t)maxneigh * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&g.d_nn, nb * N * sizeof(int)));
+    HIPCHK(hipMalloc(&g.d_stats, nb * 2 * sizeof(int)));
+    HIPCHK(hipMalloc(&g.d_partial, nb * g.nsplit_max * sizeof(double)));
+    HIPCHK(hipMalloc(&g.d_cpartial, nb * g.nsplit_max * 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&g.d_energy, nb * sizeof(double)));
+    HIPCHK(hipMalloc(&g.d_counts, nb * 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(g.d_pos, 0, nb * N * 3 * sizeof(double)));
+    HIPCHK(hipMemset(g.d_ivect, 0, nb * g.ivcap * 3 * sizeof(double)));
+    HIPCHK(hipMemset(g.d_nivect, 0, nb * sizeof(int)));
+    HIPCHK(hipMemset(g.d_nn, 0, nb * N * sizeof(int)));
+    HIPCHK(hipMemset(g.d_list, 0, nb * N * (size_t)maxneigh * sizeof(uint32_t)));
+    HIPCHK(hipMemset(g.d_energy, 0, nb * sizeof(double)));
+    HIPCHK(hipMemset(g.d_counts, 0, nb * 2 * sizeof(unsigned long long)));
+    HIPCHK(hipHostMalloc(&g.h_pin, 4096, hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void**)&g.d_pin, g.h_pin, 0));
+    g.h_ivect.assign(nb * g.ivcap * 3, 0.0);
+    g.h_nivect.assign(nb, 0);
+    for (int s = 0; s < kTimerSlots; ++s) {
+        HIPCHK(hipEventCreate(&g.ev[s][0]));
+        HIPCHK(hipEventCreate(&g.ev[s][1]));
+    }
+    // the LDS-staged kernel asks for more than the default 64 KiB of dynamic LDS
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_model_energy<true, 1024>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    g.live = true;
+    return 0;
+}
+
+int mw_finalize(void)
+{
+    if (!g.live) return 0;
+    hipSetDevice(g.device);
+    hipStreamSynchronize(g.stream);
+    hipFree(g.d_pos); hipFree(g.d_ivect); hipFree(g.d_nivect); hipFree(g.d_list); hipFree(g.d_nn); hipFree(g.d_stats);
+    hipFree(g.d_partial); hipFree(g.d_cpartial); hipFree(g.d_energy); hipFree(g.d_counts);
+    if (g.d_mbox) { hipFree(g.d_mbox); hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); }
+    hipHostFree(g.h_pin);
+    for (int s = 0; s < kTimerSlots; ++s) { hipEventDestroy(g.ev[s][0]); hipEventDestroy(g.ev[s][1]); }
+    hipStreamDestroy(g.stream);
+    g = Ctx();
+    return 0;
+}
+
+int mw_device_info(char* name, int name_len, int* compute_units, long long* global_mem)
+{
+    if (check_live()) return 1;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, g.device));
+    if (name && name_len > 0) { std::strncpy(name, prop.name, (size_t)name_len - 1); name[name_len - 1] = 0; }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (global_mem) *global_mem = (long long)prop.totalGlobalMem;
+    return 0;
+}
+
+int mw_set_cell(int ils, const double h[9], int* nivect_out)
+{
+    if (check_live() || check_box(ils)) return 1;
+    std::vector<double> iv;
+    const int n = host_ivects(h, iv);
+    if (n < 0) return fail("mw_set_cell: cell of box %d is so small that it needs more than %d image vectors", ils, MW_MAX_IVECT);
+    if (n > g.ivcap && grow_ivcap(n)) return 1;
+    const size_t off = (size_t)(ils - 1) * g.ivcap * 3;
+    std::memcpy(&g.h_ivect[off], iv.data(), iv.size() * sizeof(double));
+    g.h_nivect[ils - 1] = n;
+    HIPCHK(hipMemcpyAsync(g.d_ivect + off, &g.h_ivect[off], iv.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.d_nivect + (ils - 1), &g.h_nivect[ils - 1], sizeof(int), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    if (nivect_out) *nivect_out = n;
+    return 0;
+}
+
+int mw_get_ivects(int ils, double* out, int max_vectors, int* nivect_out)
+{
+    if (check_live() || check_box(ils)) return 1;
+    const int n = g.h_nivect[ils - 1];
+    if (nivect_out) *nivect_out = n;
+    if (out) {
+        if (max_vectors < n) return fail("mw_get_ivects: buffer holds %d vectors, box %d has %d", max_vectors, ils, n);
+        std::memcpy(out, &g.h_ivect[(size_t)(ils - 1) * g.ivcap * 3], sizeof(double) * 3 * n);
+    }
+    return 0;
+}
+
+int mw_upload_positions(int ils, const double* xyz)
+{
+    if (check_live() || check_box(ils)) return 1;
+    if (!xyz) return fail("mw_upload_positions: null pointer");
+    const size_t bytes = (size_t)g.N * 3 * sizeof(double);
+    HIPCHK(hipMemcpyAsync(g.d_pos + (size_t)(ils - 1) * g.N * 3, xyz, bytes, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));   // the caller may overwrite ljr right after we return
+    return 0;
+}
+
+int mw_download_positions(int ils, double* xyz)
+{
+    if (check_live() || check_box(ils)) return 1;
+    const size_t bytes = (size_t)g.N * 3 * sizeof(double);
+    HIPCHK(hipMemcpyAsync(xyz, g.d_pos + (size_t)(ils - 1) * g.N * 3, bytes, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int mw_patch_position(int ils, int imol, const double r[3])
+{
+    if (check_live() || check_box(ils) || check_mol(imol)) return 1;
+    HIPCHK(hipMemcpyAsync(g.d_pos + ((size_t)(ils - 1) * g.N + (imol - 1)) * 3, r, 3 * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int mw_build_neighbours_launch(int first_ils, int count)
+{
+    if (check_live() || check_range(first_ils, count)) return 1;
+    for (int b = first_ils; b < first_ils + count; ++b)
+        if (g.h_nivect[b - 1] < 1) return fail("mw_build_neighbours: box %d has no cell yet (call mw_set_cell / compute_ivects)", b);
+    return launch_build(first_ils, count);
+}
+
+int mw_build_neighbours_batch(int first_ils, int count, int* min_nn, int* max_nn)
+{
+    if (mw_build_neighbours_launch(first_ils, count)) return 1;
+    return finish_build(first_ils, count, min_nn, max_nn);
+}
+
+int mw_build_neighbours(int ils, int* min_nn, int* max_nn) { return mw_build_neighbours_batch(ils, 1, min_nn, max_nn); }
+
+int mw_get_neighbours(int ils, int* nn, int* jn, int* vn)
+{
+    if (check_live() || check_box(ils)) return 1;
+    const size_t N = (size_t)g.N, S = (size_t)g.S;
+    std::vector<int> hnn(N);
+    std::vector<uint32_t> hl(N * S);
+    HIPCHK(hipMemcpyAsync(hnn.data(), g.d_nn + (size_t)(ils - 1) * N, N * sizeof(int), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(hl.data(), g.d_list + (size_t)(ils - 1) * N * S, N * S * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (size_t i = 0; i < N; ++i) {
+        if (nn) nn[i] = hnn[i];
+        for (size_t s = 0; s < S; ++s) {
+            const bool used = (int)s < hnn[i];
+            const uint32_t e = hl[s * N + i];                      // device layout is slot-major
+            if (jn) jn[i * S + s] = used ? (int)(e & mw::kJMask) + 1 : 0;   // reference layout jn(slot, imol)
+            if (vn) vn[i * S + s] = used ? (int)(e >> mw::kJBits) + 1 : 0;
+        }
+    }
+    return 0;
+}
+
+int mw_model_energy_launch(int first_ils, int count)
+{
+    if (check_live() || check_range(first_ils, count)) return 1;
+    return launch_model_energy(first_ils, count);
+}
+
+int mw_model_energy_fetch(int first_ils, int count, double* e_out)
+{
+    if (check_live() || check_range(first_ils, count)) return 1;
+    HIPCHK(hipMemcpyAsync(e_out, g.d_energy + (first_ils - 1), sizeof(double) * count, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int mw_model_energy_batch(int first_ils, int count, double* e_out)
+{
+    if (mw_model_energy_launch(first_ils, count)) return 1;
+    return mw_model_energy_fetch(first_ils, count, e_out);
+}
+
+int mw_model_energy(int ils, double* e) { return mw_model_energy_batch(ils, 1, e); }
+
+int mw_model_energy_counts(int ils, long long* npairs, long long* ntriplets)
+{
+    if (check_live() || check_box(ils)) return 1;
+    unsigned long long c[2];
+    HIPCHK(hipMemcpyAsync(c, g.d_counts + 2 * (size_t)(ils - 1), sizeof c, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    if (npairs) *npairs = (long long)c[0];
+    if (ntriplets) *ntriplets = (long long)c[1];
+    return 0;
+}
+
+int mw_local_energy_patched(int ils, int imol, const double r_imol[3], int imol_prev, const double r_prev[3], double* e)
+{
+    if (check_live() || check_box(ils) || check_mol(imol)) return 1;
+    mw::Override o1, o2;
+    o1.idx = -1; o1.x = o1.y = o1.z = 0.0;
+    o2 = o1;
+    if (r_imol) { o1.idx = imol - 1; o1.x = r_imol[0]; o1.y = r_imol[1]; o1.z = r_imol[2]; }
+    if (r_prev && imol_prev >= 1 && imol_prev != imol) {
+        if (check_mol(imol_prev)) return 1;
+        o2.idx = imol_prev - 1; o2.x = r_prev[0]; o2.y = r_prev[1]; o2.z = r_prev[2];
+    }
+    hipLaunchKernelGGL(mw::k_local_energy_single, dim3(1), dim3(64), 0, g.stream, g.d_pos, g.d_ivect, g.d_list, g.d_nn,
+                       ils - 1, imol - 1, o1, o2, 1, g.d_pin, g.N, g.S, g.ivcap);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g.stream));
+    *e = g.h_pin[0];
+    return 0;
+}
+
+int mw_local_energy(int ils, int imol, double* e) { return mw_local_energy_patched(ils, imol, nullptr, 0, nullptr, e); }
+
+int mw_moves_upload(int n, const int* ils, const int* imol, const double* trial_xyz)
+{
+    if (check_live()) return 1;
+    if (n < 0) return fail("mw_moves_upload: n = %d", n);
+    g.mn = 0;
+    if (n == 0) return 0;
+    if (!ils || !imol) return fail("mw_moves_upload: null request arrays");
+    std::vector<int> b0((size_t)n), i0((size_t)n);
+    for (int m = 0; m < n; ++m) {
+        if (ils[m] < 1 || ils[m] > g.nbox) return fail("mw_moves_upload: request %d has box %d outside 1..%d", m, ils[m], g.nbox);
+        if (imol[m] < 1 || imol[m] > g.N) return fail("mw_moves_upload: request %d has molecule %d outside 1..%d", m, imol[m], g.N);
+        b0[m] = ils[m] - 1; i0[m] = imol[m] - 1;
+    }
+    if (ensure_moves(n)) return 1;
+    HIPCHK(hipMemcpyAsync(g.d_mbox, b0.data(), sizeof(int) * n, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.d_mimol, i0.data(), sizeof(int) * n, hipMemcpyHostToDevice, g.stream));
+    if (trial_xyz) HIPCHK(hipMemcpyAsync(g.d_mtrial, trial_xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    g.mn = n;
+    return 0;
+}
+
+static int launch_moves(int mode)
+{
+    if (g.mn == 0) return 0;
+    hipLaunchKernelGGL(mw::k_local_energy, dim3((g.mn + 3) / 4), dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_list, g.d_nn,
+                       g.d_mbox, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.mn, g.N, g.S, g.ivcap, mode);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int mw_moves_launch(void)
+{
+    if (check_live()) return 1;
+    return launch_moves(3);
+}
+
+int mw_moves_fetch(double* e_old, double* e_new)
+{
+    if (check_live()) return 1;
+    if (g.mn > 0) {
+        if (e_old) HIPCHK(hipMemcpyAsync(e_old, g.d_meold, sizeof(double) * g.mn, hipMemcpyDeviceToHost, g.stream));
+        if (e_new) HIPCHK(hipMemcpyAsync(e_new, g.d_menew, sizeof(double) * g.mn, hipMemcpyDeviceToHost, g.stream));
+    }
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int mw_local_energy_batch(int n, const int* ils, const int* imol, const double* trial_xyz, double* e_out)
+{
+    if (mw_moves_upload(n, ils, imol, trial_xyz)) return 1;
+    if (launch_moves(trial_xyz ? 2 : 1)) return 1;
+    return trial_xyz ? mw_moves_fetch(nullptr, e_out) : mw_moves_fetch(e_out, nullptr);
+}
+
+int mw_delta_energy_batch(int n, const int* ils, const int* imol, const double* trial_xyz, double* e_old, double* e_new)
+{
+    if (!trial_xyz) return fail("mw_delta_energy_batch: trial positions are required");
+    if (mw_moves_upload(n, ils, imol, trial_xyz)) return 1;
+    if (launch_moves(3)) return 1;
+    return mw_moves_fetch(e_old, e_new);
+}
+
+int mw_sync(void)
+{
+    if (check_live()) return 1;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int mw_timer_start(int slot)
+{
+    if (check_live()) return 1;
+    if (slot < 0 || slot >= kTimerSlots) return fail("mw_timer: slot %d outside 0..%d", slot, kTimerSlots - 1);
+    HIPCHK(hipEventRecord(g.ev[slot][0], g.stream));
+    return 0;
+}
+
+int mw_timer_stop(int slot)
+{
+    if (check_live()) return 1;
+    if (slot < 0 || slot >= kTimerSlots) return fail("mw_timer: slot %d outside 0..%d", slot, kTimerSlots - 1);
+    HIPCHK(hipEventRecord(g.ev[slot][1], g.stream));
+    return 0;
+}
+
+int mw_timer_elapsed_ms(int slot, float* ms)
+{
+    if (check_live()) return 1;
+    if (slot < 0 || slot >= kTimerSlots) return fail("mw_timer: slot %d outside 0..%d", slot, kTimerSlots - 1);
+    HIPCHK(hipEventSynchronize(g.ev[slot][1]));
+    HIPCHK(hipEventElapsedTime(ms, g.ev[slot][0], g.ev[slot][1]));
+    return 0;
+}
+
+}  // extern "C"

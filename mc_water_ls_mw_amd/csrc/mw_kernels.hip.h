@@ -1,0 +1,447 @@
+// mw_kernels.hip.h -- gfx950 (MI355X, CDNA4) device code of the mW energy engine.
+//
+// What each kernel stands behind in the reference (keb721/mc_water_ls_mw):
+//   k_build_neighbours  compute_neighbours       molint.F90:501-559
+//   k_model_energy      compute_model_energy     molint.F90:407-499
+//   k_local_energy      compute_local_real_energy molint.F90:220-404
+// None of it is a translation: the list is slot-major and packed for coalesced
+// reads, positions of a whole box are staged in LDS, the three-body sum is
+// evaluated from per-atom moments in O(neighbours), and the single-move path
+// maps one request onto one 64-wide wavefront.  Double precision throughout;
+// this is gather + transcendental work, so no MFMA.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mw {
+
+// ---- model constants (molint.F90:63-74, constants.f90:42-43) -----------------------
+constexpr double kAngToBohr = 1.0 / 0.5291772108;
+constexpr double kSigma     = 2.3925 * kAngToBohr;       // bohr
+constexpr double kEpsilon   = 6.189 / 627.509469;        // Hartree
+constexpr double kLambda    = 23.15;
+constexpr double kBigA      = 7.049556277;
+constexpr double kBigB      = 0.6022245584;
+constexpr double kGamma     = 1.2;
+constexpr double kSmallA    = 1.8;
+// molint.F90:74 has no _dp suffix: the reference holds float32(-0.33331324756) widened
+constexpr double kCos0      = (double)(-0.33331324756f);
+constexpr double kSigA      = kSigma * kSmallA;                       // rc = a*sigma
+constexpr double kRcSq      = kSigma * kSmallA * kSigma * kSmallA;    // molint.F90:255,432 order
+constexpr double kRn        = kSmallA * kSigma * 1.18;                // molint.F90:516
+constexpr double kRnSq      = kRn * kRn;                              // molint.F90:537
+constexpr double kAeps      = kBigA * kEpsilon;
+constexpr double kLamEps    = kLambda * kEpsilon;
+constexpr double kGamSig    = kGamma * kSigma;
+constexpr double kSigSq     = kSigma * kSigma;
+
+// ---- packed list entry: (jmol-1) in the low 22 bits, (image-1) in the next 10 -------
+constexpr int      kJBits = 22;
+constexpr uint32_t kJMask = (1u << kJBits) - 1u;
+
+__device__ __forceinline__ uint32_t pack_entry(int j0, int k0) { return (uint32_t)j0 | ((uint32_t)k0 << kJBits); }
+
+// ---- wave / block reductions ---------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;   // valid in lane 0
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_down(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+// =====================================================================================
+// Neighbour list, brute force over (j, image): the reference's own enumeration
+// order (j ascending, image ascending) falls out of the loop nest, so the list is
+// identical entry for entry.  r_j and the image vector are wave-uniform (scalar
+// registers); only r_i and the running count live in vector registers.
+// The distance arithmetic is kept unfused (no FMA contraction) so that the
+// in/out decision at the list radius is bit-identical to the reference's
+// molint.F90:529-537 evaluated on a CPU without FMA.
+//   grid = (ceil(N/256), nboxes_in_launch), block = 256
+// =====================================================================================
+__global__ __launch_bounds__(256)
+void k_build_neighbours(const double* __restrict__ pos, const double* __restrict__ ivect,
+                        const int* __restrict__ nivect, uint32_t* __restrict__ list,
+                        int* __restrict__ nn, int* __restrict__ stats,
+                        int N, int S, int ivcap, int box0)
+{
+#pragma clang fp contract(off)
+    const int b = box0 + blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const double* P  = pos + (size_t)b * N * 3;
+    const double* IV = ivect + (size_t)b * ivcap * 3;
+    const int niv = nivect[b];
+    uint32_t* L = list + (size_t)b * S * N;
+    const bool active = i < N;
+    const int ii = active ? i : 0;
+    const double xi = P[3 * ii], yi = P[3 * ii + 1], zi = P[3 * ii + 2];   // molint.F90:522
+    int cnt = 0;
+
+    for (int j = 0; j < N; ++j) {                                           // :525
+        const double vx = P[3 * j] - xi, vy = P[3 * j + 1] - yi, vz = P[3 * j + 2] - zi;   // :529
+        for (int k = 0; k < niv; ++k) {                                     // :531
+            const double tx = vx + IV[3 * k], ty = vy + IV[3 * k + 1], tz = vz + IV[3 * k + 2];   // :534
+            const double r2 = tx * tx + ty * ty + tz * tz;                  // :535
+            if (r2 < kRnSq && !(k == 0 && j == i)) {                        // :532,537
+                if (active && cnt < S) L[(size_t)cnt * N + i] = pack_entry(j, k);
+                ++cnt;
+            }
+        }
+    }
+    if (active) nn[(size_t)b * N + i] = cnt < S ? cnt : S;
+
+    // per-box statistics: min nn, max nn (max > S means overflow)
+    int mn = wave_min_i(active ? cnt : 0x7fffffff);
+    int mx = wave_max_i(active ? cnt : 0);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&stats[2 * b], mn);
+        atomicMax(&stats[2 * b + 1], mx);
+    }
+}
+
+// =====================================================================================
+// Full-box energy.
+//
+// Per atom i with in-range neighbours j (r_ij < rc), unit vectors u_j, weights
+// g_j = exp(gamma*sigma/(r_ij - a*sigma)):
+//   E_i = 1/2 sum_j phi2(r_ij) + lambda*eps * sum_{j<k} g_j g_k (u_j.u_k - cos0)^2
+// The reference walks all pairs j<k (molint.F90:467-487).  Here the triplet sum
+// comes from moments accumulated in ONE pass over the neighbours:
+//   S0 = sum g, S1 = sum g u, S2 = sum g u u^T, Q = sum g^2
+//   sum_{j<k} g_j g_k (c_jk - c0)^2 = 1/2 [ (|S2|_F^2 - Q) - 2 c0 (|S1|^2 - Q) + c0^2 (S0^2 - Q) ]
+// (c_jj = 1 gives the three Q terms).  No per-neighbour storage, so nothing
+// spills and the loop is O(neighbours).  Cancellation is harmless at this
+// tolerance: the terms are O(S0^2) ~ 0.4 while the parity bar is 1e-10 relative
+// on E_i ~ 2e-2 -- fourteen digits are left over.
+//
+// Both exponentials of a pair come from one: with t = exp(0.2*sigma/(r - a*sigma)),
+// exp(sigma/(r-a sigma)) = t^5 and g = exp(1.2 sigma/(r - a sigma)) = t^6.
+//
+// Divergence control: phase 1 runs the cheap distance test over all list slots
+// and records the in-range slots in a 64-bit mask; phase 2 runs the expensive
+// part only over set bits, so a wave's trip count is its largest in-range count
+// (4-12) rather than its largest list length (16-25).
+//
+// LDSPOS = true : one workgroup stages the whole box's positions in LDS
+//                 (N*24 B: 96 KiB at N = 4096) and gathers r_j from there.
+// LDSPOS = false: r_j gathered from global memory (L2-resident for the sizes
+//                 that do not fit LDS, e.g. 786 KiB at N = 32768).
+//   grid = (nsplit, nboxes_in_launch); each block takes atoms [split*chunk, ...)
+// =====================================================================================
+struct AtomSum { double e; unsigned long long np, nt; };
+
+template <typename PosFn, typename IvFn>
+__device__ __forceinline__ AtomSum atom_energy(int i, int n, const uint32_t* __restrict__ L, int N,
+                                               PosFn getpos, IvFn getiv)
+{
+    double xi, yi, zi;
+    getpos(i, xi, yi, zi);
+
+    // phase 1: which list slots are within rc
+    unsigned long long mask = 0ull;
+    for (int s = 0; s < n; ++s) {
+        const uint32_t e = L[(size_t)s * N + i];
+        double xj, yj, zj, ix, iy, iz;
+        getpos((int)(e & kJMask), xj, yj, zj);
+        getiv((int)(e >> kJBits), ix, iy, iz);
+        const double dx = (xj + ix) - xi, dy = (yj + iy) - yi, dz = (zj + iz) - zi;   // molint.F90:447,450
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        if (r2 < kRcSq) mask |= (1ull << s);                                          // :454
+    }
+
+    // phase 2: pair term and moments over the in-range slots only
+    double e2 = 0.0, S0 = 0.0, Q = 0.0, S1x = 0.0, S1y = 0.0, S1z = 0.0;
+    double Sxx = 0.0, Syy = 0.0, Szz = 0.0, Sxy = 0.0, Sxz = 0.0, Syz = 0.0;
+    const int cnt = __popcll(mask);
+    while (mask) {
+        const int s = __ffsll((long long)mask) - 1;
+        mask &= mask - 1ull;
+        const uint32_t e = L[(size_t)s * N + i];
+        double xj, yj, zj, ix, iy, iz;
+        getpos((int)(e & kJMask), xj, yj, zj);
+        getiv((int)(e >> kJBits), ix, iy, iz);
+        const double dx = (xj + ix) - xi, dy = (yj + iy) - yi, dz = (zj + iz) - zi;
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        const double rinv = 1.0 / sqrt(r2);
+        const double r = r2 * rinv;
+        const double den = r - kSigA;               // < 0 inside the cutoff
+        // r2 < rc^2 but r rounded onto rc: the pair's energy is exactly 0 in the limit
+        const double w = den < 0.0 ? 1.0 / den : -1.0e300;
+        const double t = exp(0.2 * kSigma * w);
+        const double t2 = t * t, t4 = t2 * t2;
+        const double e1 = t4 * t;                   // exp(sigma/(r - a sigma))       :459
+        const double g  = t4 * t2;                  // exp(gamma sigma/(r - a sigma)) :462
+        const double q = kSigSq * rinv * rinv;
+        e2 += (kAeps * (kBigB * (q * q) - 1.0)) * e1;                                 // :460-461
+        const double ux = dx * rinv, uy = dy * rinv, uz = dz * rinv;
+        const double gx = g * ux, gy = g * uy, gz = g * uz;
+        S0 += g;  Q += g * g;
+        S1x += gx; S1y += gy; S1z += gz;
+        Sxx += gx * ux; Syy += gy * uy; Szz += gz * uz;
+        Sxy += gx * uy; Sxz += gx * uz; Syz += gy * uz;
+    }
+    const double F2 = Sxx * Sxx + Syy * Syy + Szz * Szz + 2.0 * (Sxy * Sxy + Sxz * Sxz + Syz * Syz);
+    const double F1 = S1x * S1x + S1y * S1y + S1z * S1z;
+    const double T = 0.5 * ((F2 - Q) - 2.0 * kCos0 * (F1 - Q) + kCos0 * kCos0 * (S0 * S0 - Q));
+    AtomSum out;
+    out.e  = 0.5 * e2 + kLamEps * T;                                                   // :464,483
+    out.np = (unsigned long long)cnt;
+    out.nt = (unsigned long long)(cnt * (cnt - 1) / 2);
+    return out;
+}
+
+template <bool LDSPOS, int BLOCK>
+__global__ __launch_bounds__(BLOCK)
+void k_model_energy(const double* __restrict__ pos, const double* __restrict__ ivect,
+                    const int* __restrict__ nivect, const uint32_t* __restrict__ list,
+                    const int* __restrict__ nn, double* __restrict__ partial,
+                    unsigned long long* __restrict__ cpartial,
+                    int N, int S, int ivcap, int box0, int nsplit, int chunk)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double red_e[BLOCK / 64];
+    __shared__ unsigned long long red_p[BLOCK / 64], red_t[BLOCK / 64];
+
+    const int b = box0 + blockIdx.y;
+    const int split = blockIdx.x;
+    const int tid = threadIdx.x;
+    const double* P  = pos + (size_t)b * N * 3;
+    const double* IV = ivect + (size_t)b * ivcap * 3;
+    const uint32_t* L = list + (size_t)b * S * N;
+    const int* NN = nn + (size_t)b * N;
+    const int niv = nivect[b];
+
+    double* siv = smem;                         // niv*3 doubles (ivcap*3 reserved)
+    double* spos = smem + (size_t)ivcap * 3;    // 3N doubles when LDSPOS
+    for (int t = tid; t < niv * 3; t += BLOCK) siv[t] = IV[t];
+    if (LDSPOS) {
+        for (int t = tid; t < 3 * N; t += BLOCK) spos[t] = P[t];   // flat, fully coalesced copy
+    }
+    __syncthreads();
+
+    auto getiv = [&](int k, double& x, double& y, double& z) { x = siv[3 * k]; y = siv[3 * k + 1]; z = siv[3 * k + 2]; };
+    auto getpos = [&](int j, double& x, double& y, double& z) {
+        const double* p = LDSPOS ? (spos + 3 * (size_t)j) : (P + 3 * (size_t)j);
+        x = p[0]; y = p[1]; z = p[2];
+    };
+
+    double esum = 0.0;
+    unsigned long long np = 0, nt = 0;
+    const int a0 = split * chunk;
+    const int a1 = min(N, a0 + chunk);
+    for (int i = a0 + tid; i < a1; i += BLOCK) {
+        AtomSum a = atom_energy(i, NN[i], L, N, getpos, getiv);
+        esum += a.e; np += a.np; nt += a.nt;
+    }
+
+    esum = wave_sum(esum); np = wave_sum_u64(np); nt = wave_sum_u64(nt);
+    const int wid = tid >> 6;
+    if ((tid & 63) == 0) { red_e[wid] = esum; red_p[wid] = np; red_t[wid] = nt; }
+    __syncthreads();
+    if (tid == 0) {
+        double e = 0.0; unsigned long long p = 0, t = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) { e += red_e[w]; p += red_p[w]; t += red_t[w]; }
+        const size_t o = (size_t)(b) * nsplit + split;
+        partial[o] = e; cpartial[2 * o] = p; cpartial[2 * o + 1] = t;
+    }
+}
+
+// Fixed-order sum of the per-block partials: model_energy(ils) and its counts.
+__global__ void k_sum_partials(const double* __restrict__ partial, const unsigned long long* __restrict__ cpartial,
+                               double* __restrict__ energy, unsigned long long* __restrict__ counts,
+                               int box0, int count, int nsplit)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int b = box0 + t;
+    double e = 0.0; unsigned long long p = 0, q = 0;
+    for (int s = 0; s < nsplit; ++s) {
+        const size_t o = (size_t)b * nsplit + s;
+        e += partial[o]; p += cpartial[2 * o]; q += cpartial[2 * o + 1];
+    }
+    energy[b] = e; counts[2 * b] = p; counts[2 * b + 1] = q;
+}
+
+// =====================================================================================
+// Local energy of one molecule = every pair and every triplet it takes part in
+// (as centre or as end), the building block of a single-move Delta E.
+// One 64-wide wavefront per request; lane l owns slot l of a neighbour list
+// (maxneigh <= 64).  Pass 0: the lanes hold imol's own list and evaluate the pair
+// term and g for the in-range lanes.  Then for every in-range j (a wave-uniform
+// loop over the ballot mask):
+//   * j--i--k triplets: lanes above j that are in range combine with j's
+//     broadcast vector (molint.F90:302-318: the remaining entries of imol's list);
+//   * i--j--k triplets: the lanes re-load jmol's list, shifted by j's image
+//     (molint.F90:324-343), and each evaluates its k.
+// A slot whose cos(theta) >= 0.99 contributes 0 (molint.F90:367-371; this is how
+// the k == i self term drops out) and so does an out-of-range slot (G2).
+//
+// A request may carry up to two position overrides {index, xyz}: the molecule
+// itself at a trial position, and (single-call drop-in path) the previously
+// queried molecule whose host copy may have been reverted.  Overrides are used
+// from registers wherever that index is gathered; with `commit` they are also
+// written to the mirrored positions for later launches.
+//   grid = ceil(nreq/4), block = 256 (4 requests per block)
+// =====================================================================================
+struct Override { int idx; double x, y, z; };   // idx < 0: none (0-based molecule index)
+
+__device__ __forceinline__ void load_pos(const double* __restrict__ P, int j, const Override& o1, const Override& o2,
+                                         double& x, double& y, double& z)
+{
+    const double* p = P + 3 * (size_t)j;
+    x = p[0]; y = p[1]; z = p[2];
+    if (j == o1.idx) { x = o1.x; y = o1.y; z = o1.z; }
+    if (j == o2.idx) { x = o2.x; y = o2.y; z = o2.z; }
+}
+
+__device__ __forceinline__ void pair_terms(double r2, double& rinv, double& e1, double& g)
+{
+    rinv = 1.0 / sqrt(r2);                       // molint.F90:278
+    const double r = r2 * rinv;                  // :286
+    const double den = r - kSigA;
+    const double w = den < 0.0 ? 1.0 / den : -1.0e300;   // :288 (guard: see k_model_energy)
+    const double t = exp(0.2 * kSigma * w);
+    const double t2 = t * t, t4 = t2 * t2;
+    e1 = t4 * t;                                 // :291
+    g  = t4 * t2;                                // :292
+}
+
+// Returns the local energy in every lane.
+__device__ __forceinline__ double local_energy_wave(const double* __restrict__ P, const double* __restrict__ IV,
+                                                    const uint32_t* __restrict__ L, const int* __restrict__ NN,
+                                                    int N, int i, const Override& o1, const Override& o2, int lane)
+{
+    double xi, yi, zi;
+    load_pos(P, i, o1, o2, xi, yi, zi);                                   // molint.F90:258
+    const int n_i = NN[i];
+
+    // pass 0: imol's own list, one slot per lane
+    const bool has = lane < n_i;
+    const uint32_t e = has ? L[(size_t)lane * N + i] : 0u;
+    const int j = (int)(e & kJMask), kimg = (int)(e >> kJBits);
+    double xj, yj, zj;
+    load_pos(P, j, o1, o2, xj, yj, zj);
+    const double jvx = IV[3 * kimg], jvy = IV[3 * kimg + 1], jvz = IV[3 * kimg + 2];
+    const double qx = xj + jvx, qy = yj + jvy, qz = zj + jvz;             // :269 position of j's image
+    const double dx = qx - xi, dy = qy - yi, dz = qz - zi;                // :272
+    const double r2 = dx * dx + dy * dy + dz * dz;                        // :273
+    const bool inr = has && (r2 < kRcSq);                                 // :276
+    double rinv = 0.0, e1 = 0.0, g = 0.0;
+    if (inr) pair_terms(r2, rinv, e1, g);
+    const double q = kSigSq * rinv * rinv;
+    double acc2 = inr ? (kAeps * (kBigB * (q * q) - 1.0)) * e1 : 0.0;     // :294-297
+    double acc3 = 0.0;
+
+    unsigned long long mask = __ballot(inr);
+    while (mask) {                                                        // wave-uniform loop over in-range j
+        const int jl = __ffsll((long long)mask) - 1;
+        mask &= mask - 1ull;
+        const double ajx = __shfl(dx, jl, 64), ajy = __shfl(dy, jl, 64), ajz = __shfl(dz, jl, 64);
+        const double rinv_j = __shfl(rinv, jl, 64), g_j = __shfl(g, jl, 64);
+
+        // j--i--k: later in-range slots of imol's own list                 :302-318
+        if (inr && lane > jl) {
+            const double ct = ((ajx * dx + ajy * dy + ajz * dz) * rinv_j) * rinv;     // :316,365
+            if (ct < 0.99) { const double d = ct - kCos0; acc3 += g_j * (g * (d * d)); }   // :367-368,385-387
+        }
+
+        // i--j--k: jmol's list, translated by j's image                    :324-343
+        const int jj = __shfl(j, jl, 64);
+        const double sjx = __shfl(jvx, jl, 64), sjy = __shfl(jvy, jl, 64), sjz = __shfl(jvz, jl, 64);
+        const double pjx = __shfl(qx, jl, 64), pjy = __shfl(qy, jl, 64), pjz = __shfl(qz, jl, 64);
+        const int n_j = NN[jj];
+        if (lane < n_j) {
+            const uint32_t e2 = L[(size_t)lane * N + jj];
+            const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
+            double xk, yk, zk;
+            load_pos(P, kk, o1, o2, xk, yk, zk);
+            const double bx = ((xk + IV[3 * k2]) + sjx) - pjx;            // :332,334
+            const double by = ((yk + IV[3 * k2 + 1]) + sjy) - pjy;
+            const double bz = ((zk + IV[3 * k2 + 2]) + sjz) - pjz;
+            const double s2 = bx * bx + by * by + bz * bz;                // :335
+            if (s2 < kRcSq) {                                             // :361
+                double rinv_k, e1_k, g_k;
+                pair_terms(s2, rinv_k, e1_k, g_k);
+                const double ct = (-(ajx * bx + ajy * by + ajz * bz) * rinv_j) * rinv_k;   // :320,341,365
+                if (ct < 0.99) { const double d = ct - kCos0; acc3 += g_j * (g_k * (d * d)); }
+            }
+        }
+    }
+    double tot = acc2 + kLamEps * acc3;                                    // :397
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+    return tot;
+}
+
+// mode bit 0: evaluate with the mirrored positions (+ o2) -> e_old
+// mode bit 1: evaluate with the molecule at its trial position          -> e_new
+__global__ __launch_bounds__(256)
+void k_local_energy(const double* __restrict__ pos, const double* __restrict__ ivect,
+                    const uint32_t* __restrict__ list, const int* __restrict__ nn,
+                    const int* __restrict__ req_box, const int* __restrict__ req_imol,
+                    const double* __restrict__ req_trial,
+                    double* __restrict__ e_old, double* __restrict__ e_new,
+                    int nreq, int N, int S, int ivcap, int mode)
+{
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= nreq) return;                                   // wave-uniform
+    const int b = req_box[m];
+    const int i = req_imol[m];
+    const double* P  = pos + (size_t)b * N * 3;
+    const double* IV = ivect + (size_t)b * ivcap * 3;
+    const uint32_t* L = list + (size_t)b * S * N;
+    const int* NN = nn + (size_t)b * N;
+    Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
+    if (mode & 1) {
+        const double e = local_energy_wave(P, IV, L, NN, N, i, none, none, lane);
+        if (lane == 0) e_old[m] = e;
+    }
+    if (mode & 2) {
+        Override tr; tr.idx = i; tr.x = req_trial[3 * m]; tr.y = req_trial[3 * m + 1]; tr.z = req_trial[3 * m + 2];
+        const double e = local_energy_wave(P, IV, L, NN, N, i, tr, none, lane);
+        if (lane == 0) e_new[m] = e;
+    }
+}
+
+// Single request with by-value overrides (the drop-in compute_local_real_energy call):
+// one wave, result written straight to host-visible memory.
+__global__ __launch_bounds__(64)
+void k_local_energy_single(double* __restrict__ pos, const double* __restrict__ ivect,
+                           const uint32_t* __restrict__ list, const int* __restrict__ nn,
+                           int b, int i, Override o1, Override o2, int commit,
+                           double* __restrict__ e_out, int N, int S, int ivcap)
+{
+    const int lane = threadIdx.x;
+    double* P = pos + (size_t)b * N * 3;
+    const double e = local_energy_wave(P, ivect + (size_t)b * ivcap * 3, list + (size_t)b * S * N,
+                                       nn + (size_t)b * N, N, i, o1, o2, lane);
+    if (lane == 0) {
+        *e_out = e;
+        if (commit) {   // these two indices are never read from memory in this launch (overrides win)
+            if (o1.idx >= 0) { P[3 * o1.idx] = o1.x; P[3 * o1.idx + 1] = o1.y; P[3 * o1.idx + 2] = o1.z; }
+            if (o2.idx >= 0 && o2.idx != o1.idx) { P[3 * o2.idx] = o2.x; P[3 * o2.idx + 1] = o2.y; P[3 * o2.idx + 2] = o2.z; }
+        }
+    }
+}
+
+}  // namespace mw
