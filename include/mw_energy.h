@@ -89,6 +89,10 @@ int mw_model_energy_batch(int first_ils, int count, double *e_out);
  * as the reference enumerates them: directed pairs (molint.F90:454) and
  * i-centred triplets (molint.F90:477). */
 int mw_model_energy_counts(int ils, long long *npairs, long long *ntriplets);
+/* The same, summed over boxes first_ils .. first_ils+count-1. */
+int mw_model_energy_counts_total(int first_ils, int count, long long *npairs, long long *ntriplets);
+/* Sum of nn(imol) over those boxes: the number of list entries a full-box pass reads. */
+int mw_neighbour_total(int first_ils, int count, long long *total_entries);
 
 /* ---- compute_local_real_energy(imol, ils) (molint.F90:220-404) ------------------- */
 
@@ -117,12 +121,17 @@ int mw_delta_energy_batch(int n, const int *ils, const int *imol,
 int mw_moves_upload(int n, const int *ils, const int *imol, const double *trial_xyz);
 int mw_moves_launch(void);                       /* old + new local energies of every staged move */
 int mw_moves_fetch(double *e_old, double *e_new);
+/* Totals over the staged moves of the last launch: out = {interactions_old, slots_old,
+ * interactions_new, slots_new}.  An interaction is an in-range pair or an in-range triplet
+ * slot with cos(theta) < 0.99 (molint.F90:276,361,367); a slot is one list entry visited
+ * (nn(i) + sum of nn(j) over in-range j), which prices the call's algorithmic bytes. */
+int mw_moves_counts(long long out[4]);
 int mw_model_energy_launch(int first_ils, int count);
 int mw_model_energy_fetch(int first_ils, int count, double *e_out);
 int mw_build_neighbours_launch(int first_ils, int count);
 int mw_sync(void);
 
-/* HIP-event timers on the engine's stream: slot in 0..15. */
+/* HIP-event timers on the engine's stream: slot in 0..4095. */
 int mw_timer_start(int slot);
 int mw_timer_stop(int slot);
 int mw_timer_elapsed_ms(int slot, float *ms);    /* synchronises on the stop event */

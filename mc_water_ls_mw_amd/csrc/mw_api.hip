@@ -37,7 +37,7 @@ int fail(const char* fmt, ...)
             return fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__, __LINE__); \
     } while (0)
 
-constexpr int kTimerSlots = 16;
+constexpr int kTimerSlots = 4096;
 constexpr int kLdsBudget = 160 * 1024 - 2048;   // leave room for the static reduction arrays
 
 struct Ctx {
@@ -59,13 +59,15 @@ struct Ctx {
     int mcap = 0, mn = 0;
     int *d_mbox = nullptr, *d_mimol = nullptr;
     double *d_mtrial = nullptr, *d_meold = nullptr, *d_menew = nullptr;
+    unsigned int* d_mcnt = nullptr;
+    int mmode = 0;
     // pinned, device-visible scratch for single results
     double* h_pin = nullptr;
     double* d_pin = nullptr;
     // host mirrors
     std::vector<double> h_ivect;   // nbox * ivcap * 3
     std::vector<int> h_nivect;     // nbox
-    hipEvent_t ev[kTimerSlots][2] = {};
+    hipEvent_t ev[kTimerSlots][2] = {};   // created on first use
 };
 
 Ctx g;
@@ -133,7 +135,7 @@ int ensure_moves(int n)
 {
     if (n <= g.mcap) return 0;
     HIPCHK(hipStreamSynchronize(g.stream));
-    if (g.d_mbox) { hipFree(g.d_mbox); hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); }
+    if (g.d_mbox) { hipFree(g.d_mbox); hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); hipFree(g.d_mcnt); }
     int cap = 1024;
     while (cap < n) cap *= 2;
     HIPCHK(hipMalloc(&g.d_mbox, sizeof(int) * cap));
@@ -141,6 +143,7 @@ int ensure_moves(int n)
     HIPCHK(hipMalloc(&g.d_mtrial, sizeof(double) * 3 * cap));
     HIPCHK(hipMalloc(&g.d_meold, sizeof(double) * cap));
     HIPCHK(hipMalloc(&g.d_menew, sizeof(double) * cap));
+    HIPCHK(hipMalloc(&g.d_mcnt, sizeof(unsigned int) * 4 * cap));
     g.mcap = cap;
     return 0;
 }
@@ -281,10 +284,6 @@ int mw_init(int device, int nwater, int nboxes, int maxneigh)
     HIPCHK(hipHostGetDevicePointer((void**)&g.d_pin, g.h_pin, 0));
     g.h_ivect.assign(nb * g.ivcap * 3, 0.0);
     g.h_nivect.assign(nb, 0);
-    for (int s = 0; s < kTimerSlots; ++s) {
-        HIPCHK(hipEventCreate(&g.ev[s][0]));
-        HIPCHK(hipEventCreate(&g.ev[s][1]));
-    }
     // the LDS-staged kernel asks for more than the default 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_model_energy<true, 1024>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
@@ -299,9 +298,12 @@ int mw_finalize(void)
     hipStreamSynchronize(g.stream);
     hipFree(g.d_pos); hipFree(g.d_ivect); hipFree(g.d_nivect); hipFree(g.d_list); hipFree(g.d_nn); hipFree(g.d_stats);
     hipFree(g.d_partial); hipFree(g.d_cpartial); hipFree(g.d_energy); hipFree(g.d_counts);
-    if (g.d_mbox) { hipFree(g.d_mbox); hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); }
+    if (g.d_mbox) { hipFree(g.d_mbox); hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); hipFree(g.d_mcnt); }
     hipHostFree(g.h_pin);
-    for (int s = 0; s < kTimerSlots; ++s) { hipEventDestroy(g.ev[s][0]); hipEventDestroy(g.ev[s][1]); }
+    for (int s = 0; s < kTimerSlots; ++s) {
+        if (g.ev[s][0]) hipEventDestroy(g.ev[s][0]);
+        if (g.ev[s][1]) hipEventDestroy(g.ev[s][1]);
+    }
     hipStreamDestroy(g.stream);
     g = Ctx();
     return 0;
@@ -411,6 +413,31 @@ int mw_get_neighbours(int ils, int* nn, int* jn, int* vn)
     return 0;
 }
 
+int mw_neighbour_total(int first_ils, int count, long long* total_entries)
+{
+    if (check_live() || check_range(first_ils, count)) return 1;
+    std::vector<int> hnn((size_t)count * g.N);
+    HIPCHK(hipMemcpyAsync(hnn.data(), g.d_nn + (size_t)(first_ils - 1) * g.N, hnn.size() * sizeof(int), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    long long t = 0;
+    for (int v : hnn) t += v;
+    *total_entries = t;
+    return 0;
+}
+
+int mw_model_energy_counts_total(int first_ils, int count, long long* npairs, long long* ntriplets)
+{
+    if (check_live() || check_range(first_ils, count)) return 1;
+    std::vector<unsigned long long> c((size_t)count * 2);
+    HIPCHK(hipMemcpyAsync(c.data(), g.d_counts + 2 * (size_t)(first_ils - 1), c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    long long p = 0, t = 0;
+    for (int b = 0; b < count; ++b) { p += (long long)c[2 * (size_t)b]; t += (long long)c[2 * (size_t)b + 1]; }
+    if (npairs) *npairs = p;
+    if (ntriplets) *ntriplets = t;
+    return 0;
+}
+
 int mw_model_energy_launch(int first_ils, int count)
 {
     if (check_live() || check_range(first_ils, count)) return 1;
@@ -491,8 +518,9 @@ static int launch_moves(int mode)
 {
     if (g.mn == 0) return 0;
     hipLaunchKernelGGL(mw::k_local_energy, dim3((g.mn + 3) / 4), dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_list, g.d_nn,
-                       g.d_mbox, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.mn, g.N, g.S, g.ivcap, mode);
+                       g.d_mbox, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.mn, g.N, g.S, g.ivcap, mode);
     HIPCHK(hipGetLastError());
+    g.mmode = mode;
     return 0;
 }
 
@@ -510,6 +538,21 @@ int mw_moves_fetch(double* e_old, double* e_new)
         if (e_new) HIPCHK(hipMemcpyAsync(e_new, g.d_menew, sizeof(double) * g.mn, hipMemcpyDeviceToHost, g.stream));
     }
     HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int mw_moves_counts(long long out[4])
+{
+    if (check_live()) return 1;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (g.mn == 0) return 0;
+    std::vector<unsigned int> c((size_t)g.mn * 4);
+    HIPCHK(hipMemcpyAsync(c.data(), g.d_mcnt, sizeof(unsigned int) * 4 * g.mn, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (int m = 0; m < g.mn; ++m) {
+        if (g.mmode & 1) { out[0] += c[4 * (size_t)m]; out[1] += c[4 * (size_t)m + 1]; }
+        if (g.mmode & 2) { out[2] += c[4 * (size_t)m + 2]; out[3] += c[4 * (size_t)m + 3]; }
+    }
     return 0;
 }
 
@@ -539,6 +582,7 @@ int mw_timer_start(int slot)
 {
     if (check_live()) return 1;
     if (slot < 0 || slot >= kTimerSlots) return fail("mw_timer: slot %d outside 0..%d", slot, kTimerSlots - 1);
+    if (!g.ev[slot][0]) { HIPCHK(hipEventCreate(&g.ev[slot][0])); HIPCHK(hipEventCreate(&g.ev[slot][1])); }
     HIPCHK(hipEventRecord(g.ev[slot][0], g.stream));
     return 0;
 }
@@ -547,6 +591,7 @@ int mw_timer_stop(int slot)
 {
     if (check_live()) return 1;
     if (slot < 0 || slot >= kTimerSlots) return fail("mw_timer: slot %d outside 0..%d", slot, kTimerSlots - 1);
+    if (!g.ev[slot][1]) return fail("mw_timer_stop: slot %d was never started", slot);
     HIPCHK(hipEventRecord(g.ev[slot][1], g.stream));
     return 0;
 }
@@ -555,6 +600,7 @@ int mw_timer_elapsed_ms(int slot, float* ms)
 {
     if (check_live()) return 1;
     if (slot < 0 || slot >= kTimerSlots) return fail("mw_timer: slot %d outside 0..%d", slot, kTimerSlots - 1);
+    if (!g.ev[slot][1]) return fail("mw_timer_elapsed_ms: slot %d was never started", slot);
     HIPCHK(hipEventSynchronize(g.ev[slot][1]));
     HIPCHK(hipEventElapsedTime(ms, g.ev[slot][0], g.ev[slot][1]));
     return 0;

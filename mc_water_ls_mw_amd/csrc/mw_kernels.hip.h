@@ -325,10 +325,14 @@ __device__ __forceinline__ void pair_terms(double r2, double& rinv, double& e1, 
     g  = t4 * t2;                                // :292
 }
 
-// Returns the local energy in every lane.
+// Returns the local energy in every lane.  `ninter` / `nslots` (wave-uniform) receive the number
+// of in-range interactions as the reference enumerates them (pairs + triplet slots with
+// cos(theta) < 0.99) and the number of list slots visited (n_i + sum of n_j over in-range j),
+// which prices the call's algorithmic bytes.
 __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P, const double* __restrict__ IV,
                                                     const uint32_t* __restrict__ L, const int* __restrict__ NN,
-                                                    int N, int i, const Override& o1, const Override& o2, int lane)
+                                                    int N, int i, const Override& o1, const Override& o2, int lane,
+                                                    unsigned int& ninter, unsigned int& nslots)
 {
     double xi, yi, zi;
     load_pos(P, i, o1, o2, xi, yi, zi);                                   // molint.F90:258
@@ -350,8 +354,11 @@ __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P
     const double q = kSigSq * rinv * rinv;
     double acc2 = inr ? (kAeps * (kBigB * (q * q) - 1.0)) * e1 : 0.0;     // :294-297
     double acc3 = 0.0;
+    unsigned int ntl = 0;            // per-lane count of triplet slots that contribute
 
     unsigned long long mask = __ballot(inr);
+    ninter = (unsigned int)__popcll(mask);
+    nslots = (unsigned int)n_i;
     while (mask) {                                                        // wave-uniform loop over in-range j
         const int jl = __ffsll((long long)mask) - 1;
         mask &= mask - 1ull;
@@ -361,7 +368,7 @@ __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P
         // j--i--k: later in-range slots of imol's own list                 :302-318
         if (inr && lane > jl) {
             const double ct = ((ajx * dx + ajy * dy + ajz * dz) * rinv_j) * rinv;     // :316,365
-            if (ct < 0.99) { const double d = ct - kCos0; acc3 += g_j * (g * (d * d)); }   // :367-368,385-387
+            if (ct < 0.99) { const double d = ct - kCos0; acc3 += g_j * (g * (d * d)); ++ntl; }   // :367-368,385-387
         }
 
         // i--j--k: jmol's list, translated by j's image                    :324-343
@@ -369,6 +376,7 @@ __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P
         const double sjx = __shfl(jvx, jl, 64), sjy = __shfl(jvy, jl, 64), sjz = __shfl(jvz, jl, 64);
         const double pjx = __shfl(qx, jl, 64), pjy = __shfl(qy, jl, 64), pjz = __shfl(qz, jl, 64);
         const int n_j = NN[jj];
+        nslots += (unsigned int)n_j;
         if (lane < n_j) {
             const uint32_t e2 = L[(size_t)lane * N + jj];
             const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
@@ -382,13 +390,17 @@ __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P
                 double rinv_k, e1_k, g_k;
                 pair_terms(s2, rinv_k, e1_k, g_k);
                 const double ct = (-(ajx * bx + ajy * by + ajz * bz) * rinv_j) * rinv_k;   // :320,341,365
-                if (ct < 0.99) { const double d = ct - kCos0; acc3 += g_j * (g_k * (d * d)); }
+                if (ct < 0.99) { const double d = ct - kCos0; acc3 += g_j * (g_k * (d * d)); ++ntl; }
             }
         }
     }
     double tot = acc2 + kLamEps * acc3;                                    // :397
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+        tot += __shfl_xor(tot, off, 64);
+        ntl += (unsigned int)__shfl_xor((int)ntl, off, 64);
+    }
+    ninter += ntl;
     return tot;
 }
 
@@ -400,6 +412,7 @@ void k_local_energy(const double* __restrict__ pos, const double* __restrict__ i
                     const int* __restrict__ req_box, const int* __restrict__ req_imol,
                     const double* __restrict__ req_trial,
                     double* __restrict__ e_old, double* __restrict__ e_new,
+                    unsigned int* __restrict__ counts,   // [nreq][4]: inter_old, slots_old, inter_new, slots_new
                     int nreq, int N, int S, int ivcap, int mode)
 {
     const int lane = threadIdx.x & 63;
@@ -412,14 +425,15 @@ void k_local_energy(const double* __restrict__ pos, const double* __restrict__ i
     const uint32_t* L = list + (size_t)b * S * N;
     const int* NN = nn + (size_t)b * N;
     Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
+    unsigned int ni = 0, ns = 0;
     if (mode & 1) {
-        const double e = local_energy_wave(P, IV, L, NN, N, i, none, none, lane);
-        if (lane == 0) e_old[m] = e;
+        const double e = local_energy_wave(P, IV, L, NN, N, i, none, none, lane, ni, ns);
+        if (lane == 0) { e_old[m] = e; counts[4 * (size_t)m] = ni; counts[4 * (size_t)m + 1] = ns; }
     }
     if (mode & 2) {
         Override tr; tr.idx = i; tr.x = req_trial[3 * m]; tr.y = req_trial[3 * m + 1]; tr.z = req_trial[3 * m + 2];
-        const double e = local_energy_wave(P, IV, L, NN, N, i, tr, none, lane);
-        if (lane == 0) e_new[m] = e;
+        const double e = local_energy_wave(P, IV, L, NN, N, i, tr, none, lane, ni, ns);
+        if (lane == 0) { e_new[m] = e; counts[4 * (size_t)m + 2] = ni; counts[4 * (size_t)m + 3] = ns; }
     }
 }
 
@@ -433,8 +447,9 @@ void k_local_energy_single(double* __restrict__ pos, const double* __restrict__ 
 {
     const int lane = threadIdx.x;
     double* P = pos + (size_t)b * N * 3;
+    unsigned int ni, ns;
     const double e = local_energy_wave(P, ivect + (size_t)b * ivcap * 3, list + (size_t)b * S * N,
-                                       nn + (size_t)b * N, N, i, o1, o2, lane);
+                                       nn + (size_t)b * N, N, i, o1, o2, lane, ni, ns);
     if (lane == 0) {
         *e_out = e;
         if (commit) {   // these two indices are never read from memory in this launch (overrides win)

@@ -38,8 +38,9 @@ ABI_SYMBOLS = (
     "mw_set_cell", "mw_get_ivects", "mw_upload_positions", "mw_download_positions", "mw_patch_position",
     "mw_build_neighbours", "mw_build_neighbours_batch", "mw_get_neighbours",
     "mw_model_energy", "mw_model_energy_batch", "mw_model_energy_counts",
+    "mw_model_energy_counts_total", "mw_neighbour_total",
     "mw_local_energy", "mw_local_energy_patched", "mw_local_energy_batch", "mw_delta_energy_batch",
-    "mw_moves_upload", "mw_moves_launch", "mw_moves_fetch",
+    "mw_moves_upload", "mw_moves_launch", "mw_moves_fetch", "mw_moves_counts",
     "mw_model_energy_launch", "mw_model_energy_fetch", "mw_build_neighbours_launch", "mw_sync",
     "mw_timer_start", "mw_timer_stop", "mw_timer_elapsed_ms", "mw_device_info",
 )
@@ -60,10 +61,35 @@ def load_library(path=LIB_PATH):
     if not os.path.exists(path):
         raise MwError(f"{path} not found: build it with `python -m mc_water_ls_mw_amd.build` "
                       "(the mW engine has no CPU fallback)")
+    _share_hip_runtime_with_torch()
     L = ctypes.CDLL(path)
     L.mw_last_error.restype = ctypes.c_char_p
     _lib = L
     return L
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels carry their own
+    libamdhip64.so (same SONAME as /opt/rocm's); if libmw_hip.so were loaded first it
+    would bind the system copy, a later ``import torch`` would bring in a second
+    runtime, and whichever initialises second sees no device.  So when torch is
+    installed, its copy is loaded (globally) before ours, whatever the import order.
+    A process without torch -- the Fortran host -- simply uses /opt/rocm's."""
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def _d(a):
@@ -191,6 +217,18 @@ class EnergyModule:
         self._chk(self.L.mw_model_energy_counts(ils, ctypes.byref(p), ctypes.byref(t)))
         return p.value, t.value
 
+    def model_energy_counts_total(self, first_ils=1, count=None):
+        count = self.num_lattices - first_ils + 1 if count is None else count
+        p, t = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        self._chk(self.L.mw_model_energy_counts_total(first_ils, count, ctypes.byref(p), ctypes.byref(t)))
+        return p.value, t.value
+
+    def neighbour_total(self, first_ils=1, count=None):
+        count = self.num_lattices - first_ils + 1 if count is None else count
+        t = ctypes.c_longlong(0)
+        self._chk(self.L.mw_neighbour_total(first_ils, count, ctypes.byref(t)))
+        return t.value
+
     # -- compute_local_real_energy (molint.F90:220-404) -------------------------------
     def compute_local_real_energy(self, imol, ils):
         """Local energy of molecule imol in lattice ils from the HOST's current ljr.
@@ -267,6 +305,12 @@ class EnergyModule:
         eo, en = np.zeros(self._nmoves), np.zeros(self._nmoves)
         self._chk(self.L.mw_moves_fetch(_d(eo), _d(en)))
         return eo, en
+
+    def moves_counts(self):
+        """(interactions_old, slots_old, interactions_new, slots_new) summed over the staged moves."""
+        out = (ctypes.c_longlong * 4)()
+        self._chk(self.L.mw_moves_counts(out))
+        return tuple(int(v) for v in out)
 
     def model_energy_launch(self, first_ils, count):
         self._chk(self.L.mw_model_energy_launch(first_ils, count))

@@ -1,0 +1,84 @@
+"""CPU: the C-ABI library loads, exports every symbol include/mw_energy.h declares,
+and fails loudly -- never silently -- when there is no GPU.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def _lib():
+    from mc_water_ls_mw_amd import build
+    from mc_water_ls_mw_amd.energy import load_library
+    build.build()
+    return load_library()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mw_energy.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mw_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    L = _lib()
+    names = _declared_symbols()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(L, name), f"libmw_hip.so does not export {name}"
+    from mc_water_ls_mw_amd.energy import ABI_SYMBOLS
+    assert sorted(ABI_SYMBOLS) == names
+
+
+def test_constants_without_a_device():
+    L = _lib()
+    out = np.zeros(8)
+    assert L.mw_constants(out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == 0
+    assert np.array_equal(out, np.load(GOLDEN + "/constants.npz")["constants"])
+
+
+def test_calls_before_init_fail_with_a_message():
+    L = _lib()
+    if L.mw_is_initialised():
+        pytest.skip("engine is live in this process")
+    e = ctypes.c_double(0)
+    assert L.mw_model_energy(1, ctypes.byref(e)) != 0
+    assert b"not initialised" in L.mw_last_error()
+    assert L.mw_sync() != 0
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a gfx950 device mw_init must fail and say so; the Python mirror raises."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the no-device behaviour is checked on the CPU box")
+    L = _lib()
+    assert L.mw_init(0, 48, 1, 50) != 0
+    msg = L.mw_last_error().decode()
+    assert "no HIP device" in msg or "no CPU fallback" in msg
+    from mc_water_ls_mw_amd.energy import EnergyModule, MwError
+    em = EnergyModule(48, 1)
+    with pytest.raises(MwError):
+        em.energy_init()
+
+
+def test_argument_validation_needs_no_device():
+    L = _lib()
+    if L.mw_is_initialised():
+        pytest.skip("engine is live in this process")
+    assert L.mw_init(0, 0, 1, 50) != 0 and b"positive" in L.mw_last_error()
+    assert L.mw_init(0, 48, 1, 65) != 0 and b"maxneigh" in L.mw_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is the checker, never the thing shipped."""
+    pkg = os.path.join(ROOT, "mc_water_ls_mw_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".F90", ".f90", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "mw_oracle" not in text and "libmw_ref" not in text, f
