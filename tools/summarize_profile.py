@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (tools/profile.sh) into profiles/<tag>_*:
+the rocprofv3 --kernel-trace --stats table, per-kernel FETCH_SIZE / WRITE_SIZE
+(separate --pmc passes) and the bench line of the traced run.
+
+HBM bytes per launch follow MI355X_MICROARCH.md "HBM": FETCH_SIZE and
+WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads
+by exactly 2x, so  traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (an upper-side
+estimate for narrower accesses, which are uncalibrated)."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for name in ("fetch", "write"):
+    path = os.path.join(src, f"pmc_{name}", f"{name}_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
+W, M = bench["config"]["walkers_per_gpu"], bench["config"]["moves_per_walker"]
+traffic = {"walkers": W, "moves": M, "tag": tag}
+lines = [f"# rocprofv3 summary `{tag}`", "",
+         f"Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps {bench['steps']} --warmup {bench['warmup']}`"
+         f" (walkers {W}, moves/walker {M}); PMC in separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs.", "",
+         "| kernel | calls | avg us (rocprof) | avg us (bench HIP events) | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes/launch (2*F+W)*1024 |",
+         "|---|---|---|---|---|---|---|"]
+stats = {r["Name"].split("(")[0].replace("void ", ""): r for r in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv")))}
+for k, r in stats.items():
+    if not k.startswith("mw::"):
+        continue
+    f = pmc.get(k, {}).get("FETCH_SIZE", [])
+    w = pmc.get(k, {}).get("WRITE_SIZE", [])
+    fa = sum(f) / len(f) if f else None
+    wa = sum(w) / len(w) if w else None
+    hb = (2 * fa + wa) * 1024 if fa is not None and wa is not None else None
+    short = k.replace("mw::", "").split("<")[0]
+    ev = bench["kernels"].get(short, {}).get("avg_ms")
+    if hb is not None and short in ("k_model_energy", "k_local_energy"):
+        traffic[short] = hb
+    lines.append(f"| {k} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {'' if ev is None else f'{ev*1e3:.1f}'} | "
+                 f"{'' if fa is None else f'{fa:.0f}'} | {'' if wa is None else f'{wa:.0f}'} | {'' if hb is None else f'{hb:.4g}'} |")
+lines += ["", "Bench line of the traced run:", "", "```json", json.dumps(bench), "```", ""]
+open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines))
+json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"))
+print("\n".join(lines[:12]))
