@@ -39,7 +39,10 @@ extern "C" {
 
 /* Allocate device state for `nboxes` boxes of `nwater` molecules each with
  * `maxneigh` list slots per molecule (reference: 50, molint.F90:79).  `device`
- * is the HIP device ordinal (the local rank in a one-process-per-GPU farm). */
+ * is the HIP device ordinal (the local rank in a one-process-per-GPU farm); -1
+ * takes it from MW_DEVICE / LOCAL_RANK / OMPI_COMM_WORLD_LOCAL_RANK /
+ * MV2_COMM_WORLD_LOCAL_RANK / MPI_LOCALRANKID / SLURM_LOCALID, modulo the
+ * number of devices (0 if none is set). */
 int mw_init(int device, int nwater, int nboxes, int maxneigh);
 int mw_finalize(void);
 int mw_is_initialised(void);

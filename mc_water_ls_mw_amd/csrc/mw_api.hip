@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -250,7 +251,17 @@ int mw_init(int device, int nwater, int nboxes, int maxneigh)
     if (e != hipSuccess || ndev < 1)
         return fail("mw_init: no HIP device available (%s); this engine has no CPU fallback",
                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
-    if (device < 0 || device >= ndev) return fail("mw_init: device %d outside 0..%d", device, ndev - 1);
+    if (device < 0) {
+        // one process per GPU: take the local rank from the launcher's environment
+        device = 0;
+        const char* vars[] = {"MW_DEVICE", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK",
+                              "MPI_LOCALRANKID", "SLURM_LOCALID"};
+        for (const char* v : vars) {
+            const char* s = std::getenv(v);
+            if (s && *s) { device = std::atoi(s) % ndev; if (device < 0) device = 0; break; }
+        }
+    }
+    if (device >= ndev) return fail("mw_init: device %d outside 0..%d", device, ndev - 1);
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
