@@ -8,6 +8,7 @@
 #include "mw_kernels.hip.h"
 #include "../../include/mw_energy.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -49,7 +50,8 @@ struct Ctx {
     double* d_pos = nullptr;
     double* d_ivect = nullptr;
     int* d_nivect = nullptr;
-    uint32_t* d_list = nullptr;
+    uint32_t* d_list = nullptr;    // slot-major   [box][S][N]
+    uint32_t* d_listm = nullptr;   // molecule-major [box][N][64]
     int* d_nn = nullptr;
     int* d_stats = nullptr;
     double* d_partial = nullptr;
@@ -61,6 +63,10 @@ struct Ctx {
     int *d_mbox = nullptr, *d_mimol = nullptr;
     double *d_mtrial = nullptr, *d_meold = nullptr, *d_menew = nullptr;
     unsigned int* d_mcnt = nullptr;
+    int* d_mperm = nullptr;        // sorted request -> caller's index
+    int4* d_mwork = nullptr;       // work items {box, begin, end, 0}
+    int mwork_cap = 0, mwork_n = 0;
+    bool mlds = false;
     int mmode = 0;
     // pinned, device-visible scratch for single results
     double* h_pin = nullptr;
@@ -136,7 +142,7 @@ int ensure_moves(int n)
 {
     if (n <= g.mcap) return 0;
     HIPCHK(hipStreamSynchronize(g.stream));
-    if (g.d_mbox) { hipFree(g.d_mbox); hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); hipFree(g.d_mcnt); }
+    if (g.d_mbox) { hipFree(g.d_mbox); hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); hipFree(g.d_mcnt); hipFree(g.d_mperm); }
     int cap = 1024;
     while (cap < n) cap *= 2;
     HIPCHK(hipMalloc(&g.d_mbox, sizeof(int) * cap));
@@ -145,6 +151,7 @@ int ensure_moves(int n)
     HIPCHK(hipMalloc(&g.d_meold, sizeof(double) * cap));
     HIPCHK(hipMalloc(&g.d_menew, sizeof(double) * cap));
     HIPCHK(hipMalloc(&g.d_mcnt, sizeof(unsigned int) * 4 * cap));
+    HIPCHK(hipMalloc(&g.d_mperm, sizeof(int) * cap));
     g.mcap = cap;
     return 0;
 }
@@ -202,7 +209,7 @@ int launch_build(int first, int count)
     HIPCHK(hipStreamSynchronize(g.stream));   // `init` is pageable: make sure it was consumed
     dim3 grid((g.N + 255) / 256, count);
     hipLaunchKernelGGL(mw::k_build_neighbours, grid, dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_nivect, g.d_list,
-                       g.d_nn, g.d_stats, g.N, g.S, g.ivcap, box0);
+                       g.d_listm, g.d_nn, g.d_stats, g.N, g.S, g.ivcap, box0);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -278,6 +285,7 @@ int mw_init(int device, int nwater, int nboxes, int maxneigh)
     HIPCHK(hipMalloc(&g.d_ivect, nb * g.ivcap * 3 * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_nivect, nb * sizeof(int)));
     HIPCHK(hipMalloc(&g.d_list, nb * N * (size_t)maxneigh * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&g.d_listm, nb * N * (size_t)mw::kRow * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.d_nn, nb * N * sizeof(int)));
     HIPCHK(hipMalloc(&g.d_stats, nb * 2 * sizeof(int)));
     HIPCHK(hipMalloc(&g.d_partial, nb * g.nsplit_max * sizeof(double)));
@@ -289,6 +297,7 @@ int mw_init(int device, int nwater, int nboxes, int maxneigh)
     HIPCHK(hipMemset(g.d_nivect, 0, nb * sizeof(int)));
     HIPCHK(hipMemset(g.d_nn, 0, nb * N * sizeof(int)));
     HIPCHK(hipMemset(g.d_list, 0, nb * N * (size_t)maxneigh * sizeof(uint32_t)));
+    HIPCHK(hipMemset(g.d_listm, 0, nb * N * (size_t)mw::kRow * sizeof(uint32_t)));
     HIPCHK(hipMemset(g.d_energy, 0, nb * sizeof(double)));
     HIPCHK(hipMemset(g.d_counts, 0, nb * 2 * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc(&g.h_pin, 4096, hipHostMallocMapped));
@@ -297,6 +306,8 @@ int mw_init(int device, int nwater, int nboxes, int maxneigh)
     g.h_nivect.assign(nb, 0);
     // the LDS-staged kernel asks for more than the default 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_model_energy<true, 1024>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_move_energy<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
     g.live = true;
     return 0;
@@ -307,9 +318,10 @@ int mw_finalize(void)
     if (!g.live) return 0;
     hipSetDevice(g.device);
     hipStreamSynchronize(g.stream);
-    hipFree(g.d_pos); hipFree(g.d_ivect); hipFree(g.d_nivect); hipFree(g.d_list); hipFree(g.d_nn); hipFree(g.d_stats);
+    hipFree(g.d_pos); hipFree(g.d_ivect); hipFree(g.d_nivect); hipFree(g.d_list); hipFree(g.d_listm); hipFree(g.d_nn); hipFree(g.d_stats);
     hipFree(g.d_partial); hipFree(g.d_cpartial); hipFree(g.d_energy); hipFree(g.d_counts);
-    if (g.d_mbox) { hipFree(g.d_mbox); hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); hipFree(g.d_mcnt); }
+    if (g.d_mbox) { hipFree(g.d_mbox); hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); hipFree(g.d_mcnt); hipFree(g.d_mperm); }
+    if (g.d_mwork) hipFree(g.d_mwork);
     hipHostFree(g.h_pin);
     for (int s = 0; s < kTimerSlots; ++s) {
         if (g.ev[s][0]) hipEventDestroy(g.ev[s][0]);
@@ -493,8 +505,8 @@ int mw_local_energy_patched(int ils, int imol, const double r_imol[3], int imol_
         if (check_mol(imol_prev)) return 1;
         o2.idx = imol_prev - 1; o2.x = r_prev[0]; o2.y = r_prev[1]; o2.z = r_prev[2];
     }
-    hipLaunchKernelGGL(mw::k_local_energy_single, dim3(1), dim3(64), 0, g.stream, g.d_pos, g.d_ivect, g.d_list, g.d_nn,
-                       ils - 1, imol - 1, o1, o2, 1, g.d_pin, g.N, g.S, g.ivcap);
+    hipLaunchKernelGGL(mw::k_local_energy_single, dim3(1), dim3(64), 0, g.stream, g.d_pos, g.d_ivect, g.d_listm, g.d_nn,
+                       ils - 1, imol - 1, o1, o2, 1, g.d_pin, g.N, g.ivcap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(g.stream));
     *e = g.h_pin[0];
@@ -510,17 +522,46 @@ int mw_moves_upload(int n, const int* ils, const int* imol, const double* trial_
     g.mn = 0;
     if (n == 0) return 0;
     if (!ils || !imol) return fail("mw_moves_upload: null request arrays");
-    std::vector<int> b0((size_t)n), i0((size_t)n);
+    // Bucket the requests by box (stable counting sort): a workgroup then serves requests of ONE
+    // box and can stage that box's positions in LDS.  perm maps sorted slot -> caller's index.
+    std::vector<int> cnt((size_t)g.nbox + 1, 0);
     for (int m = 0; m < n; ++m) {
         if (ils[m] < 1 || ils[m] > g.nbox) return fail("mw_moves_upload: request %d has box %d outside 1..%d", m, ils[m], g.nbox);
         if (imol[m] < 1 || imol[m] > g.N) return fail("mw_moves_upload: request %d has molecule %d outside 1..%d", m, imol[m], g.N);
-        b0[m] = ils[m] - 1; i0[m] = imol[m] - 1;
+        ++cnt[(size_t)ils[m]];
     }
+    std::vector<int> start((size_t)g.nbox + 1, 0);
+    int used_boxes = 0;
+    for (int b = 0; b < g.nbox; ++b) { start[(size_t)b + 1] = start[b] + cnt[(size_t)b + 1]; if (cnt[(size_t)b + 1]) ++used_boxes; }
+    std::vector<int> perm((size_t)n), i0((size_t)n), fill(start.begin(), start.end() - 1);
+    std::vector<double> tr(trial_xyz ? (size_t)3 * n : 0);
+    for (int m = 0; m < n; ++m) {
+        const int s = fill[(size_t)ils[m] - 1]++;
+        perm[s] = m; i0[s] = imol[m] - 1;
+        if (trial_xyz) { tr[3 * (size_t)s] = trial_xyz[3 * (size_t)m]; tr[3 * (size_t)s + 1] = trial_xyz[3 * (size_t)m + 1]; tr[3 * (size_t)s + 2] = trial_xyz[3 * (size_t)m + 2]; }
+    }
+    // LDS staging pays when a box's 24N bytes are shared by enough requests
+    g.mlds = lds_fits(g.N, g.ivcap) && ((long long)n * 2048 >= (long long)used_boxes * 24 * g.N);
+    const int chunk = g.mlds ? 256 : 16;
+    std::vector<int4> work;
+    for (int b = 0; b < g.nbox; ++b)
+        for (int s = start[b]; s < start[(size_t)b + 1]; s += chunk) {
+            int4 w; w.x = b; w.y = s; w.z = std::min(s + chunk, start[(size_t)b + 1]); w.w = 0;
+            work.push_back(w);
+        }
     if (ensure_moves(n)) return 1;
-    HIPCHK(hipMemcpyAsync(g.d_mbox, b0.data(), sizeof(int) * n, hipMemcpyHostToDevice, g.stream));
+    if ((int)work.size() > g.mwork_cap) {
+        HIPCHK(hipStreamSynchronize(g.stream));
+        if (g.d_mwork) HIPCHK(hipFree(g.d_mwork));
+        g.mwork_cap = (int)work.size() * 2;
+        HIPCHK(hipMalloc(&g.d_mwork, sizeof(int4) * g.mwork_cap));
+    }
+    HIPCHK(hipMemcpyAsync(g.d_mwork, work.data(), sizeof(int4) * work.size(), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.d_mperm, perm.data(), sizeof(int) * n, hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipMemcpyAsync(g.d_mimol, i0.data(), sizeof(int) * n, hipMemcpyHostToDevice, g.stream));
-    if (trial_xyz) HIPCHK(hipMemcpyAsync(g.d_mtrial, trial_xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, g.stream));
+    if (trial_xyz) HIPCHK(hipMemcpyAsync(g.d_mtrial, tr.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
+    g.mwork_n = (int)work.size();
     g.mn = n;
     return 0;
 }
@@ -528,8 +569,15 @@ int mw_moves_upload(int n, const int* ils, const int* imol, const double* trial_
 static int launch_moves(int mode)
 {
     if (g.mn == 0) return 0;
-    hipLaunchKernelGGL(mw::k_local_energy, dim3((g.mn + 3) / 4), dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_list, g.d_nn,
-                       g.d_mbox, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.mn, g.N, g.S, g.ivcap, mode);
+    const size_t iv_bytes = (size_t)3 * g.ivcap * sizeof(double);
+    if (g.mlds)
+        hipLaunchKernelGGL(mw::k_move_energy<true>, dim3(g.mwork_n), dim3(1024), iv_bytes + (size_t)3 * g.N * sizeof(double), g.stream,
+                           g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
+                           g.d_meold, g.d_menew, g.d_mcnt, g.N, g.ivcap, mode);
+    else
+        hipLaunchKernelGGL(mw::k_move_energy<false>, dim3(g.mwork_n), dim3(1024), iv_bytes, g.stream,
+                           g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
+                           g.d_meold, g.d_menew, g.d_mcnt, g.N, g.ivcap, mode);
     HIPCHK(hipGetLastError());
     g.mmode = mode;
     return 0;

@@ -3,7 +3,7 @@
 // What each kernel stands behind in the reference (keb721/mc_water_ls_mw):
 //   k_build_neighbours  compute_neighbours       molint.F90:501-559
 //   k_model_energy      compute_model_energy     molint.F90:407-499
-//   k_local_energy      compute_local_real_energy molint.F90:220-404
+//   k_move_energy / k_local_energy_single   compute_local_real_energy molint.F90:220-404
 // None of it is a translation: the list is slot-major and packed for coalesced
 // reads, positions of a whole box are staged in LDS, the three-body sum is
 // evaluated from per-atom moments in O(neighbours), and the single-move path
@@ -41,6 +41,71 @@ constexpr int      kJBits = 22;
 constexpr uint32_t kJMask = (1u << kJBits) - 1u;
 
 __device__ __forceinline__ uint32_t pack_entry(int j0, int k0) { return (uint32_t)j0 | ((uint32_t)k0 << kJBits); }
+
+// The list is kept in two layouts, each coalesced for its consumer:
+//   list  [box][S][N]   slot-major     -- full-box kernel: thread = molecule, loop over slots
+//   listm [box][N][64]  molecule-major -- single-move kernels: lane = slot of one molecule's row
+// (a row is 256 B = two 128-B lines; S <= 64)
+constexpr int kRow = 64;
+
+// Wave-uniform broadcast of a double from lane `l` (l must be uniform: v_readlane, no LDS traffic).
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// ---- double-precision primitives sized for this tolerance ---------------------------------
+// The parity bar is 1e-10 relative on energies; these keep every factor below 1e-14 relative
+// while costing a fraction of the IEEE-exact sqrt / divide / libm exp sequences (which spend
+// most of their instructions on the last ulp and on special cases that cannot occur here:
+// the arguments are finite, positive (r^2), nonzero (r - a sigma < 0) or <= 0 (exponent)).
+
+// 1/sqrt(x), x > 0 finite and normal: hardware estimate + two Newton steps.
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-x * y, y, 1.0);          // 1 - x y^2
+    y = __builtin_fma(y, e * __builtin_fma(e, 0.375, 0.5), y);   // y (1 + e/2 + 3e^2/8)
+    e = __builtin_fma(-x * y, y, 1.0);
+    y = __builtin_fma(y * 0.5, e, y);
+    return y;
+}
+
+// 1/x, x finite, normal, nonzero: hardware estimate + two Newton steps.
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    return y;
+}
+
+// exp(x) for x <= 0 (any magnitude; underflows smoothly to 0).  n = round(x log2 e),
+// r = x - n ln2 in two pieces, degree-11 Taylor on |r| <= 0.347 (remainder < 7e-15), 2^n by ldexp.
+__device__ __forceinline__ double fast_exp_neg(double x)
+{
+    x = x < -800.0 ? -800.0 : x;                                    // exp(-800) == 0 in double anyway
+    const double n = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(n, -6.93147180369123816490e-01, x);    // ln2 high part (fdlibm split)
+    r = __builtin_fma(n, -1.90821492927058770002e-10, r);           // ln2 low part
+    double p = 2.50521083854417187751e-08;                           // 1/11!
+    p = __builtin_fma(p, r, 2.75573192239858906526e-07);             // 1/10!
+    p = __builtin_fma(p, r, 2.75573192239858906526e-06);             // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873015873e-05);             // 1/8!
+    p = __builtin_fma(p, r, 1.98412698412698412698e-04);             // 1/7!
+    p = __builtin_fma(p, r, 1.38888888888888888889e-03);             // 1/6!
+    p = __builtin_fma(p, r, 8.33333333333333333333e-03);             // 1/5!
+    p = __builtin_fma(p, r, 4.16666666666666666667e-02);             // 1/4!
+    p = __builtin_fma(p, r, 1.66666666666666666667e-01);             // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)n);
+}
 
 // ---- wave / block reductions ---------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v)
@@ -81,7 +146,7 @@ __device__ __forceinline__ int wave_max_i(int v)
 __global__ __launch_bounds__(256)
 void k_build_neighbours(const double* __restrict__ pos, const double* __restrict__ ivect,
                         const int* __restrict__ nivect, uint32_t* __restrict__ list,
-                        int* __restrict__ nn, int* __restrict__ stats,
+                        uint32_t* __restrict__ listm, int* __restrict__ nn, int* __restrict__ stats,
                         int N, int S, int ivcap, int box0)
 {
 #pragma clang fp contract(off)
@@ -91,6 +156,7 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
     const double* IV = ivect + (size_t)b * ivcap * 3;
     const int niv = nivect[b];
     uint32_t* L = list + (size_t)b * S * N;
+    uint32_t* LM = listm + ((size_t)b * N + (i < N ? i : 0)) * kRow;
     const bool active = i < N;
     const int ii = active ? i : 0;
     const double xi = P[3 * ii], yi = P[3 * ii + 1], zi = P[3 * ii + 2];   // molint.F90:522
@@ -102,7 +168,7 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
             const double tx = vx + IV[3 * k], ty = vy + IV[3 * k + 1], tz = vz + IV[3 * k + 2];   // :534
             const double r2 = tx * tx + ty * ty + tz * tz;                  // :535
             if (r2 < kRnSq && !(k == 0 && j == i)) {                        // :532,537
-                if (active && cnt < S) L[(size_t)cnt * N + i] = pack_entry(j, k);
+                if (active && cnt < S) { const uint32_t e = pack_entry(j, k); L[(size_t)cnt * N + i] = e; LM[cnt] = e; }
                 ++cnt;
             }
         }
@@ -181,12 +247,12 @@ __device__ __forceinline__ AtomSum atom_energy(int i, int n, const uint32_t* __r
         getiv((int)(e >> kJBits), ix, iy, iz);
         const double dx = (xj + ix) - xi, dy = (yj + iy) - yi, dz = (zj + iz) - zi;
         const double r2 = dx * dx + dy * dy + dz * dz;
-        const double rinv = 1.0 / sqrt(r2);
+        const double rinv = fast_rsqrt(r2);
         const double r = r2 * rinv;
         const double den = r - kSigA;               // < 0 inside the cutoff
         // r2 < rc^2 but r rounded onto rc: the pair's energy is exactly 0 in the limit
-        const double w = den < 0.0 ? 1.0 / den : -1.0e300;
-        const double t = exp(0.2 * kSigma * w);
+        const double w = den < 0.0 ? fast_rcp(den) : -1.0e300;
+        const double t = fast_exp_neg(0.2 * kSigma * w);
         const double t2 = t * t, t4 = t2 * t2;
         const double e1 = t4 * t;                   // exp(sigma/(r - a sigma))       :459
         const double g  = t4 * t2;                  // exp(gamma sigma/(r - a sigma)) :462
@@ -300,7 +366,6 @@ __global__ void k_sum_partials(const double* __restrict__ partial, const unsigne
 // queried molecule whose host copy may have been reverted.  Overrides are used
 // from registers wherever that index is gathered; with `commit` they are also
 // written to the mirrored positions for later launches.
-//   grid = ceil(nreq/4), block = 256 (4 requests per block)
 // =====================================================================================
 struct Override { int idx; double x, y, z; };   // idx < 0: none (0-based molecule index)
 
@@ -315,11 +380,12 @@ __device__ __forceinline__ void load_pos(const double* __restrict__ P, int j, co
 
 __device__ __forceinline__ void pair_terms(double r2, double& rinv, double& e1, double& g)
 {
-    rinv = 1.0 / sqrt(r2);                       // molint.F90:278
+    rinv = fast_rsqrt(r2);                       // molint.F90:278
     const double r = r2 * rinv;                  // :286
     const double den = r - kSigA;
-    const double w = den < 0.0 ? 1.0 / den : -1.0e300;   // :288 (guard: see k_model_energy)
-    const double t = exp(0.2 * kSigma * w);
+    // r2 < rc^2 but r rounded onto rc: the term is exactly 0 in that limit          :288
+    const double w = den < 0.0 ? fast_rcp(den) : -1.0e300;
+    const double t = fast_exp_neg(0.2 * kSigma * w);
     const double t2 = t * t, t4 = t2 * t2;
     e1 = t4 * t;                                 // :291
     g  = t4 * t2;                                // :292
@@ -330,8 +396,8 @@ __device__ __forceinline__ void pair_terms(double r2, double& rinv, double& e1, 
 // cos(theta) < 0.99) and the number of list slots visited (n_i + sum of n_j over in-range j),
 // which prices the call's algorithmic bytes.
 __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P, const double* __restrict__ IV,
-                                                    const uint32_t* __restrict__ L, const int* __restrict__ NN,
-                                                    int N, int i, const Override& o1, const Override& o2, int lane,
+                                                    const uint32_t* __restrict__ LM, const int* __restrict__ NN,
+                                                    int i, const Override& o1, const Override& o2, int lane,
                                                     unsigned int& ninter, unsigned int& nslots)
 {
     double xi, yi, zi;
@@ -340,7 +406,7 @@ __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P
 
     // pass 0: imol's own list, one slot per lane
     const bool has = lane < n_i;
-    const uint32_t e = has ? L[(size_t)lane * N + i] : 0u;
+    const uint32_t e = has ? LM[(size_t)i * kRow + lane] : 0u;
     const int j = (int)(e & kJMask), kimg = (int)(e >> kJBits);
     double xj, yj, zj;
     load_pos(P, j, o1, o2, xj, yj, zj);
@@ -378,7 +444,7 @@ __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P
         const int n_j = NN[jj];
         nslots += (unsigned int)n_j;
         if (lane < n_j) {
-            const uint32_t e2 = L[(size_t)lane * N + jj];
+            const uint32_t e2 = LM[(size_t)jj * kRow + lane];
             const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
             double xk, yk, zk;
             load_pos(P, kk, o1, o2, xk, yk, zk);
@@ -404,36 +470,223 @@ __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P
     return tot;
 }
 
-// mode bit 0: evaluate with the mirrored positions (+ o2) -> e_old
-// mode bit 1: evaluate with the molecule at its trial position          -> e_new
-__global__ __launch_bounds__(256)
-void k_local_energy(const double* __restrict__ pos, const double* __restrict__ ivect,
-                    const uint32_t* __restrict__ list, const int* __restrict__ nn,
-                    const int* __restrict__ req_box, const int* __restrict__ req_imol,
-                    const double* __restrict__ req_trial,
-                    double* __restrict__ e_old, double* __restrict__ e_new,
-                    unsigned int* __restrict__ counts,   // [nreq][4]: inter_old, slots_old, inter_new, slots_new
-                    int nreq, int N, int S, int ivcap, int mode)
+// -------------------------------------------------------------------------------------
+// Batched single-move path: old AND new local energy of a trial move in one pass.
+//
+// What the two evaluations share is most of the work: the same list rows, the same
+// gathered positions and -- for the i--j--k triplets -- the same r_jk, g_jk (only the
+// molecule itself sits somewhere else), so each exp(.) of a third body is evaluated
+// once and used for both.  Lanes are packed across ALL in-range neighbours j at once:
+// the rows of the in-range j's are laid end to end (sum of nn(j) ~ 150 slots) and dealt
+// to the 64 lanes, so a pass is ~80 % full instead of one partly filled pass per j.
+// Each lane finds the j that owns its slot from the (wave-uniform) prefix sums and
+// pulls that j's vector/weights from the owning lane with cross-lane reads.
+//
+// Cases where a periodic image of the molecule itself takes part: as third body
+// (k == i through a non-identical image) both geometries are evaluated in line; a
+// molecule that neighbours its own image (cells narrower than the list radius) takes
+// the plain one-evaluation-at-a-time routine above.  The k == i self term is skipped
+// explicitly (the reference drops it through its cos(theta) >= 0.99 rule).
+// -------------------------------------------------------------------------------------
+struct MoveRes { double eo, en; unsigned int io, so, in_, sn; };
+
+template <typename PosFn, typename IvFn>
+__device__ __forceinline__ MoveRes move_energy_wave(PosFn getpos, IvFn getiv,
+                                                    const uint32_t* __restrict__ LM, const int* __restrict__ NN,
+                                                    int i, double xo, double yo, double zo,
+                                                    double xn, double yn, double zn, int lane)
 {
-    const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= nreq) return;                                   // wave-uniform
-    const int b = req_box[m];
-    const int i = req_imol[m];
+    const int n_i = NN[i];
+    const bool has = lane < n_i;
+    const uint32_t e = has ? LM[(size_t)i * kRow + lane] : 0u;
+    const int j = (int)(e & kJMask), kimg = (int)(e >> kJBits);
+    double xj, yj, zj, jvx, jvy, jvz;
+    getpos(j, xj, yj, zj);
+    getiv(kimg, jvx, jvy, jvz);
+    const int nnj = has ? NN[j] : 0;
+    const double qx = xj + jvx, qy = yj + jvy, qz = zj + jvz;                 // molint.F90:269
+    const double aox = qx - xo, aoy = qy - yo, aoz = qz - zo;                 // :272 (old position)
+    const double anx = qx - xn, any_ = qy - yn, anz = qz - zn;                //      (trial position)
+    const double r2o = aox * aox + aoy * aoy + aoz * aoz;
+    const double r2n = anx * anx + any_ * any_ + anz * anz;
+    const bool ino = has && (r2o < kRcSq), inn = has && (r2n < kRcSq);        // :276
+    double rinvo = 0.0, e1o = 0.0, go = 0.0, rinvn = 0.0, e1n = 0.0, gn = 0.0;
+    if (ino) pair_terms(r2o, rinvo, e1o, go);
+    if (inn) pair_terms(r2n, rinvn, e1n, gn);
+    const double qo = kSigSq * rinvo * rinvo, qn = kSigSq * rinvn * rinvn;
+    double acco = ino ? (kAeps * (kBigB * (qo * qo) - 1.0)) * e1o : 0.0;      // :294-297
+    double accn = inn ? (kAeps * (kBigB * (qn * qn) - 1.0)) * e1n : 0.0;
+    double t3o = 0.0, t3n = 0.0;
+    unsigned int nto = 0, ntn = 0;
+
+    const unsigned long long mo = __ballot(ino), mn = __ballot(inn);
+    // j--i--k triplets among imol's own in-range neighbours (molint.F90:302-318), old then new
+    for (unsigned long long m = mo; m;) {
+        const int jl = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const double ax = readlane_f64(aox, jl), ay = readlane_f64(aoy, jl), az = readlane_f64(aoz, jl);
+        const double rj = readlane_f64(rinvo, jl), gj = readlane_f64(go, jl);
+        if (ino && lane > jl) {
+            const double ct = ((ax * aox + ay * aoy + az * aoz) * rj) * rinvo;          // :316,365
+            if (ct < 0.99) { const double d = ct - kCos0; t3o += gj * (go * (d * d)); ++nto; }
+        }
+    }
+    for (unsigned long long m = mn; m;) {
+        const int jl = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const double ax = readlane_f64(anx, jl), ay = readlane_f64(any_, jl), az = readlane_f64(anz, jl);
+        const double rj = readlane_f64(rinvn, jl), gj = readlane_f64(gn, jl);
+        if (inn && lane > jl) {
+            const double ct = ((ax * anx + ay * any_ + az * anz) * rj) * rinvn;
+            if (ct < 0.99) { const double d = ct - kCos0; t3n += gj * (gn * (d * d)); ++ntn; }
+        }
+    }
+
+    // i--j--k triplets (molint.F90:324-343): rows of every j in range of either position, end to end
+    const unsigned long long U = mo | mn;
+    int start = 0, T = 0;
+    unsigned int so = (unsigned int)n_i, sn = (unsigned int)n_i;
+    for (unsigned long long m = U; m;) {
+        const int jl = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const int nj = __builtin_amdgcn_readlane(nnj, jl);
+        if (lane == jl) start = T;
+        T += nj;
+        if ((mo >> jl) & 1ull) so += (unsigned int)nj;
+        if ((mn >> jl) & 1ull) sn += (unsigned int)nj;
+    }
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        int own = 0, obase = 0;
+        for (unsigned long long m = U; m;) {
+            const int jl = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            const int sj = __builtin_amdgcn_readlane(start, jl);
+            if (t >= sj) { own = jl; obase = sj; }
+        }
+        const bool valid = t < T;
+        const int jj = __shfl(j, own, 64), kj = __shfl(kimg, own, 64);
+        const uint32_t e2 = valid ? LM[(size_t)jj * kRow + (t - obase)] : 0u;
+        const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
+        double xk, yk, zk, kvx, kvy, kvz, sjx, sjy, sjz;
+        getpos(kk, xk, yk, zk);
+        getiv(k2, kvx, kvy, kvz);
+        getiv(kj, sjx, sjy, sjz);
+        const double pjx = __shfl(qx, own, 64), pjy = __shfl(qy, own, 64), pjz = __shfl(qz, own, 64);
+        const double rjo = __shfl(rinvo, own, 64), rjn = __shfl(rinvn, own, 64);
+        const double gjo = __shfl(go, own, 64), gjn = __shfl(gn, own, 64);
+        const bool fo = (mo >> own) & 1ull, fn = (mn >> own) & 1ull;
+        const bool self = valid && (kk == i);
+        const bool selfimg = self && (kvx + sjx == 0.0) && (kvy + sjy == 0.0) && (kvz + sjz == 0.0);
+        const bool selfmove = self && !selfimg;
+        const double box_ = ((xk + kvx) + sjx) - pjx;                            // :332,334
+        const double boy_ = ((yk + kvy) + sjy) - pjy;
+        const double boz_ = ((zk + kvz) + sjz) - pjz;
+        const double s2o = box_ * box_ + boy_ * boy_ + boz_ * boz_;              // :335
+        double bnx = box_, bny = boy_, bnz = boz_, s2n = s2o;
+        if (selfmove) {   // an image of the molecule itself as third body: it moves too
+            bnx = ((xn + kvx) + sjx) - pjx; bny = ((yn + kvy) + sjy) - pjy; bnz = ((zn + kvz) + sjz) - pjz;
+            s2n = bnx * bnx + bny * bny + bnz * bnz;
+        }
+        const bool act = valid && !selfimg;
+        const bool ko = act && (s2o < kRcSq), kn = act && (s2n < kRcSq);         // :361
+        double rko = 0.0, gko = 0.0, e1k;
+        if (ko) pair_terms(s2o, rko, e1k, gko);
+        double rkn = rko, gkn = gko;
+        if (__ballot(selfmove) != 0ull) {
+            if (selfmove && kn) pair_terms(s2n, rkn, e1k, gkn);
+        }
+        if (ko && fo) {
+            const double ax = pjx - xo, ay = pjy - yo, az = pjz - zo;
+            const double ct = (-(ax * box_ + ay * boy_ + az * boz_) * rjo) * rko;   // :320,341,365
+            if (ct < 0.99) { const double d = ct - kCos0; t3o += gjo * (gko * (d * d)); ++nto; }
+        }
+        if (kn && fn) {
+            const double ax = pjx - xn, ay = pjy - yn, az = pjz - zn;
+            const double ct = (-(ax * bnx + ay * bny + az * bnz) * rjn) * rkn;
+            if (ct < 0.99) { const double d = ct - kCos0; t3n += gjn * (gkn * (d * d)); ++ntn; }
+        }
+    }
+    double eo = acco + kLamEps * t3o, en = accn + kLamEps * t3n;                 // :397
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        eo += __shfl_xor(eo, off, 64);
+        en += __shfl_xor(en, off, 64);
+        nto += (unsigned int)__shfl_xor((int)nto, off, 64);
+        ntn += (unsigned int)__shfl_xor((int)ntn, off, 64);
+    }
+    MoveRes r;
+    r.eo = eo; r.en = en;
+    r.io = (unsigned int)__popcll(mo) + nto; r.in_ = (unsigned int)__popcll(mn) + ntn;
+    r.so = so; r.sn = sn;
+    return r;
+}
+
+// One workgroup per work item {box, first request, last request+1}: the requests are
+// sorted by box on upload, so the workgroup stages that box's positions in LDS once
+// (LDSPOS) and its 16 wavefronts then serve the item's requests from LDS gathers.
+//   mode bit 0: write e_old (mirrored positions), bit 1: write e_new (trial position)
+template <bool LDSPOS>
+__global__ __launch_bounds__(1024)
+void k_move_energy(const double* __restrict__ pos, const double* __restrict__ ivect,
+                   const int* __restrict__ nivect, const uint32_t* __restrict__ listm,
+                   const int* __restrict__ nn, const int4* __restrict__ work,
+                   const int* __restrict__ req_imol, const double* __restrict__ req_trial,
+                   const int* __restrict__ perm,
+                   double* __restrict__ e_old, double* __restrict__ e_new,
+                   unsigned int* __restrict__ counts,   // [nreq][4]: inter_old, slots_old, inter_new, slots_new
+                   int N, int ivcap, int mode)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int4 w = work[blockIdx.x];
+    const int b = w.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* P  = pos + (size_t)b * N * 3;
     const double* IV = ivect + (size_t)b * ivcap * 3;
-    const uint32_t* L = list + (size_t)b * S * N;
+    const uint32_t* LM = listm + (size_t)b * N * kRow;
     const int* NN = nn + (size_t)b * N;
-    Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
-    unsigned int ni = 0, ns = 0;
-    if (mode & 1) {
-        const double e = local_energy_wave(P, IV, L, NN, N, i, none, none, lane, ni, ns);
-        if (lane == 0) { e_old[m] = e; counts[4 * (size_t)m] = ni; counts[4 * (size_t)m + 1] = ns; }
+    const int niv = nivect[b];
+
+    double* siv = smem;
+    double* spos = smem + (size_t)ivcap * 3;
+    for (int t = tid; t < niv * 3; t += 1024) siv[t] = IV[t];
+    if (LDSPOS) {
+        for (int t = tid; t < 3 * N; t += 1024) spos[t] = P[t];
     }
-    if (mode & 2) {
-        Override tr; tr.idx = i; tr.x = req_trial[3 * m]; tr.y = req_trial[3 * m + 1]; tr.z = req_trial[3 * m + 2];
-        const double e = local_energy_wave(P, IV, L, NN, N, i, tr, none, lane, ni, ns);
-        if (lane == 0) { e_new[m] = e; counts[4 * (size_t)m + 2] = ni; counts[4 * (size_t)m + 3] = ns; }
+    __syncthreads();
+
+    auto getiv = [&](int k, double& x, double& y, double& z) { x = siv[3 * k]; y = siv[3 * k + 1]; z = siv[3 * k + 2]; };
+    auto getpos = [&](int jx, double& x, double& y, double& z) {
+        const double* p = LDSPOS ? (spos + 3 * (size_t)jx) : (P + 3 * (size_t)jx);
+        x = p[0]; y = p[1]; z = p[2];
+    };
+
+    for (int m = w.y + wave; m < w.z; m += 16) {
+        const int i = req_imol[m];
+        double xo, yo, zo;
+        getpos(i, xo, yo, zo);
+        double xn = xo, yn = yo, zn = zo;
+        if (mode & 2) { xn = req_trial[3 * (size_t)m]; yn = req_trial[3 * (size_t)m + 1]; zn = req_trial[3 * (size_t)m + 2]; }
+
+        // does the molecule neighbour one of its own periodic images?  (wave-uniform)
+        const int n_i = NN[i];
+        const uint32_t e = lane < n_i ? LM[(size_t)i * kRow + lane] : 0xffffffffu;
+        const bool ownimage = __ballot((int)(e & kJMask) == i && lane < n_i) != 0ull;
+
+        MoveRes r;
+        if (!ownimage) {
+            r = move_energy_wave(getpos, getiv, LM, NN, i, xo, yo, zo, xn, yn, zn, lane);
+        } else {
+            Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
+            Override tr; tr.idx = i; tr.x = xn; tr.y = yn; tr.z = zn;
+            r.eo = local_energy_wave(P, IV, LM, NN, i, none, none, lane, r.io, r.so);
+            r.en = local_energy_wave(P, IV, LM, NN, i, tr, none, lane, r.in_, r.sn);
+        }
+        if (lane == 0) {
+            const size_t o = (size_t)perm[m];
+            if (mode & 1) { e_old[o] = r.eo; counts[4 * o] = r.io; counts[4 * o + 1] = r.so; }
+            if (mode & 2) { e_new[o] = r.en; counts[4 * o + 2] = r.in_; counts[4 * o + 3] = r.sn; }
+        }
     }
 }
 
@@ -441,15 +694,15 @@ void k_local_energy(const double* __restrict__ pos, const double* __restrict__ i
 // one wave, result written straight to host-visible memory.
 __global__ __launch_bounds__(64)
 void k_local_energy_single(double* __restrict__ pos, const double* __restrict__ ivect,
-                           const uint32_t* __restrict__ list, const int* __restrict__ nn,
+                           const uint32_t* __restrict__ listm, const int* __restrict__ nn,
                            int b, int i, Override o1, Override o2, int commit,
-                           double* __restrict__ e_out, int N, int S, int ivcap)
+                           double* __restrict__ e_out, int N, int ivcap)
 {
     const int lane = threadIdx.x;
     double* P = pos + (size_t)b * N * 3;
     unsigned int ni, ns;
-    const double e = local_energy_wave(P, ivect + (size_t)b * ivcap * 3, list + (size_t)b * S * N,
-                                       nn + (size_t)b * N, N, i, o1, o2, lane, ni, ns);
+    const double e = local_energy_wave(P, ivect + (size_t)b * ivcap * 3, listm + (size_t)b * N * kRow,
+                                       nn + (size_t)b * N, i, o1, o2, lane, ni, ns);
     if (lane == 0) {
         *e_out = e;
         if (commit) {   // these two indices are never read from memory in this launch (overrides win)

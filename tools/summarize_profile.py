@@ -48,7 +48,7 @@ for k, r in stats.items():
     hb = (2 * fa + wa) * 1024 if fa is not None and wa is not None else None
     short = k.replace("mw::", "").split("<")[0]
     ev = bench["kernels"].get(short, {}).get("avg_ms")
-    if hb is not None and short in ("k_model_energy", "k_local_energy"):
+    if hb is not None and short in ("k_model_energy", "k_move_energy"):
         traffic[short] = hb
     lines.append(f"| {k} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {'' if ev is None else f'{ev*1e3:.1f}'} | "
                  f"{'' if fa is None else f'{fa:.0f}'} | {'' if wa is None else f'{wa:.0f}'} | {'' if hb is None else f'{hb:.4g}'} |")
