@@ -80,6 +80,11 @@ struct Ctx {
 Ctx g;
 
 bool lds_fits(int N, int ivcap) { return (size_t)(3 * (size_t)N + 3 * (size_t)ivcap) * sizeof(double) <= (size_t)kLdsBudget; }
+constexpr size_t kMoveScratch = 16 * sizeof(mw::WaveScratch);
+bool lds_fits_move(int N, int ivcap)
+{
+    return kMoveScratch + (size_t)(3 * (size_t)N + 3 * (size_t)ivcap) * sizeof(double) <= (size_t)kLdsBudget;
+}
 
 int check_live() { return g.live ? 0 : fail("mw: engine not initialised (call mw_init / energy_init first)"); }
 int check_box(int ils) { return (ils >= 1 && ils <= g.nbox) ? 0 : fail("mw: box index %d outside 1..%d", ils, g.nbox); }
@@ -541,7 +546,7 @@ int mw_moves_upload(int n, const int* ils, const int* imol, const double* trial_
         if (trial_xyz) { tr[3 * (size_t)s] = trial_xyz[3 * (size_t)m]; tr[3 * (size_t)s + 1] = trial_xyz[3 * (size_t)m + 1]; tr[3 * (size_t)s + 2] = trial_xyz[3 * (size_t)m + 2]; }
     }
     // LDS staging pays when a box's 24N bytes are shared by enough requests
-    g.mlds = lds_fits(g.N, g.ivcap) && ((long long)n * 2048 >= (long long)used_boxes * 24 * g.N);
+    g.mlds = lds_fits_move(g.N, g.ivcap) && ((long long)n * 2048 >= (long long)used_boxes * 24 * g.N);
     const int chunk = g.mlds ? 256 : 16;
     std::vector<int4> work;
     for (int b = 0; b < g.nbox; ++b)
@@ -569,7 +574,7 @@ int mw_moves_upload(int n, const int* ils, const int* imol, const double* trial_
 static int launch_moves(int mode)
 {
     if (g.mn == 0) return 0;
-    const size_t iv_bytes = (size_t)3 * g.ivcap * sizeof(double);
+    const size_t iv_bytes = kMoveScratch + (size_t)3 * g.ivcap * sizeof(double);
     if (g.mlds)
         hipLaunchKernelGGL(mw::k_move_energy<true>, dim3(g.mwork_n), dim3(1024), iv_bytes + (size_t)3 * g.N * sizeof(double), g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,

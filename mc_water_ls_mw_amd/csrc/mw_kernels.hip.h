@@ -490,12 +490,28 @@ __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P
 // -------------------------------------------------------------------------------------
 struct MoveRes { double eo, en; unsigned int io, so, in_, sn; };
 
+// Per-wavefront LDS scratch: the in-range neighbours of the molecule, compacted by rank, so
+// that any lane can pull neighbour `r`'s record with plain LDS reads (a broadcast when lanes
+// of one group read the same record).
+constexpr int kCap = 24;                       // more in-range neighbours than this: plain routine
+struct WaveScratch {
+    double q[3][kCap];                         // position of j's image            (molint.F90:269)
+    double rinvo[kCap], rinvn[kCap];           // 1/r_ij at the old / trial position
+    double go[kCap], gn[kCap];                 // exp(gamma sigma/(r_ij - a sigma)) old / trial
+    int j[kCap], kimg[kCap], flag[kCap];       // molecule, image, bit0 = in range (old), bit1 = (trial)
+    int start[kCap + 2];                       // first slot of j's row in the end-to-end numbering
+};
+static_assert(sizeof(WaveScratch) % 8 == 0, "scratch records must keep 8-byte alignment");
+
+// Returns false (nothing written) when the request needs the plain routine.
 template <typename PosFn, typename IvFn>
-__device__ __forceinline__ MoveRes move_energy_wave(PosFn getpos, IvFn getiv,
-                                                    const uint32_t* __restrict__ LM, const int* __restrict__ NN,
-                                                    int i, double xo, double yo, double zo,
-                                                    double xn, double yn, double zn, int lane)
+__device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv,
+                                                 const uint32_t* __restrict__ LM, const int* __restrict__ NN,
+                                                 WaveScratch* __restrict__ ws,
+                                                 int i, double xo, double yo, double zo,
+                                                 double xn, double yn, double zn, int lane, MoveRes& res)
 {
+    // ---- pass 0: imol's own row, one slot per lane ----------------------------------------
     const int n_i = NN[i];
     const bool has = lane < n_i;
     const uint32_t e = has ? LM[(size_t)i * kRow + lane] : 0u;
@@ -510,6 +526,11 @@ __device__ __forceinline__ MoveRes move_energy_wave(PosFn getpos, IvFn getiv,
     const double r2o = aox * aox + aoy * aoy + aoz * aoz;
     const double r2n = anx * anx + any_ * any_ + anz * anz;
     const bool ino = has && (r2o < kRcSq), inn = has && (r2n < kRcSq);        // :276
+    const bool inu = ino || inn;
+    const unsigned long long U = __ballot(inu);
+    const int cntU = __popcll(U);
+    if (cntU > kCap) return false;
+
     double rinvo = 0.0, e1o = 0.0, go = 0.0, rinvn = 0.0, e1n = 0.0, gn = 0.0;
     if (ino) pair_terms(r2o, rinvo, e1o, go);
     if (inn) pair_terms(r2n, rinvn, e1n, gn);
@@ -519,63 +540,76 @@ __device__ __forceinline__ MoveRes move_energy_wave(PosFn getpos, IvFn getiv,
     double t3o = 0.0, t3n = 0.0;
     unsigned int nto = 0, ntn = 0;
 
-    const unsigned long long mo = __ballot(ino), mn = __ballot(inn);
-    // j--i--k triplets among imol's own in-range neighbours (molint.F90:302-318), old then new
-    for (unsigned long long m = mo; m;) {
-        const int jl = __ffsll((long long)m) - 1;
-        m &= m - 1ull;
-        const double ax = readlane_f64(aox, jl), ay = readlane_f64(aoy, jl), az = readlane_f64(aoz, jl);
-        const double rj = readlane_f64(rinvo, jl), gj = readlane_f64(go, jl);
-        if (ino && lane > jl) {
-            const double ct = ((ax * aox + ay * aoy + az * aoz) * rj) * rinvo;          // :316,365
-            if (ct < 0.99) { const double d = ct - kCos0; t3o += gj * (go * (d * d)); ++nto; }
-        }
+    // ---- compact the in-range neighbours into the wave's scratch ----------------------------
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(U >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)U, 0u));
+    int incl = inu ? nnj : 0;                                                  // inclusive scan of row lengths
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
     }
-    for (unsigned long long m = mn; m;) {
-        const int jl = __ffsll((long long)m) - 1;
-        m &= m - 1ull;
-        const double ax = readlane_f64(anx, jl), ay = readlane_f64(any_, jl), az = readlane_f64(anz, jl);
-        const double rj = readlane_f64(rinvn, jl), gj = readlane_f64(gn, jl);
-        if (inn && lane > jl) {
-            const double ct = ((ax * anx + ay * any_ + az * anz) * rj) * rinvn;
-            if (ct < 0.99) { const double d = ct - kCos0; t3n += gj * (gn * (d * d)); ++ntn; }
+    const int T = __builtin_amdgcn_readlane(incl, 63);
+    if (inu) {
+        ws->q[0][rank] = qx; ws->q[1][rank] = qy; ws->q[2][rank] = qz;
+        ws->rinvo[rank] = rinvo; ws->rinvn[rank] = rinvn; ws->go[rank] = go; ws->gn[rank] = gn;
+        ws->j[rank] = j; ws->kimg[rank] = kimg; ws->flag[rank] = (ino ? 1 : 0) | (inn ? 2 : 0);
+        ws->start[rank] = incl - nnj;
+    }
+    unsigned int so = (unsigned int)n_i, sn = (unsigned int)n_i;              // list slots visited
+    {
+        int a = ino ? nnj : 0, b = inn ? nnj : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+        so += (unsigned int)a; sn += (unsigned int)b;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- j--i--k triplets: pairs (a < b) of in-range neighbours, one pair per lane ------------
+    // (molint.F90:302-318; a is the earlier list slot, so cos is formed in the reference's order)
+    const int npairs = cntU * (cntU - 1) / 2;
+    for (int p0 = 0; p0 < npairs; p0 += 64) {
+        const int p = p0 + lane;
+        int b = (int)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+        if (b * (b - 1) / 2 > p) --b;
+        if ((b + 1) * b / 2 <= p) ++b;
+        const int a = p - b * (b - 1) / 2;
+        if (p < npairs) {
+            const int fa = ws->flag[a], fb = ws->flag[b];
+            const double qax = ws->q[0][a], qay = ws->q[1][a], qaz = ws->q[2][a];
+            const double qbx = ws->q[0][b], qby = ws->q[1][b], qbz = ws->q[2][b];
+            if (fa & fb & 1) {
+                const double ct = (((qax - xo) * (qbx - xo) + (qay - yo) * (qby - yo) + (qaz - zo) * (qbz - zo))
+                                   * ws->rinvo[a]) * ws->rinvo[b];                              // :316,365
+                if (ct < 0.99) { const double d = ct - kCos0; t3o += ws->go[a] * (ws->go[b] * (d * d)); ++nto; }
+            }
+            if (fa & fb & 2) {
+                const double ct = (((qax - xn) * (qbx - xn) + (qay - yn) * (qby - yn) + (qaz - zn) * (qbz - zn))
+                                   * ws->rinvn[a]) * ws->rinvn[b];
+                if (ct < 0.99) { const double d = ct - kCos0; t3n += ws->gn[a] * (ws->gn[b] * (d * d)); ++ntn; }
+            }
         }
     }
 
-    // i--j--k triplets (molint.F90:324-343): rows of every j in range of either position, end to end
-    const unsigned long long U = mo | mn;
-    int start = 0, T = 0;
-    unsigned int so = (unsigned int)n_i, sn = (unsigned int)n_i;
-    for (unsigned long long m = U; m;) {
-        const int jl = __ffsll((long long)m) - 1;
-        m &= m - 1ull;
-        const int nj = __builtin_amdgcn_readlane(nnj, jl);
-        if (lane == jl) start = T;
-        T += nj;
-        if ((mo >> jl) & 1ull) so += (unsigned int)nj;
-        if ((mn >> jl) & 1ull) sn += (unsigned int)nj;
-    }
+    // ---- i--j--k triplets (molint.F90:324-343): the rows of all in-range j, end to end --------
     for (int t0 = 0; t0 < T; t0 += 64) {
         const int t = t0 + lane;
-        int own = 0, obase = 0;
-        for (unsigned long long m = U; m;) {
-            const int jl = __ffsll((long long)m) - 1;
-            m &= m - 1ull;
-            const int sj = __builtin_amdgcn_readlane(start, jl);
-            if (t >= sj) { own = jl; obase = sj; }
-        }
         const bool valid = t < T;
-        const int jj = __shfl(j, own, 64), kj = __shfl(kimg, own, 64);
-        const uint32_t e2 = valid ? LM[(size_t)jj * kRow + (t - obase)] : 0u;
+        int own = 0;                                         // largest r with start[r] <= t
+#pragma unroll
+        for (int step = 16; step > 0; step >>= 1) {
+            const int cand = own + step;
+            if (cand < cntU && ws->start[cand < kCap ? cand : kCap - 1] <= t) own = cand;
+        }
+        const int jj = ws->j[own], kj = ws->kimg[own], fl = ws->flag[own];
+        const uint32_t e2 = valid ? LM[(size_t)jj * kRow + (t - ws->start[own])] : 0u;
         const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
         double xk, yk, zk, kvx, kvy, kvz, sjx, sjy, sjz;
         getpos(kk, xk, yk, zk);
         getiv(k2, kvx, kvy, kvz);
         getiv(kj, sjx, sjy, sjz);
-        const double pjx = __shfl(qx, own, 64), pjy = __shfl(qy, own, 64), pjz = __shfl(qz, own, 64);
-        const double rjo = __shfl(rinvo, own, 64), rjn = __shfl(rinvn, own, 64);
-        const double gjo = __shfl(go, own, 64), gjn = __shfl(gn, own, 64);
-        const bool fo = (mo >> own) & 1ull, fn = (mn >> own) & 1ull;
+        const double pjx = ws->q[0][own], pjy = ws->q[1][own], pjz = ws->q[2][own];
         const bool self = valid && (kk == i);
         const bool selfimg = self && (kvx + sjx == 0.0) && (kvy + sjy == 0.0) && (kvz + sjz == 0.0);
         const bool selfmove = self && !selfimg;
@@ -596,17 +630,17 @@ __device__ __forceinline__ MoveRes move_energy_wave(PosFn getpos, IvFn getiv,
         if (__ballot(selfmove) != 0ull) {
             if (selfmove && kn) pair_terms(s2n, rkn, e1k, gkn);
         }
-        if (ko && fo) {
-            const double ax = pjx - xo, ay = pjy - yo, az = pjz - zo;
-            const double ct = (-(ax * box_ + ay * boy_ + az * boz_) * rjo) * rko;   // :320,341,365
-            if (ct < 0.99) { const double d = ct - kCos0; t3o += gjo * (gko * (d * d)); ++nto; }
+        if (ko && (fl & 1)) {
+            const double ct = (-((pjx - xo) * box_ + (pjy - yo) * boy_ + (pjz - zo) * boz_) * ws->rinvo[own]) * rko;   // :320,341,365
+            if (ct < 0.99) { const double d = ct - kCos0; t3o += ws->go[own] * (gko * (d * d)); ++nto; }
         }
-        if (kn && fn) {
-            const double ax = pjx - xn, ay = pjy - yn, az = pjz - zn;
-            const double ct = (-(ax * bnx + ay * bny + az * bnz) * rjn) * rkn;
-            if (ct < 0.99) { const double d = ct - kCos0; t3n += gjn * (gkn * (d * d)); ++ntn; }
+        if (kn && (fl & 2)) {
+            const double ct = (-((pjx - xn) * bnx + (pjy - yn) * bny + (pjz - zn) * bnz) * ws->rinvn[own]) * rkn;
+            if (ct < 0.99) { const double d = ct - kCos0; t3n += ws->gn[own] * (gkn * (d * d)); ++ntn; }
         }
     }
+    __builtin_amdgcn_wave_barrier();                          // scratch is reused by the wave's next request
+
     double eo = acco + kLamEps * t3o, en = accn + kLamEps * t3n;                 // :397
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -615,11 +649,10 @@ __device__ __forceinline__ MoveRes move_energy_wave(PosFn getpos, IvFn getiv,
         nto += (unsigned int)__shfl_xor((int)nto, off, 64);
         ntn += (unsigned int)__shfl_xor((int)ntn, off, 64);
     }
-    MoveRes r;
-    r.eo = eo; r.en = en;
-    r.io = (unsigned int)__popcll(mo) + nto; r.in_ = (unsigned int)__popcll(mn) + ntn;
-    r.so = so; r.sn = sn;
-    return r;
+    res.eo = eo; res.en = en;
+    res.io = (unsigned int)__popcll(__ballot(ino)) + nto; res.in_ = (unsigned int)__popcll(__ballot(inn)) + ntn;
+    res.so = so; res.sn = sn;
+    return true;
 }
 
 // One workgroup per work item {box, first request, last request+1}: the requests are
@@ -647,8 +680,10 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
     const int* NN = nn + (size_t)b * N;
     const int niv = nivect[b];
 
-    double* siv = smem;
-    double* spos = smem + (size_t)ivcap * 3;
+    // dynamic LDS: [16 wave scratches][image vectors][positions]
+    WaveScratch* ws = reinterpret_cast<WaveScratch*>(smem) + wave;
+    double* siv = smem + (16 * sizeof(WaveScratch)) / sizeof(double);
+    double* spos = siv + (size_t)ivcap * 3;
     for (int t = tid; t < niv * 3; t += 1024) siv[t] = IV[t];
     if (LDSPOS) {
         for (int t = tid; t < 3 * N; t += 1024) spos[t] = P[t];
@@ -674,9 +709,8 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
         const bool ownimage = __ballot((int)(e & kJMask) == i && lane < n_i) != 0ull;
 
         MoveRes r;
-        if (!ownimage) {
-            r = move_energy_wave(getpos, getiv, LM, NN, i, xo, yo, zo, xn, yn, zn, lane);
-        } else {
+        const bool fast = !ownimage && move_energy_wave(getpos, getiv, LM, NN, ws, i, xo, yo, zo, xn, yn, zn, lane, r);
+        if (!fast) {
             Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
             Override tr; tr.idx = i; tr.x = xn; tr.y = yn; tr.z = zn;
             r.eo = local_energy_wave(P, IV, LM, NN, i, none, none, lane, r.io, r.so);
