@@ -79,7 +79,12 @@ struct Ctx {
 
 Ctx g;
 
-bool lds_fits(int N, int ivcap) { return (size_t)(3 * (size_t)N + 3 * (size_t)ivcap) * sizeof(double) <= (size_t)kLdsBudget; }
+constexpr size_t kQueue1024 = (size_t)mw::kQCap * 1024 * sizeof(uint32_t);
+constexpr size_t kQueue256 = (size_t)mw::kQCap * 256 * sizeof(uint32_t);
+bool lds_fits(int N, int ivcap)
+{
+    return kQueue1024 + (size_t)(3 * (size_t)N + 3 * (size_t)ivcap) * sizeof(double) <= (size_t)kLdsBudget;
+}
 constexpr size_t kMoveScratch = 16 * sizeof(mw::WaveScratch);
 bool lds_fits_move(int N, int ivcap)
 {
@@ -174,11 +179,11 @@ Geo model_geo(int count)
         int want = (2 * g.cu + count - 1) / count;
         int maxsplit = (g.N + ge.block - 1) / ge.block;
         ge.nsplit = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
-        ge.shmem = (size_t)(3 * (size_t)g.N + 3 * (size_t)g.ivcap) * sizeof(double);
+        ge.shmem = kQueue1024 + (size_t)(3 * (size_t)g.N + 3 * (size_t)g.ivcap) * sizeof(double);
     } else {
         ge.block = 256;
         ge.nsplit = (g.N + ge.block - 1) / ge.block;
-        ge.shmem = (size_t)(3 * (size_t)g.ivcap) * sizeof(double);
+        ge.shmem = kQueue256 + (size_t)(3 * (size_t)g.ivcap) * sizeof(double);
     }
     if (ge.nsplit > g.nsplit_max) ge.nsplit = g.nsplit_max;
     ge.chunk = (g.N + ge.nsplit - 1) / ge.nsplit;

@@ -203,8 +203,9 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
 // exp(sigma/(r-a sigma)) = t^5 and g = exp(1.2 sigma/(r - a sigma)) = t^6.
 //
 // Divergence control: phase 1 runs the cheap distance test over all list slots
-// and records the in-range slots in a 64-bit mask; phase 2 runs the expensive
-// part only over set bits, so a wave's trip count is its largest in-range count
+// (list read eight slots at a time, so eight coalesced loads are in flight) and
+// parks the in-range entries in a per-thread LDS queue; phase 2 runs the expensive
+// part only over that queue, so a wave's trip count is its largest in-range count
 // (4-12) rather than its largest list length (16-25).
 //
 // LDSPOS = true : one workgroup stages the whole box's positions in LDS
@@ -215,33 +216,46 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
 // =====================================================================================
 struct AtomSum { double e; unsigned long long np, nt; };
 
-template <typename PosFn, typename IvFn>
+constexpr int kQCap = 12;   // in-range entries per molecule parked in LDS between the two phases
+
+// `queue` points at this thread's column of an LDS array [kQCap][BLOCK] (entry q at queue[q*BLOCK]:
+// consecutive threads, consecutive banks).
+template <int BLOCK, typename PosFn, typename IvFn>
 __device__ __forceinline__ AtomSum atom_energy(int i, int n, const uint32_t* __restrict__ L, int N,
-                                               PosFn getpos, IvFn getiv)
+                                               uint32_t* __restrict__ queue, PosFn getpos, IvFn getiv)
 {
     double xi, yi, zi;
     getpos(i, xi, yi, zi);
 
-    // phase 1: which list slots are within rc
-    unsigned long long mask = 0ull;
-    for (int s = 0; s < n; ++s) {
-        const uint32_t e = L[(size_t)s * N + i];
-        double xj, yj, zj, ix, iy, iz;
-        getpos((int)(e & kJMask), xj, yj, zj);
-        getiv((int)(e >> kJBits), ix, iy, iz);
-        const double dx = (xj + ix) - xi, dy = (yj + iy) - yi, dz = (zj + iz) - zi;   // molint.F90:447,450
-        const double r2 = dx * dx + dy * dy + dz * dz;
-        if (r2 < kRcSq) mask |= (1ull << s);                                          // :454
+    // phase 1: cheap distance test over all list slots.  The list is read eight slots at a time
+    // -- eight independent, coalesced loads in flight -- and the in-range entries are parked in LDS.
+    int cnt = 0;
+    unsigned long long over = 0ull;             // in-range slots beyond the LDS queue (re-read later)
+    for (int s0 = 0; s0 < n; s0 += 8) {
+        uint32_t e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = (s0 + u < n) ? L[(size_t)(s0 + u) * N + i] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (s0 + u < n) {
+                double xj, yj, zj, ix, iy, iz;
+                getpos((int)(e[u] & kJMask), xj, yj, zj);
+                getiv((int)(e[u] >> kJBits), ix, iy, iz);
+                const double dx = (xj + ix) - xi, dy = (yj + iy) - yi, dz = (zj + iz) - zi;   // molint.F90:447,450
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                if (r2 < kRcSq) {                                                             // :454
+                    if (cnt < kQCap) queue[cnt * BLOCK] = e[u];
+                    else over |= 1ull << (s0 + u);
+                    ++cnt;
+                }
+            }
+        }
     }
 
-    // phase 2: pair term and moments over the in-range slots only
+    // phase 2: pair term and moments over the in-range entries only
     double e2 = 0.0, S0 = 0.0, Q = 0.0, S1x = 0.0, S1y = 0.0, S1z = 0.0;
     double Sxx = 0.0, Syy = 0.0, Szz = 0.0, Sxy = 0.0, Sxz = 0.0, Syz = 0.0;
-    const int cnt = __popcll(mask);
-    while (mask) {
-        const int s = __ffsll((long long)mask) - 1;
-        mask &= mask - 1ull;
-        const uint32_t e = L[(size_t)s * N + i];
+    auto accumulate = [&](uint32_t e) {
         double xj, yj, zj, ix, iy, iz;
         getpos((int)(e & kJMask), xj, yj, zj);
         getiv((int)(e >> kJBits), ix, iy, iz);
@@ -264,6 +278,13 @@ __device__ __forceinline__ AtomSum atom_energy(int i, int n, const uint32_t* __r
         S1x += gx; S1y += gy; S1z += gz;
         Sxx += gx * ux; Syy += gy * uy; Szz += gz * uz;
         Sxy += gx * uy; Sxz += gx * uz; Syz += gy * uz;
+    };
+    const int nq = cnt < kQCap ? cnt : kQCap;
+    for (int q = 0; q < nq; ++q) accumulate(queue[q * BLOCK]);
+    while (over) {
+        const int s = __ffsll((long long)over) - 1;
+        over &= over - 1ull;
+        accumulate(L[(size_t)s * N + i]);
     }
     const double F2 = Sxx * Sxx + Syy * Syy + Szz * Szz + 2.0 * (Sxy * Sxy + Sxz * Sxz + Syz * Syz);
     const double F1 = S1x * S1x + S1y * S1y + S1z * S1z;
@@ -296,8 +317,10 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
     const int* NN = nn + (size_t)b * N;
     const int niv = nivect[b];
 
-    double* siv = smem;                         // niv*3 doubles (ivcap*3 reserved)
-    double* spos = smem + (size_t)ivcap * 3;    // 3N doubles when LDSPOS
+    // dynamic LDS: [in-range queue kQCap x BLOCK u32][image vectors][positions when LDSPOS]
+    uint32_t* queue = reinterpret_cast<uint32_t*>(smem) + tid;
+    double* siv = smem + ((size_t)kQCap * BLOCK * sizeof(uint32_t)) / sizeof(double);
+    double* spos = siv + (size_t)ivcap * 3;
     for (int t = tid; t < niv * 3; t += BLOCK) siv[t] = IV[t];
     if (LDSPOS) {
         for (int t = tid; t < 3 * N; t += BLOCK) spos[t] = P[t];   // flat, fully coalesced copy
@@ -315,7 +338,7 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
     const int a0 = split * chunk;
     const int a1 = min(N, a0 + chunk);
     for (int i = a0 + tid; i < a1; i += BLOCK) {
-        AtomSum a = atom_energy(i, NN[i], L, N, getpos, getiv);
+        AtomSum a = atom_energy<BLOCK>(i, NN[i], L, N, queue, getpos, getiv);
         esum += a.e; np += a.np; nt += a.nt;
     }
 

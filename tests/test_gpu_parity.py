@@ -71,6 +71,53 @@ def test_4096_boxes_match_reference(name, c_oracle):
     _check_case(load_golden(name), c_oracle, full_lists=False)
 
 
+def test_32768_stress_box_list_rebuild_and_full_energy():
+    """BASELINE.json configs[4]: 32768-molecule ice Ih, neighbour-list rebuild + full energy
+    (positions do not fit LDS: the full-box kernel gathers from L2)."""
+    z = load_golden("ih32768_t015")
+    em = _engine(z)
+    try:
+        nn, jn, vn = em.neighbours(1)
+        assert np.array_equal(nn, z["nn"])
+        assert list_digest(nn, jn, vn) == str(z["list_sha256"])
+        e_ref = float(z["model_energy"])
+        assert abs(em.model_energy[0] - e_ref) <= RTOL * abs(e_ref)
+        loc = em.local_energy_batch(1, np.arange(1, int(z["n"]) + 1))
+        assert abs(loc.sum() - float(z["local_sum"])) <= RTOL * abs(float(z["local_sum"]))
+        # G4: sum_i local = 2 E2 + 3 E3 and model = E2 + E3, so E3 = sum_local - 2 model must be positive and small
+        e3 = loc.sum() - 2 * em.model_energy[0]
+        assert 0 < e3 < 0.2 * abs(e_ref)
+    finally:
+        em.energy_deinit()
+
+
+def test_batched_walkers_match_single_box_results(c_oracle):
+    """Many boxes in one launch (the bench path) give the same numbers as one box at a time."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.energy import load_boxes
+    h, x0 = lat.ice_box("ih", (3, 2, 2), 0.0)
+    xs = [lat.thermalise(x0, 0.15, 100 + w) for w in range(7)]
+    em = load_boxes([h] * 7, xs)
+    try:
+        iv = c_oracle.ivects(h)
+        e = em.model_energy_batch(1, 7)
+        rng = np.random.default_rng(3)
+        ils = rng.integers(1, 8, 500).astype(np.int32)
+        imol = rng.integers(1, len(x0) + 1, 500).astype(np.int32)
+        trial = np.stack([xs[b - 1][i - 1] for b, i in zip(ils, imol)]) + rng.normal(0, 0.5, (500, 3))
+        eo, en = em.delta_energy_batch(ils, imol, trial)
+        for w in range(7):
+            nn, jn, vn = c_oracle.neighbours(xs[w], iv)
+            ref = c_oracle.model_energy(xs[w], iv, nn, jn, vn)
+            assert abs(e[w] - ref) <= RTOL * abs(ref)
+            sel = np.nonzero(ils == w + 1)[0]
+            ro, rn = c_oracle.trial_moves(imol[sel], trial[sel], xs[w], iv, nn, jn, vn)
+            assert np.all(np.abs(eo[sel] - ro) <= RTOL * np.abs(ro))
+            assert np.all(np.abs((en[sel] - eo[sel]) - (rn - ro)) <= DE_ATOL)
+    finally:
+        em.energy_deinit()
+
+
 def test_single_call_local_energy_follows_host_moves(c_oracle):
     """The drop-in protocol of mc_water_translation (mc_moves.F90:1010-1190):
     old energy, move the molecule on the HOST only, new energy, silently revert
