@@ -54,6 +54,15 @@ struct Ctx {
     uint32_t* d_listm = nullptr;   // molecule-major [box][N][64]
     int* d_nn = nullptr;
     int* d_stats = nullptr;
+    // cell-grid neighbour builder
+    mw::GridDesc* d_grid = nullptr;
+    int* d_usegrid = nullptr;
+    int *d_cellid = nullptr, *d_shift = nullptr, *d_sorted = nullptr;
+    int *d_ccount = nullptr, *d_cstart = nullptr, *d_ccursor = nullptr;
+    int cstride = 0;
+    std::vector<mw::GridDesc> h_grid;
+    std::vector<int> h_usegrid;
+    bool force_brute = false;
     double* d_partial = nullptr;
     unsigned long long* d_cpartial = nullptr;
     double* d_energy = nullptr;
@@ -102,7 +111,7 @@ int check_mol(int imol) { return (imol >= 1 && imol <= g.N) ? 0 : fail("mw: mole
 
 // Image vectors exactly as compute_ivects builds them (molint.F90:174-217):
 // central cell first, then icell, jcell, kcell loops (kcell fastest), (sx+sy)+sz.
-int host_ivects(const double h[9], std::vector<double>& out)
+int host_ivects(const double h[9], std::vector<double>& out, int imv[3])
 {
     const double* h1 = h; const double* h2 = h + 3; const double* h3 = h + 6;
     const double rc = mw::kSmallA * mw::kSigma;
@@ -110,6 +119,7 @@ int host_ivects(const double h[9], std::vector<double>& out)
     const int jm = (int)std::floor(rc / std::sqrt(h2[0] * h2[0] + h2[1] * h2[1] + h2[2] * h2[2])) + 1;
     const int km = (int)std::floor(rc / std::sqrt(h3[0] * h3[0] + h3[1] * h3[1] + h3[2] * h3[2])) + 1;
     const long long n = (long long)(2 * im + 1) * (2 * jm + 1) * (2 * km + 1);                            // :193
+    imv[0] = im; imv[1] = jm; imv[2] = km;
     if (n > MW_MAX_IVECT) return -1;
     out.assign((size_t)n * 3, 0.0);                                                                       // :197
     size_t k = 1;
@@ -129,6 +139,43 @@ int host_ivects(const double h[9], std::vector<double>& out)
         }
     }
     return (int)n;
+}
+
+// Grid for the cell-list neighbour builder: spacing >= list radius along every cell vector.
+// nc = 0 means "fewer than 3 cells somewhere": that box keeps the brute-force kernel.
+mw::GridDesc make_grid(const double h[9], const int imv[3], int max_cells)
+{
+    mw::GridDesc G;
+    std::memset(&G, 0, sizeof G);
+    const double* a = h; const double* b = h + 3; const double* c = h + 6;     // cell vectors
+    const double bc[3] = {b[1] * c[2] - b[2] * c[1], b[2] * c[0] - b[0] * c[2], b[0] * c[1] - b[1] * c[0]};
+    const double ca[3] = {c[1] * a[2] - c[2] * a[1], c[2] * a[0] - c[0] * a[2], c[0] * a[1] - c[1] * a[0]};
+    const double ab[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    const double det = a[0] * bc[0] + a[1] * bc[1] + a[2] * bc[2];
+    G.im[0] = imv[0]; G.im[1] = imv[1]; G.im[2] = imv[2];
+    if (!(std::fabs(det) > 0.0)) return G;
+    // r = s1 a + s2 b + s3 c  =>  s1 = (b x c).r / det, ...
+    for (int d = 0; d < 3; ++d) { G.hinv[d] = bc[d] / det; G.hinv[3 + d] = ca[d] / det; G.hinv[6 + d] = ab[d] / det; }
+    const double rn = mw::kRn * (1.0 + 1.0e-9);
+    const double* cr[3] = {bc, ca, ab};
+    int nc[3];
+    for (int d = 0; d < 3; ++d) {
+        const double width = std::fabs(det) / std::sqrt(cr[d][0] * cr[d][0] + cr[d][1] * cr[d][1] + cr[d][2] * cr[d][2]);
+        const double q = std::floor(width / rn);
+        nc[d] = q > 1024.0 ? 1024 : (int)q;
+        if (nc[d] < 3) return G;                          // nc stays 0: brute force for this box
+        if (imv[d] > 500) return G;
+    }
+    while ((long long)nc[0] * nc[1] * nc[2] > max_cells) {   // coarser cells are still valid cells
+        int big = 0;
+        if (nc[1] > nc[big]) big = 1;
+        if (nc[2] > nc[big]) big = 2;
+        if (nc[big] <= 3) return G;
+        --nc[big];
+    }
+    G.nc[0] = nc[0]; G.nc[1] = nc[1]; G.nc[2] = nc[2];
+    G.ncell = nc[0] * nc[1] * nc[2];
+    return G;
 }
 
 int grow_ivcap(int need)
@@ -217,10 +264,30 @@ int launch_build(int first, int count)
     for (int b = 0; b < count; ++b) { init[2 * b] = 0x7fffffff; init[2 * b + 1] = 0; }
     HIPCHK(hipMemcpyAsync(g.d_stats + 2 * box0, init.data(), sizeof(int) * 2 * count, hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));   // `init` is pageable: make sure it was consumed
+    int ngrid = 0;
+    for (int b = box0; b < box0 + count; ++b) ngrid += g.h_usegrid[b] ? 1 : 0;
     dim3 grid((g.N + 255) / 256, count);
-    hipLaunchKernelGGL(mw::k_build_neighbours, grid, dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_nivect, g.d_list,
-                       g.d_listm, g.d_nn, g.d_stats, g.N, g.S, g.ivcap, box0);
-    HIPCHK(hipGetLastError());
+    if (ngrid > 0) {
+        HIPCHK(hipMemsetAsync(g.d_ccount + (size_t)box0 * g.cstride, 0, sizeof(int) * (size_t)count * g.cstride, g.stream));
+        hipLaunchKernelGGL(mw::k_cell_bin, grid, dim3(256), 0, g.stream, g.d_pos, g.d_grid, g.d_cellid, g.d_shift, g.d_ccount,
+                           g.N, g.cstride, box0);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(mw::k_cell_scan, dim3(count), dim3(1024), 0, g.stream, g.d_grid, g.d_ccount, g.d_cstart, g.d_ccursor,
+                           g.cstride, box0);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(mw::k_cell_scatter, grid, dim3(256), 0, g.stream, g.d_grid, g.d_cellid, g.d_ccursor, g.d_sorted,
+                           g.N, g.cstride, box0);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(mw::k_cell_search, grid, dim3(256), (size_t)g.S * 256 * sizeof(uint32_t), g.stream, g.d_pos, g.d_ivect,
+                           g.d_grid, g.d_cellid, g.d_shift, g.d_cstart, g.d_sorted, g.d_list, g.d_listm, g.d_nn, g.d_stats,
+                           g.N, g.S, g.ivcap, g.cstride, box0);
+        HIPCHK(hipGetLastError());
+    }
+    if (ngrid < count) {
+        hipLaunchKernelGGL(mw::k_build_neighbours, grid, dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_nivect, g.d_list,
+                           g.d_listm, g.d_nn, g.d_stats, g.d_usegrid, g.N, g.S, g.ivcap, box0);
+        HIPCHK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -298,6 +365,21 @@ int mw_init(int device, int nwater, int nboxes, int maxneigh)
     HIPCHK(hipMalloc(&g.d_listm, nb * N * (size_t)mw::kRow * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.d_nn, nb * N * sizeof(int)));
     HIPCHK(hipMalloc(&g.d_stats, nb * 2 * sizeof(int)));
+    g.cstride = nwater + 64;
+    HIPCHK(hipMalloc(&g.d_grid, nb * sizeof(mw::GridDesc)));
+    HIPCHK(hipMalloc(&g.d_usegrid, nb * sizeof(int)));
+    HIPCHK(hipMalloc(&g.d_cellid, nb * N * sizeof(int)));
+    HIPCHK(hipMalloc(&g.d_shift, nb * N * sizeof(int)));
+    HIPCHK(hipMalloc(&g.d_sorted, nb * N * sizeof(int)));
+    HIPCHK(hipMalloc(&g.d_ccount, nb * (size_t)g.cstride * sizeof(int)));
+    HIPCHK(hipMalloc(&g.d_cstart, nb * ((size_t)g.cstride + 1) * sizeof(int)));
+    HIPCHK(hipMalloc(&g.d_ccursor, nb * (size_t)g.cstride * sizeof(int)));
+    HIPCHK(hipMemset(g.d_grid, 0, nb * sizeof(mw::GridDesc)));
+    HIPCHK(hipMemset(g.d_usegrid, 0, nb * sizeof(int)));
+    g.h_grid.assign(nb, mw::GridDesc());
+    for (auto& G : g.h_grid) std::memset(&G, 0, sizeof G);
+    g.h_usegrid.assign(nb, 0);
+    { const char* fb = std::getenv("MW_FORCE_BRUTE_NEIGHBOURS"); g.force_brute = fb && *fb && *fb != '0'; }
     HIPCHK(hipMalloc(&g.d_partial, nb * g.nsplit_max * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_cpartial, nb * g.nsplit_max * 2 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&g.d_energy, nb * sizeof(double)));
@@ -317,6 +399,8 @@ int mw_init(int device, int nwater, int nboxes, int maxneigh)
     // the LDS-staged kernel asks for more than the default 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_model_energy<true, 1024>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_cell_search),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, MW_MAXNEIGH_LIMIT * 256 * (int)sizeof(uint32_t)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_move_energy<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
     g.live = true;
@@ -329,6 +413,8 @@ int mw_finalize(void)
     hipSetDevice(g.device);
     hipStreamSynchronize(g.stream);
     hipFree(g.d_pos); hipFree(g.d_ivect); hipFree(g.d_nivect); hipFree(g.d_list); hipFree(g.d_listm); hipFree(g.d_nn); hipFree(g.d_stats);
+    hipFree(g.d_grid); hipFree(g.d_usegrid); hipFree(g.d_cellid); hipFree(g.d_shift); hipFree(g.d_sorted);
+    hipFree(g.d_ccount); hipFree(g.d_cstart); hipFree(g.d_ccursor);
     hipFree(g.d_partial); hipFree(g.d_cpartial); hipFree(g.d_energy); hipFree(g.d_counts);
     if (g.d_mbox) { hipFree(g.d_mbox); hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); hipFree(g.d_mcnt); hipFree(g.d_mperm); }
     if (g.d_mwork) hipFree(g.d_mwork);
@@ -357,7 +443,8 @@ int mw_set_cell(int ils, const double h[9], int* nivect_out)
 {
     if (check_live() || check_box(ils)) return 1;
     std::vector<double> iv;
-    const int n = host_ivects(h, iv);
+    int imv[3] = {1, 1, 1};
+    const int n = host_ivects(h, iv, imv);
     if (n < 0) return fail("mw_set_cell: cell of box %d is so small that it needs more than %d image vectors", ils, MW_MAX_IVECT);
     if (n > g.ivcap && grow_ivcap(n)) return 1;
     const size_t off = (size_t)(ils - 1) * g.ivcap * 3;
@@ -365,6 +452,11 @@ int mw_set_cell(int ils, const double h[9], int* nivect_out)
     g.h_nivect[ils - 1] = n;
     HIPCHK(hipMemcpyAsync(g.d_ivect + off, &g.h_ivect[off], iv.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipMemcpyAsync(g.d_nivect + (ils - 1), &g.h_nivect[ils - 1], sizeof(int), hipMemcpyHostToDevice, g.stream));
+    g.h_grid[ils - 1] = make_grid(h, imv, g.cstride);
+    g.h_usegrid[ils - 1] = (!g.force_brute && g.h_grid[ils - 1].nc[0] > 0) ? 1 : 0;
+    if (!g.h_usegrid[ils - 1]) g.h_grid[ils - 1].nc[0] = 0;
+    HIPCHK(hipMemcpyAsync(g.d_grid + (ils - 1), &g.h_grid[ils - 1], sizeof(mw::GridDesc), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.d_usegrid + (ils - 1), &g.h_usegrid[ils - 1], sizeof(int), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     if (nivect_out) *nivect_out = n;
     return 0;
