@@ -62,26 +62,23 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
 // most of their instructions on the last ulp and on special cases that cannot occur here:
 // the arguments are finite, positive (r^2), nonzero (r - a sigma < 0) or <= 0 (exponent)).
 
-// 1/sqrt(x), x > 0 finite and normal: hardware estimate + two Newton steps.
+// The gfx950 v_rsq_f64 / v_rcp_f64 estimates are good to ~5e-8 relative (measured, tools/hwprec.hip);
+// one third-order correction brings both to double rounding (1.4e-16 / <1e-16 measured).
+
+// 1/sqrt(x), x > 0 finite and normal.
 __device__ __forceinline__ double fast_rsqrt(double x)
 {
-    double y = __builtin_amdgcn_rsq(x);
-    double e = __builtin_fma(-x * y, y, 1.0);          // 1 - x y^2
-    y = __builtin_fma(y, e * __builtin_fma(e, 0.375, 0.5), y);   // y (1 + e/2 + 3e^2/8)
-    e = __builtin_fma(-x * y, y, 1.0);
-    y = __builtin_fma(y * 0.5, e, y);
-    return y;
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-x * y, y, 1.0);                 // 1 - x y^2
+    return __builtin_fma(y, e * __builtin_fma(e, 0.375, 0.5), y);   // y (1 + e/2 + 3e^2/8)
 }
 
-// 1/x, x finite, normal, nonzero: hardware estimate + two Newton steps.
+// 1/x, x finite, normal, nonzero.
 __device__ __forceinline__ double fast_rcp(double x)
 {
-    double y = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-x, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    return y;
+    const double y = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, y, 1.0);                     // 1 - x y
+    return __builtin_fma(y, __builtin_fma(e, e, e), y);             // y (1 + e + e^2)
 }
 
 // exp(x) for x <= 0 (any magnitude; underflows smoothly to 0).  n = round(x log2 e),
@@ -757,25 +754,25 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv,
 
     // ---- compact the in-range neighbours into the wave's scratch ----------------------------
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(U >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)U, 0u));
-    int incl = inu ? nnj : 0;                                                  // inclusive scan of row lengths
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int up = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += up;
+    // first slot of every in-range j's row in the end-to-end numbering: a scalar walk over the set
+    // bits (row lengths via v_readlane, sums on the scalar unit), plus the list slots each evaluation visits
+    const unsigned long long mo_ = __ballot(ino), mn_ = __ballot(inn);
+    int start = 0, T = 0;
+    unsigned int so = (unsigned int)n_i, sn = (unsigned int)n_i;
+    for (unsigned long long m = U; m;) {
+        const int jl = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const int nj = __builtin_amdgcn_readlane(nnj, jl);
+        if (lane == jl) start = T;
+        T += nj;
+        if ((mo_ >> jl) & 1ull) so += (unsigned int)nj;
+        if ((mn_ >> jl) & 1ull) sn += (unsigned int)nj;
     }
-    const int T = __builtin_amdgcn_readlane(incl, 63);
     if (inu) {
         ws->q[0][rank] = qx; ws->q[1][rank] = qy; ws->q[2][rank] = qz;
         ws->rinvo[rank] = rinvo; ws->rinvn[rank] = rinvn; ws->go[rank] = go; ws->gn[rank] = gn;
         ws->j[rank] = j; ws->kimg[rank] = kimg; ws->flag[rank] = (ino ? 1 : 0) | (inn ? 2 : 0);
-        ws->start[rank] = incl - nnj;
-    }
-    unsigned int so = (unsigned int)n_i, sn = (unsigned int)n_i;              // list slots visited
-    {
-        int a = ino ? nnj : 0, b = inn ? nnj : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
-        so += (unsigned int)a; sn += (unsigned int)b;
+        ws->start[rank] = start;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -865,7 +862,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv,
         ntn += (unsigned int)__shfl_xor((int)ntn, off, 64);
     }
     res.eo = eo; res.en = en;
-    res.io = (unsigned int)__popcll(__ballot(ino)) + nto; res.in_ = (unsigned int)__popcll(__ballot(inn)) + ntn;
+    res.io = (unsigned int)__popcll(mo_) + nto; res.in_ = (unsigned int)__popcll(mn_) + ntn;
     res.so = so; res.sn = sn;
     return true;
 }

@@ -117,6 +117,7 @@ class EnergyModule:
         self.model_energy = np.zeros(self.num_lattices, dtype=np.float64)
         self.nivect = np.zeros(self.num_lattices, dtype=np.int32)
         self._last_imol = [0] * self.num_lattices    # molecule queried last per lattice (coherence protocol)
+        self._stale = [True] * self.num_lattices     # set by compute_ivects: bulk position change pending
         self._live = False
         self.warnings = []
 
@@ -162,6 +163,9 @@ class EnergyModule:
         n = ctypes.c_int(0)
         self._chk(self.L.mw_set_cell(ils, _d(h), ctypes.byref(n)))
         self.nivect[b] = n.value
+        # a cell change comes with a bulk position change -- also when a volume move is REJECTED: the host
+        # rescales every position back and calls nothing but compute_ivects (mc_moves.F90:1410-1514)
+        self._stale[b] = True
 
     def ivect(self, ils):
         self._ils(ils)
@@ -176,6 +180,7 @@ class EnergyModule:
         x = np.ascontiguousarray(self.ljr[ils - 1], dtype=np.float64)
         self._chk(self.L.mw_upload_positions(ils, _d(x)))
         self._last_imol[ils - 1] = 0
+        self._stale[ils - 1] = False
 
     def compute_neighbours(self, ils):
         self._ils(ils)
@@ -239,6 +244,8 @@ class EnergyModule:
         b = self._ils(ils)
         if not (1 <= imol <= self.nwater):
             raise MwError(f"molecule index {imol} outside 1..{self.nwater}")
+        if self._stale[b]:
+            self._upload(ils)
         r = np.ascontiguousarray(self.ljr[b, imol - 1], dtype=np.float64)
         prev = self._last_imol[b]
         e = ctypes.c_double(0.0)

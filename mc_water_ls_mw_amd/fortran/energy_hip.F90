@@ -19,7 +19,10 @@
 !   compute_local_real_energy(imol,ils) : sends the host position of imol AND   !
 !       of the molecule queried just before it in that lattice (whose trial     !
 !       move may have been silently reverted, mc_moves.F90:1186)                !
-!   compute_ivects : re-mirrors the cell.                                       !
+!   compute_ivects : re-mirrors the cell AND marks the lattice's positions stale: !
+!       a rejected volume move rescales every position back on the host and     !
+!       then calls nothing but compute_ivects (mc_moves.F90:1410-1514), so the   !
+!       next local-energy call re-mirrors all positions first.                   !
 !=============================================================================!
 module energy
 
@@ -73,6 +76,8 @@ module energy
 
   ! molecule queried last in each lattice (0 = none since the last full mirror)
   integer,allocatable,dimension(:),save :: last_imol
+  ! .true. after compute_ivects until the lattice's positions have been mirrored again
+  logical,allocatable,dimension(:),save :: stale
 
   interface
      integer(c_int) function mw_init(device,nwater,nboxes,maxn) bind(C,name="mw_init")
@@ -179,6 +184,9 @@ contains
     allocate(last_imol(1:num_lattices),stat=ierr)
     if (ierr/=0) stop 'Error allocating last_imol'
     last_imol = 0
+    allocate(stale(1:num_lattices),stat=ierr)
+    if (ierr/=0) stop 'Error allocating stale flags'
+    stale = .true.
 
     call mw_check(mw_init(-1_c_int,int(nwater,c_int),int(num_lattices,c_int),int(maxneigh,c_int)),'energy_init')
 
@@ -250,6 +258,7 @@ contains
     h9 = reshape(hmatrix(:,:,ils),(/9/))
     call mw_check(mw_set_cell(int(ils,c_int),h9,n),'compute_ivects')
     nivect(ils) = n
+    stale(ils) = .true.        ! cell changes come with bulk position changes (volume move and its rejection)
     if (allocated(ivect)) then
        if (n>size(ivect,2)) then
           ! the reference would overrun here when the cell shrinks (SURVEY.md G9); grow instead
@@ -275,6 +284,11 @@ contains
     real(c_double) :: e,r1(3),r2(3)
     integer(c_int) :: prev
 
+    if (stale(ils)) then
+       call mw_check(mw_upload_positions(int(ils,c_int),ljr(:,1,:,ils)),'compute_local_real_energy')
+       stale(ils) = .false.
+       last_imol(ils) = 0
+    end if
     r1 = ljr(:,1,imol,ils)
     prev = last_imol(ils)
     if (prev>=1 .and. prev/=imol) then
@@ -299,6 +313,7 @@ contains
     real(c_double) :: e
     call mw_check(mw_upload_positions(int(ils,c_int),ljr(:,1,:,ils)),'compute_model_energy')
     last_imol(ils) = 0
+    stale(ils) = .false.
     call mw_check(mw_model_energy(int(ils,c_int),e),'compute_model_energy')
     model_energy(ils) = e
     return
@@ -319,6 +334,7 @@ contains
     call compute_ivects(ils)                                           ! molint.F90:518
     call mw_check(mw_upload_positions(int(ils,c_int),ljr(:,1,:,ils)),'compute_neighbours')
     last_imol(ils) = 0
+    stale(ils) = .false.
     call mw_check(mw_build_neighbours(int(ils,c_int),mn,mx),'compute_neighbours')
     if (mn<16) then                                                    ! molint.F90:552-554
        call energy_fetch_neighbours(ils)

@@ -102,7 +102,11 @@ program dropin_driver
      write(*,'(A,I2,ES26.17E3)') 'vol+  ', ils, model_energy(ils)
      hmatrix(:,:,ils) = hmatrix(:,:,ils)/scale            ! rejected: restore, :1410-1530
      ljr(:,1,:,ils) = keep(:,:)
-     call compute_ivects(ils)
+     call compute_ivects(ils)                             ! ... and NOTHING else (mc_moves.F90:1510-1514):
+     do i = 1, 5                                          ! the next translation moves see the restored box
+        call mw_scrub_stack()
+        write(*,'(A,I2,ES26.17E3)') 'lrej  ', ils, compute_local_real_energy(1 + mod(7*i, n), ils)
+     end do
      call compute_model_energy(ils)
      write(*,'(A,I2,ES26.17E3)') 'vol0  ', ils, model_energy(ils)
      call compute_neighbours(ils)
