@@ -118,6 +118,10 @@ def main():
     ap.add_argument("--sigma", type=float, default=0.15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank computes on device 0 (use with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -130,10 +134,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from mc_water_ls_mw_amd import lattice as lat
     from mc_water_ls_mw_amd.comms import WalkerComms
@@ -165,7 +174,8 @@ def main():
     em.moves_upload(ils, imol, trial)
     t_setup = time.perf_counter() - t_setup
 
-    comms = WalkerComms(NBINS, samplerun=True, device=torch.device("cuda", local_rank))
+    comms = WalkerComms(NBINS, samplerun=True,
+                        device=torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu"))
     weight, hist, uhist = np.zeros(NBINS), np.zeros(NBINS), np.zeros(NBINS)
 
     def step(k, timed):
@@ -198,9 +208,20 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every walker of every rank must have ended with the same shared weights / histograms
+        chk = torch.tensor(np.concatenate([weight, hist, uhist]), dtype=torch.float64,
+                           device="cuda" if args.backend == "nccl" else "cpu")
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit("ranks disagree on the synchronised weights/histograms")
+        expect = float(args.warmup + args.steps) * world
+        if abs(float(hist.sum()) - expect) > 1e-9:
+            raise SystemExit(f"histogram total {hist.sum()} != {expect}: the delta all-reduce lost or duplicated increments")
 
     # ---- accounting (outside the timed region) ----------------------------------------
     npairs, ntrip = em.model_energy_counts_total(1, W)
@@ -249,7 +270,7 @@ def main():
                             "per step: full-box energy of every walker + old/new local energy of every trial move",
                 "walkers_per_gpu": W, "moves_per_walker": M, "molecules": N_MOL,
                 "parallelism": f"replica farm: {world} x {W} independent walkers, one process per GPU",
-                "exchange": "one RCCL all-reduce of 3 x 101 f64 per step" if world > 1 else "none at N=1",
+                "exchange": (f"one {args.backend} all-reduce of 3 x 101 f64 per step" if world > 1 else "none at N=1"),
             },
             "per_gpu": (i_full + i_moves) * args.steps / elapsed,
             "roofline": {
