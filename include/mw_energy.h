@@ -134,6 +134,31 @@ int mw_model_energy_fetch(int first_ils, int count, double *e_out);
 int mw_build_neighbours_launch(int first_ils, int count);
 int mw_sync(void);
 
+/* ---- device-resident translation-move driver (mc_water_translation, mc_moves.F90:966-1213) ------
+ * A walker is `nlat` (1 or 2) consecutive boxes: walker w owns boxes (w-1)*nlat+1 .. w*nlat.  Each
+ * walker runs its own Markov chain on the device, one wavefront per walker: pick a molecule, trial
+ * displacement in the active lattice mapped through fractional coordinates into the partner lattice
+ * (mc_moves.F90:1042-1066), old/new local energy in every lattice, update of the order parameter mu,
+ * multicanonical weights through eta_weight (mc_moves.F90:893-964, bins from mu_to_bin :2187-2215),
+ * Metropolis acceptance, revert on rejection.  The per-box energies (the values mw_model_energy* left,
+ * or mw_set_model_energy) are edited the way the reference's caller edits model_energy.  Lists are
+ * NOT rebuilt inside: call mw_build_neighbours_batch at the host's list_update_int, as mc_cycle does.
+ * Random numbers are Philox4x32-10 with counter (move index, walker, call) and key `seed`: move
+ * `move0 + m` of walker w draws the same six numbers whatever the launch geometry. */
+int mw_sweep_configure(int nlat, double beta, double max_trans_bohr, int nbins, int eta_interp,
+                       int start_bin, int end_bin, double r_pos, double a_pos, double r_neg, double a_neg,
+                       double mu_lo, double mu_hi,
+                       const double *weight, const double *mu_bin, const double *binwidth);
+int mw_set_model_energy(int ils, double e);
+int mw_sweep_set_state(int walker, int ls, double ls_mu);
+int mw_sweep_get_state(int walker, int *ls, double *ls_mu, double *model_energy, long long *accepted);
+/* nmoves moves for walkers first_walker .. first_walker+count-1.  log (may be NULL) receives
+ * 8 doubles per walker and move: imol, accepted, old1, new1, old2, new2, ls_mu after, diffkT. */
+int mw_sweep_translation(int first_walker, int count, int nmoves, unsigned long long seed,
+                         unsigned long long move0, double *log);
+int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigned long long seed,
+                                unsigned long long move0, int want_log);
+
 /* HIP-event timers on the engine's stream: slot in 0..4095. */
 int mw_timer_start(int slot);
 int mw_timer_stop(int slot);

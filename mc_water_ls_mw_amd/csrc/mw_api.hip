@@ -67,6 +67,17 @@ struct Ctx {
     unsigned long long* d_cpartial = nullptr;
     double* d_energy = nullptr;
     unsigned long long* d_counts = nullptr;
+    // device-resident translation driver (walker = nlat consecutive boxes)
+    double* d_hmat = nullptr;                    // [box][9] hmatrix(:,:,ils), column-major
+    bool sweep_ready = false;
+    mw::SweepParams sp;
+    int nwalkers = 0;
+    double *d_sw_weight = nullptr, *d_sw_mubin = nullptr, *d_sw_binwidth = nullptr;
+    int* d_wls = nullptr;
+    double* d_wmu = nullptr;
+    unsigned long long* d_wacc = nullptr;
+    double* d_swlog = nullptr;
+    size_t swlog_cap = 0;
     // staged moves
     int mcap = 0, mn = 0;
     int *d_mbox = nullptr, *d_mimol = nullptr;
@@ -361,6 +372,8 @@ int mw_init(int device, int nwater, int nboxes, int maxneigh)
     HIPCHK(hipMalloc(&g.d_pos, nb * N * 3 * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_ivect, nb * g.ivcap * 3 * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_nivect, nb * sizeof(int)));
+    HIPCHK(hipMalloc(&g.d_hmat, nb * 9 * sizeof(double)));
+    HIPCHK(hipMemset(g.d_hmat, 0, nb * 9 * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_list, nb * N * (size_t)maxneigh * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.d_listm, nb * N * (size_t)mw::kRow * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.d_nn, nb * N * sizeof(int)));
@@ -412,6 +425,10 @@ int mw_finalize(void)
     if (!g.live) return 0;
     hipSetDevice(g.device);
     hipStreamSynchronize(g.stream);
+    hipFree(g.d_hmat);
+    if (g.d_sw_weight) { hipFree(g.d_sw_weight); hipFree(g.d_sw_mubin); hipFree(g.d_sw_binwidth); }
+    if (g.d_wls) { hipFree(g.d_wls); hipFree(g.d_wmu); hipFree(g.d_wacc); }
+    if (g.d_swlog) hipFree(g.d_swlog);
     hipFree(g.d_pos); hipFree(g.d_ivect); hipFree(g.d_nivect); hipFree(g.d_list); hipFree(g.d_listm); hipFree(g.d_nn); hipFree(g.d_stats);
     hipFree(g.d_grid); hipFree(g.d_usegrid); hipFree(g.d_cellid); hipFree(g.d_shift); hipFree(g.d_sorted);
     hipFree(g.d_ccount); hipFree(g.d_cstart); hipFree(g.d_ccursor);
@@ -452,6 +469,7 @@ int mw_set_cell(int ils, const double h[9], int* nivect_out)
     g.h_nivect[ils - 1] = n;
     HIPCHK(hipMemcpyAsync(g.d_ivect + off, &g.h_ivect[off], iv.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipMemcpyAsync(g.d_nivect + (ils - 1), &g.h_nivect[ils - 1], sizeof(int), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.d_hmat + 9 * (size_t)(ils - 1), h, 9 * sizeof(double), hipMemcpyHostToDevice, g.stream));
     g.h_grid[ils - 1] = make_grid(h, imv, g.cstride);
     g.h_usegrid[ils - 1] = (!g.force_brute && g.h_grid[ils - 1].nc[0] > 0) ? 1 : 0;
     if (!g.h_usegrid[ils - 1]) g.h_grid[ils - 1].nc[0] = 0;
@@ -730,6 +748,120 @@ int mw_delta_energy_batch(int n, const int* ils, const int* imol, const double* 
     if (mw_moves_upload(n, ils, imol, trial_xyz)) return 1;
     if (launch_moves(3)) return 1;
     return mw_moves_fetch(e_old, e_new);
+}
+
+int mw_set_model_energy(int ils, double e)
+{
+    if (check_live() || check_box(ils)) return 1;
+    HIPCHK(hipMemcpyAsync(g.d_energy + (ils - 1), &e, sizeof(double), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int mw_sweep_configure(int nlat, double beta, double max_trans, int nbins, int eta_interp, int start_bin, int end_bin,
+                       double r_pos, double a_pos, double r_neg, double a_neg, double mu_lo, double mu_hi,
+                       const double* weight, const double* mu_bin, const double* binwidth)
+{
+    if (check_live()) return 1;
+    if (nlat != 1 && nlat != 2) return fail("mw_sweep_configure: num_lattices = %d (1 or 2)", nlat);
+    if (g.nbox % nlat) return fail("mw_sweep_configure: %d boxes do not split into walkers of %d lattices", g.nbox, nlat);
+    if (nlat == 2) {
+        if (nbins < 3 || !weight || !mu_bin || !binwidth) return fail("mw_sweep_configure: two lattices need the weight tables");
+        if (start_bin < 1 || end_bin > nbins || start_bin >= end_bin) return fail("mw_sweep_configure: bins %d..%d outside 1..%d", start_bin, end_bin, nbins);
+    }
+    HIPCHK(hipStreamSynchronize(g.stream));
+    g.sp.beta = beta; g.sp.max_trans = max_trans;
+    g.sp.r_pos = r_pos; g.sp.a_pos = a_pos; g.sp.r_neg = r_neg; g.sp.a_neg = a_neg; g.sp.mu_lo = mu_lo; g.sp.mu_hi = mu_hi;
+    g.sp.nlat = nlat; g.sp.nbins = nbins; g.sp.eta_interp = eta_interp; g.sp.start_bin = start_bin; g.sp.end_bin = end_bin; g.sp.pad = 0;
+    if (g.d_sw_weight) { HIPCHK(hipFree(g.d_sw_weight)); HIPCHK(hipFree(g.d_sw_mubin)); HIPCHK(hipFree(g.d_sw_binwidth)); g.d_sw_weight = nullptr; }
+    const size_t nb = (size_t)(nbins > 0 ? nbins : 1);
+    HIPCHK(hipMalloc(&g.d_sw_weight, nb * sizeof(double)));
+    HIPCHK(hipMalloc(&g.d_sw_mubin, nb * sizeof(double)));
+    HIPCHK(hipMalloc(&g.d_sw_binwidth, nb * sizeof(double)));
+    if (nlat == 2) {
+        HIPCHK(hipMemcpy(g.d_sw_weight, weight, nb * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(g.d_sw_mubin, mu_bin, nb * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(g.d_sw_binwidth, binwidth, nb * sizeof(double), hipMemcpyHostToDevice));
+    }
+    g.nwalkers = g.nbox / nlat;
+    if (!g.d_wls) {
+        HIPCHK(hipMalloc(&g.d_wls, sizeof(int) * g.nbox));
+        HIPCHK(hipMalloc(&g.d_wmu, sizeof(double) * g.nbox));
+        HIPCHK(hipMalloc(&g.d_wacc, sizeof(unsigned long long) * g.nbox));
+    }
+    std::vector<int> one((size_t)g.nbox, 1);
+    HIPCHK(hipMemcpy(g.d_wls, one.data(), sizeof(int) * g.nbox, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(g.d_wmu, 0, sizeof(double) * g.nbox));
+    HIPCHK(hipMemset(g.d_wacc, 0, sizeof(unsigned long long) * g.nbox));
+    g.sweep_ready = true;
+    return 0;
+}
+
+static int check_walker(int first, int count)
+{
+    if (!g.sweep_ready) return fail("mw_sweep: call mw_sweep_configure first");
+    if (first < 1 || count < 1 || first + count - 1 > g.nwalkers)
+        return fail("mw_sweep: walker range %d..%d outside 1..%d", first, first + count - 1, g.nwalkers);
+    return 0;
+}
+
+int mw_sweep_set_state(int walker, int ls, double ls_mu)
+{
+    if (check_live() || check_walker(walker, 1)) return 1;
+    if (ls < 1 || ls > g.sp.nlat) return fail("mw_sweep_set_state: active lattice %d outside 1..%d", ls, g.sp.nlat);
+    HIPCHK(hipMemcpyAsync(g.d_wls + (walker - 1), &ls, sizeof(int), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.d_wmu + (walker - 1), &ls_mu, sizeof(double), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int mw_sweep_get_state(int walker, int* ls, double* ls_mu, double* model_energy, long long* accepted)
+{
+    if (check_live() || check_walker(walker, 1)) return 1;
+    int l = 0; double mu = 0.0; unsigned long long a = 0; double e[2] = {0.0, 0.0};
+    HIPCHK(hipMemcpyAsync(&l, g.d_wls + (walker - 1), sizeof(int), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(&mu, g.d_wmu + (walker - 1), sizeof(double), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(&a, g.d_wacc + (walker - 1), sizeof a, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(e, g.d_energy + (size_t)(walker - 1) * g.sp.nlat, sizeof(double) * g.sp.nlat, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    if (ls) *ls = l;
+    if (ls_mu) *ls_mu = mu;
+    if (accepted) *accepted = (long long)a;
+    if (model_energy) { model_energy[0] = e[0]; if (g.sp.nlat == 2) model_energy[1] = e[1]; }
+    return 0;
+}
+
+int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigned long long seed, unsigned long long move0, int want_log)
+{
+    if (check_live() || check_walker(first_walker, count)) return 1;
+    if (nmoves < 0) return fail("mw_sweep_translation: nmoves = %d", nmoves);
+    if (nmoves == 0) return 0;
+    double* dlog = nullptr;
+    if (want_log) {
+        const size_t need = (size_t)count * nmoves * 8;
+        if (need > g.swlog_cap) {
+            HIPCHK(hipStreamSynchronize(g.stream));
+            if (g.d_swlog) HIPCHK(hipFree(g.d_swlog));
+            HIPCHK(hipMalloc(&g.d_swlog, need * sizeof(double)));
+            g.swlog_cap = need;
+        }
+        dlog = g.d_swlog;
+    }
+    const size_t shmem = (size_t)g.sp.nlat * g.ivcap * 3 * sizeof(double);
+    hipLaunchKernelGGL(mw::k_sweep_translation, dim3(count), dim3(64), shmem, g.stream, g.d_pos, g.d_hmat, g.d_ivect, g.d_nivect,
+                       g.d_listm, g.d_nn, g.d_energy, g.d_wls, g.d_wmu, g.d_wacc, g.sp, g.d_sw_weight, g.d_sw_mubin,
+                       g.d_sw_binwidth, g.N, g.ivcap, nmoves, seed, move0, first_walker - 1, dlog);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int mw_sweep_translation(int first_walker, int count, int nmoves, unsigned long long seed, unsigned long long move0, double* log)
+{
+    if (mw_sweep_translation_launch(first_walker, count, nmoves, seed, move0, log != nullptr)) return 1;
+    if (log && nmoves > 0)
+        HIPCHK(hipMemcpyAsync(log, g.d_swlog, sizeof(double) * (size_t)count * nmoves * 8, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
 }
 
 int mw_sync(void)

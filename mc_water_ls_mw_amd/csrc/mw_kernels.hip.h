@@ -936,6 +936,231 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
     }
 }
 
+// =====================================================================================
+// Device-resident translation-move driver: mc_water_translation
+// (mc_moves.F90:966-1213) with eta_weight (:893-964) and mu_to_bin (:2187-2215), for many
+// independent walkers at once.  One wavefront per walker runs its Markov chain move after
+// move: pick a molecule, draw the displacement in the active lattice, map it through
+// fractional coordinates into the partner lattice (:1042-1066), fused old/new local energy in
+// each lattice (move_energy_wave), update the order parameter mu and the multicanonical
+// weights' contribution, accept or revert (:1145-1209).  The caller-side bookkeeping of
+// model_energy (:1013-1016,1087,1190) is done here on the per-box energies.
+// Random numbers: Philox4x32-10, counter (move lo, move hi, walker, call), key = seed -- the same
+// stream as the oracle's mwo_move_uniforms.
+//   grid = walkers in the launch, block = 64
+// =====================================================================================
+struct SweepParams {
+    double beta, max_trans;
+    double r_pos, a_pos, r_neg, a_neg, mu_lo, mu_hi;
+    int nlat, nbins, eta_interp, start_bin, end_bin, pad;
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ double u53(uint32_t a, uint32_t b)
+{
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+__device__ __forceinline__ int dev_mu_to_bin(const SweepParams& g, double mu)          // mc_moves.F90:2187-2215
+{
+    if (fabs(mu) <= 0.5) return g.nbins / 2 + 1;
+    if (mu > 0.0) {
+        const double arg = 1.0 - (mu - 0.5) * (1.0 - g.r_pos) / g.a_pos;
+        return g.nbins / 2 + 2 + (int)(log(arg) / log(g.r_pos));
+    }
+    const double arg = 1.0 - (fabs(mu) - 0.5) * (1.0 - g.r_neg) / g.a_neg;
+    return g.nbins / 2 - (int)(log(arg) / log(g.r_neg));
+}
+
+__device__ __forceinline__ double dev_eta_weight(const SweepParams& g, const double* __restrict__ weight,
+                                                 const double* __restrict__ mu_bin, const double* __restrict__ binwidth,
+                                                 double mu)                                // mc_moves.F90:893-964
+{
+    if (mu < g.mu_lo || mu > g.mu_hi) return 1.7976931348623157e308;                       // huge(1.0_dp)
+    const int k = dev_mu_to_bin(g, mu);
+    const double* w = weight - 1; const double* mb = mu_bin - 1; const double* bw = binwidth - 1;   // 1-based views
+    if (!g.eta_interp) return w[k];
+    if (k == g.start_bin) return w[k] + (mu - mb[k]) * (2.0 * (w[k + 1] - w[k]) / (bw[k] + bw[k + 1]));
+    if (k == g.end_bin)   return w[k] + (mu - mb[k]) * (2.0 * (w[k] - w[k - 1]) / (bw[k] + bw[k - 1]));
+    if (mu > mb[k])       return w[k] + (mu - mb[k]) * (2.0 * (w[k + 1] - w[k]) / (bw[k] + bw[k + 1]));
+    return w[k - 1] + (mu - mb[k - 1]) * (2.0 * (w[k] - w[k - 1]) / (bw[k] + bw[k - 1]));
+}
+
+#define MW_HM(m, r, c) ((m)[((c) - 1) * 3 + ((r) - 1)])     // Fortran (r,c) of a column-major 3x3
+__device__ __forceinline__ void dev_recipmatrix(const double* __restrict__ h, double rc[9])   // util.f90:43-77
+{
+    MW_HM(rc,1,1) = MW_HM(h,2,2)*MW_HM(h,3,3) - MW_HM(h,2,3)*MW_HM(h,3,2);
+    MW_HM(rc,1,2) = MW_HM(h,2,3)*MW_HM(h,3,1) - MW_HM(h,2,1)*MW_HM(h,3,3);
+    MW_HM(rc,1,3) = MW_HM(h,2,1)*MW_HM(h,3,2) - MW_HM(h,2,2)*MW_HM(h,3,1);
+    MW_HM(rc,2,1) = MW_HM(h,1,3)*MW_HM(h,3,2) - MW_HM(h,1,2)*MW_HM(h,3,3);
+    MW_HM(rc,2,2) = MW_HM(h,1,1)*MW_HM(h,3,3) - MW_HM(h,1,3)*MW_HM(h,3,1);
+    MW_HM(rc,2,3) = MW_HM(h,1,2)*MW_HM(h,3,1) - MW_HM(h,1,1)*MW_HM(h,3,2);
+    MW_HM(rc,3,1) = MW_HM(h,1,2)*MW_HM(h,2,3) - MW_HM(h,1,3)*MW_HM(h,2,2);
+    MW_HM(rc,3,2) = MW_HM(h,1,3)*MW_HM(h,2,1) - MW_HM(h,1,1)*MW_HM(h,2,3);
+    MW_HM(rc,3,3) = MW_HM(h,1,1)*MW_HM(h,2,2) - MW_HM(h,1,2)*MW_HM(h,2,1);
+    const double vol = MW_HM(h,1,1)*MW_HM(rc,1,1) + MW_HM(h,1,2)*MW_HM(rc,1,2) + MW_HM(h,1,3)*MW_HM(rc,1,3);
+    const double f = 2.0 * 3.141592653589793238462643383279502884197 / vol;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rc[i] *= f;
+}
+
+__global__ __launch_bounds__(64)
+void k_sweep_translation(double* pos, const double* __restrict__ hmat, const double* __restrict__ ivect,
+                         const int* __restrict__ nivect, const uint32_t* __restrict__ listm,
+                         const int* __restrict__ nn, double* __restrict__ energy,
+                         int* __restrict__ wls, double* __restrict__ wmu, unsigned long long* __restrict__ wacc,
+                         SweepParams sp, const double* __restrict__ weight, const double* __restrict__ mu_bin,
+                         const double* __restrict__ binwidth,
+                         int N, int ivcap, int nmoves, unsigned long long seed, unsigned long long move0,
+                         int walker0, double* __restrict__ log)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ WaveScratch ws;
+    const int lane = threadIdx.x;
+    const int wlk = walker0 + blockIdx.x;
+    const int L = sp.nlat;
+    const int box0 = wlk * L;
+    const double invPi = 1.0 / 3.141592653589793238462643383279502884197;
+
+    // image vectors of the walker's lattices in LDS: siv[l][ivcap][3]
+    double* siv = smem;
+    for (int l = 0; l < L; ++l) {
+        const int niv = nivect[box0 + l];
+        for (int t = lane; t < niv * 3; t += 64) siv[(size_t)l * ivcap * 3 + t] = ivect[(size_t)(box0 + l) * ivcap * 3 + t];
+    }
+    __shared__ double srecip[2][9];          // recip_matrix(:,:,ils) of the walker's lattices
+    if (lane == 0) {
+        for (int l = 0; l < L; ++l) {
+            double rcp[9];
+            dev_recipmatrix(hmat + (size_t)(box0 + l) * 9, rcp);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) srecip[l][t] = rcp[t];
+        }
+    }
+    __syncthreads();
+
+    int ls = wls[wlk];                       // active lattice, 1-based
+    double ls_mu = wmu[wlk];
+    double men[2] = {energy[box0], L == 2 ? energy[box0 + 1] : 0.0};
+    unsigned long long acc = 0;
+
+    for (int mv = 0; mv < nmoves; ++mv) {
+        // six uniforms: lanes 0..2 run one Philox call each, the values are broadcast
+        double ua = 0.0, ub = 0.0;
+        if (lane < 3) {
+            const unsigned long long m = move0 + (unsigned long long)mv;
+            uint32_t c[4] = {(uint32_t)m, (uint32_t)(m >> 32), (uint32_t)wlk, (uint32_t)lane};
+            philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+            ua = u53(c[0], c[1]); ub = u53(c[2], c[3]);
+        }
+        const double u0 = readlane_f64(ua, 0), u1 = readlane_f64(ub, 0), u2 = readlane_f64(ua, 1);
+        const double u3 = readlane_f64(ub, 1), u4 = readlane_f64(ua, 2), u5 = readlane_f64(ub, 2);
+
+        const int lsn = L == 2 ? 3 - ls : 1;
+        int imol = (int)(u0 * (double)N) + 1;                                    // mc_moves.F90:1001-1002
+        imol = imol > N ? N : imol;
+        const int i = imol - 1;
+        double x = 2.0 * u1 - 1.0, y = 2.0 * u2 - 1.0, z = 2.0 * u3 - 1.0;        // :1021-1027
+        const double norm = 1.0 / sqrt(x * x + y * y + z * z);                    // :1029
+        x *= norm; y *= norm; z *= norm;
+        const double r = u4 * 2.0 - 1.0;                                          // :1035
+        x = x * sp.max_trans * r; y = y * sp.max_trans * r; z = z * sp.max_trans * r;
+        const double* rc = srecip[ls - 1];
+        double sx = MW_HM(rc,1,1) * x + MW_HM(rc,2,1) * y + MW_HM(rc,3,1) * z;    // :1042-1050
+        double sy = MW_HM(rc,1,2) * x + MW_HM(rc,2,2) * y + MW_HM(rc,3,2) * z;
+        double sz = MW_HM(rc,1,3) * x + MW_HM(rc,2,3) * y + MW_HM(rc,3,3) * z;
+        sx = sx * 0.5 * invPi; sy = sy * 0.5 * invPi; sz = sz * 0.5 * invPi;      // :1052-1054
+        double tv[2][3] = {{x, y, z}, {x, y, z}};                                  // move in the active lattice
+        if (L == 2) {                                                             // :1061-1067
+            const double* hn = hmat + (size_t)(box0 + lsn - 1) * 9;
+            const double mx = MW_HM(hn,1,1) * sx + MW_HM(hn,1,2) * sy + MW_HM(hn,1,3) * sz;
+            const double my = MW_HM(hn,2,1) * sx + MW_HM(hn,2,2) * sy + MW_HM(hn,2,3) * sz;
+            const double mz = MW_HM(hn,3,1) * sx + MW_HM(hn,3,2) * sy + MW_HM(hn,3,3) * sz;
+            if (lsn == 1) { tv[0][0] = mx; tv[0][1] = my; tv[0][2] = mz; }         // static indices only
+            else          { tv[1][0] = mx; tv[1][1] = my; tv[1][2] = mz; }
+        }
+
+        double eo[2] = {0.0, 0.0}, en[2] = {0.0, 0.0}, pn[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int l = 0; l < 2; ++l) if (l < L) {                                  // :1007-1018, 1076-1092
+            const double* P = pos + (size_t)(box0 + l) * N * 3;
+            const uint32_t* LM = listm + (size_t)(box0 + l) * N * kRow;
+            const int* NN = nn + (size_t)(box0 + l) * N;
+            const double* IVl = siv + (size_t)l * ivcap * 3;
+            auto getiv = [&](int k, double& a, double& b, double& c) { a = IVl[3 * k]; b = IVl[3 * k + 1]; c = IVl[3 * k + 2]; };
+            auto getpos = [&](int j, double& a, double& b, double& c) { const double* p = P + 3 * (size_t)j; a = p[0]; b = p[1]; c = p[2]; };
+            double xo, yo, zo;
+            getpos(i, xo, yo, zo);
+            pn[l][0] = xo + tv[l][0]; pn[l][1] = yo + tv[l][1]; pn[l][2] = zo + tv[l][2];   // :1079
+            const int n_i = NN[i];
+            const uint32_t e = lane < n_i ? LM[(size_t)i * kRow + lane] : 0xffffffffu;
+            const bool ownimage = __ballot((int)(e & kJMask) == i && lane < n_i) != 0ull;
+            MoveRes res;
+            const bool fast = !ownimage && move_energy_wave(getpos, getiv, LM, NN, &ws, i, xo, yo, zo,
+                                                            pn[l][0], pn[l][1], pn[l][2], lane, res);
+            if (!fast) {
+                Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
+                Override tr; tr.idx = i; tr.x = pn[l][0]; tr.y = pn[l][1]; tr.z = pn[l][2];
+                res.eo = local_energy_wave(P, ivect + (size_t)(box0 + l) * ivcap * 3, LM, NN, i, none, none, lane, res.io, res.so);
+                res.en = local_energy_wave(P, ivect + (size_t)(box0 + l) * ivcap * 3, LM, NN, i, tr, none, lane, res.in_, res.sn);
+            }
+            eo[l] = res.eo; en[l] = res.en;
+        }
+        const double dE0 = en[0] - eo[0], dE1 = en[1] - eo[1];                    // :1090
+        const double bk0 = men[0], bk1 = men[1];                                  // :1013
+        men[0] = (men[0] - eo[0]) + en[0];                                        // :1016,1087
+        men[1] = (men[1] - eo[1]) + en[1];
+        double diffkT;
+        if (L == 1) {
+            diffkT = sp.beta * dE0;                                               // :1106
+        } else {
+            const double eta_old = dev_eta_weight(sp, weight, mu_bin, binwidth, ls_mu);   // :1112-1116
+            ls_mu = ls_mu + (dE0 - dE1) * sp.beta;
+            const double eta_new = dev_eta_weight(sp, weight, mu_bin, binwidth, ls_mu);
+            diffkT = (ls == 1 ? dE0 : dE1) * sp.beta + eta_new - eta_old;
+        }
+        double pacc = exp(-diffkT);
+        pacc = pacc > 1.0 ? 1.0 : pacc;
+        const bool ok = u5 < pacc;                                                // :1145-1146 (false for NaN)
+        if (ok) {
+            ++acc;
+            if (lane == 0) {
+#pragma unroll
+                for (int l = 0; l < 2; ++l) if (l < L) {
+                    double* P = pos + ((size_t)(box0 + l) * N + i) * 3;
+                    P[0] = pn[l][0]; P[1] = pn[l][1]; P[2] = pn[l][2];
+                }
+            }
+        } else {                                                                  // :1182-1195
+            men[0] = bk0; men[1] = bk1;
+            if (L == 2) ls_mu = ls_mu - (dE0 - dE1) * sp.beta;
+        }
+        if (log && lane == 0) {
+            double* q = log + ((size_t)blockIdx.x * nmoves + mv) * 8;
+            q[0] = (double)imol; q[1] = ok ? 1.0 : 0.0; q[2] = eo[0]; q[3] = en[0]; q[4] = eo[1]; q[5] = en[1]; q[6] = ls_mu; q[7] = diffkT;
+        }
+        // the next move of this wavefront must see the committed position
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    if (lane == 0) {
+        wls[wlk] = ls; wmu[wlk] = ls_mu; wacc[wlk] += acc;
+        energy[box0] = men[0];
+        if (L == 2) energy[box0 + 1] = men[1];
+    }
+}
+
 // Single request with by-value overrides (the drop-in compute_local_real_energy call):
 // one wave, result written straight to host-visible memory.
 __global__ __launch_bounds__(64)

@@ -1,0 +1,133 @@
+"""Device-resident translation-move driver: many independent walkers advance their Markov
+chains on the GPU (mc_water_translation, mc_moves.F90:966-1213).
+
+:class:`MuGrid` restates the overlap-parameter grid of mc_init (mc_moves.F90:571-656);
+:class:`WalkerFarm` wraps the ``mw_sweep_*`` C-ABI entries over an initialised
+:class:`~mc_water_ls_mw_amd.energy.EnergyModule` whose boxes are grouped ``nlat`` per walker.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import numpy as np
+
+KB = 1.0 / 3.1577465e5          # constants.f90:39, Hartree / Kelvin
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _ipow(r, n):
+    acc, b = 1.0, r
+    while n > 0:
+        if n & 1:
+            acc *= b
+        b *= b
+        n >>= 1
+    return acc
+
+
+class MuGrid:
+    """Geometric bin widths either side of a unit middle bin (mc_moves.F90:571-656)."""
+
+    def __init__(self, nbins=101, mu_min=-400.0, mu_max=400.0):
+        if nbins % 2 == 0:
+            nbins += 1                                     # mc_moves.F90:555
+        self.nbins, self.mu_min, self.mu_max = nbins, float(mu_min), float(mu_max)
+        ns = nbins // 2
+        self.a_pos = self.a_neg = 1.0
+        self.r_pos = self._ratio(self.a_pos, abs(mu_max) - 0.5, ns)
+        self.r_neg = self._ratio(self.a_neg, abs(mu_min) - 0.5, ns)
+        self.mu_bin = np.zeros(nbins)
+        self.binwidth = np.zeros(nbins)
+        mu_u, k = -0.5, 0
+        for ibin in range(ns, 0, -1):                      # :625-633
+            mu_l = mu_u - self.a_neg * _ipow(self.r_neg, k)
+            self.mu_bin[ibin - 1] = 0.5 * (mu_u + mu_l)
+            self.binwidth[ibin - 1] = mu_u - mu_l
+            mu_u, k = mu_l, k + 1
+        self.mu_bin[ns] = 0.0                              # :636-637
+        self.binwidth[ns] = 1.0
+        mu_l, k = 0.5, 0
+        for ibin in range(ns + 2, nbins + 1):              # :641-649
+            mu_u = mu_l + self.a_pos * _ipow(self.r_pos, k)
+            self.mu_bin[ibin - 1] = 0.5 * (mu_u + mu_l)
+            self.binwidth[ibin - 1] = mu_u - mu_l
+            mu_l, k = mu_u, k + 1
+        self.av_binwidth = self.binwidth.sum() / nbins      # :652-656
+        # 'mw' strategy: every walker spans the whole range (mc_moves.F90:711-718)
+        self.start_bin, self.end_bin = 1, nbins
+        self.my_mu_min, self.my_mu_max = self.mu_min, self.mu_max
+
+    @staticmethod
+    def _ratio(a, s, ns):                                  # :583-596
+        r = 1.1
+        for _ in range(1000001):
+            tmpsum = a * (1.0 - _ipow(r, ns)) / (1.0 - r)
+            r_new = r * (s / tmpsum) ** (1.0 / ns)
+            if abs(r_new - r) <= 2.0 * np.finfo(float).eps:
+                break
+            r = r_new
+        return r
+
+
+class WalkerFarm:
+    def __init__(self, em, nlat, temperature, max_trans_ang=1.1, grid=None, weight=None, eta_interp=True,
+                 pressure_au=0.0):
+        from .lattice import ANG_TO_BOHR
+        self.em, self.L, self.nlat = em, em.L, int(nlat)
+        if em.num_lattices % nlat:
+            raise ValueError("boxes do not split into walkers")
+        self.nwalkers = em.num_lattices // nlat
+        self.beta = 1.0 / (KB * temperature)                # mc_moves.F90:998
+        self.max_trans = max_trans_ang * ANG_TO_BOHR        # io.f90:165
+        self.pressure = pressure_au
+        self.grid = grid if grid is not None else MuGrid()
+        g = self.grid
+        self.weight = np.zeros(g.nbins) if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
+        self.eta_interp = bool(eta_interp)
+        mb, bw = np.ascontiguousarray(g.mu_bin), np.ascontiguousarray(g.binwidth)
+        em._chk(self.L.mw_sweep_configure(
+            self.nlat, ctypes.c_double(self.beta), ctypes.c_double(self.max_trans), g.nbins, int(self.eta_interp),
+            g.start_bin, g.end_bin, ctypes.c_double(g.r_pos), ctypes.c_double(g.a_pos), ctypes.c_double(g.r_neg),
+            ctypes.c_double(g.a_neg), ctypes.c_double(g.my_mu_min), ctypes.c_double(g.my_mu_max),
+            self.weight.ctypes.data_as(_dp), mb.ctypes.data_as(_dp), bw.ctypes.data_as(_dp)))
+
+    def initial_mu(self, walker):
+        """ls_mu as mc_init / mc_lattice_switch form it (mc_moves.F90:1581-1583), without leshift."""
+        if self.nlat == 1:
+            return 0.0
+        b = (walker - 1) * 2
+        e, v, n = self.em.model_energy, self.em.volume, self.em.nwater
+        mu = (e[b] + self.pressure * v[b]) - (e[b + 1] + self.pressure * v[b + 1])
+        return mu * self.beta - n * math.log(v[b] / v[b + 1])
+
+    def set_state(self, walker, ls=1, ls_mu=None):
+        mu = self.initial_mu(walker) if ls_mu is None else ls_mu
+        self.em._chk(self.L.mw_sweep_set_state(walker, ls, ctypes.c_double(mu)))
+
+    def state(self, walker):
+        ls, mu, acc = ctypes.c_int(0), ctypes.c_double(0.0), ctypes.c_longlong(0)
+        e = (ctypes.c_double * 2)()
+        self.em._chk(self.L.mw_sweep_get_state(walker, ctypes.byref(ls), ctypes.byref(mu), e, ctypes.byref(acc)))
+        return dict(ls=ls.value, ls_mu=mu.value, model_energy=[e[k] for k in range(self.nlat)], accepted=acc.value)
+
+    def sweep(self, nmoves, seed, move0=0, first_walker=1, count=None, log=False):
+        count = self.nwalkers - first_walker + 1 if count is None else count
+        if log:
+            out = np.zeros((count, nmoves, 8))
+            self.em._chk(self.L.mw_sweep_translation(first_walker, count, nmoves, ctypes.c_ulonglong(seed),
+                                                     ctypes.c_ulonglong(move0), out.ctypes.data_as(_dp)))
+            return out
+        self.em._chk(self.L.mw_sweep_translation(first_walker, count, nmoves, ctypes.c_ulonglong(seed),
+                                                 ctypes.c_ulonglong(move0), None))
+        return None
+
+    def sweep_launch(self, nmoves, seed, move0=0, first_walker=1, count=None):
+        count = self.nwalkers - first_walker + 1 if count is None else count
+        self.em._chk(self.L.mw_sweep_translation_launch(first_walker, count, nmoves, ctypes.c_ulonglong(seed),
+                                                        ctypes.c_ulonglong(move0), 0))
+
+    def positions(self, ils):
+        x = np.zeros((self.em.nwater, 3))
+        self.em._chk(self.L.mw_download_positions(ils, x.ctypes.data_as(_dp)))
+        return x

@@ -111,6 +111,75 @@ class COracle:
         return eo, en
 
 
+class _Eta(ctypes.Structure):
+    _fields_ = [("nbins", ctypes.c_int), ("eta_interp", ctypes.c_int), ("start_bin", ctypes.c_int), ("end_bin", ctypes.c_int),
+                ("r_pos", ctypes.c_double), ("a_pos", ctypes.c_double), ("r_neg", ctypes.c_double), ("a_neg", ctypes.c_double),
+                ("mu_lo", ctypes.c_double), ("mu_hi", ctypes.c_double),
+                ("weight", _dp), ("mu_bin", _dp), ("binwidth", _dp)]
+
+
+class SweepOracle:
+    """mc_water_translation restated on the CPU (oracle/mw_oracle.c, mwo_sweep_translation)."""
+
+    def __init__(self):
+        self.C = COracle()
+        self.L = self.C.L
+        self.L.mwo_eta_weight.restype = ctypes.c_double
+
+    def uniforms(self, seed, walker, move):
+        u = np.zeros(6)
+        self.L.mwo_move_uniforms(ctypes.c_uint64(seed), ctypes.c_uint32(walker), ctypes.c_uint64(move), _d(u))
+        return u
+
+    def mu_grid(self, nbins, mu_min, mu_max):
+        mb, bw, gp = np.zeros(nbins), np.zeros(nbins), np.zeros(4)
+        self.L.mwo_mu_grid(nbins, ctypes.c_double(mu_min), ctypes.c_double(mu_max), _d(mb), _d(bw), _d(gp))
+        return mb, bw, gp
+
+    def _eta(self, grid, weight, eta_interp):
+        self._keep = (np.ascontiguousarray(weight, dtype=np.float64), np.ascontiguousarray(grid.mu_bin),
+                      np.ascontiguousarray(grid.binwidth))
+        return _Eta(grid.nbins, int(eta_interp), grid.start_bin, grid.end_bin, grid.r_pos, grid.a_pos, grid.r_neg,
+                    grid.a_neg, grid.my_mu_min, grid.my_mu_max, _d(self._keep[0]), _d(self._keep[1]), _d(self._keep[2]))
+
+    def eta_weight(self, grid, weight, eta_interp, mu):
+        e = self._eta(grid, weight, eta_interp)
+        return self.L.mwo_eta_weight(ctypes.byref(e), ctypes.c_double(mu))
+
+    def mu_to_bin(self, grid, mu):
+        e = self._eta(grid, np.zeros(grid.nbins), True)
+        return self.L.mwo_mu_to_bin(ctypes.byref(e), ctypes.c_double(mu))
+
+    def sweep(self, nmoves, seed, walker, move0, hs, xs, beta, max_trans, grid=None, weight=None, eta_interp=True,
+              ls=1, ls_mu=0.0, model_energy=None, maxneigh=MAXNEIGH, lists=None):
+        """hs, xs: lists (1 or 2 lattices).  Returns dict(xyz, ls, ls_mu, model_energy, accepted, log, lists)."""
+        nlat, n = len(xs), len(xs[0])
+        xyz = np.ascontiguousarray(np.stack(xs), dtype=np.float64).copy()
+        h = np.ascontiguousarray(np.stack(hs), dtype=np.float64)
+        ivs = [self.C.ivects(hh) for hh in hs]
+        ivstride = max(len(v) for v in ivs)
+        iv = np.zeros((nlat, ivstride, 3))
+        for l, v in enumerate(ivs):
+            iv[l, :len(v)] = v
+        if lists is None:
+            lists = [self.C.neighbours(xs[l], ivs[l], maxneigh) for l in range(nlat)]
+        nn = np.ascontiguousarray(np.stack([t[0] for t in lists]))
+        jn = np.ascontiguousarray(np.stack([t[1] for t in lists]))
+        vn = np.ascontiguousarray(np.stack([t[2] for t in lists]))
+        if model_energy is None:
+            model_energy = [self.C.model_energy(xs[l], ivs[l], *lists[l]) for l in range(nlat)]
+        me = np.ascontiguousarray(model_energy, dtype=np.float64).copy()
+        eta = self._eta(grid, weight if weight is not None else np.zeros(grid.nbins), eta_interp) if grid is not None \
+            else _Eta(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, None, None)
+        lsv, mu, acc = ctypes.c_int(ls), ctypes.c_double(ls_mu), ctypes.c_longlong(0)
+        log = np.zeros((nmoves, 8))
+        self.L.mwo_sweep_translation(nmoves, ctypes.c_uint64(seed), ctypes.c_uint32(walker), ctypes.c_uint64(move0),
+                                     nlat, n, _d(xyz), _d(h), _d(iv), ivstride, maxneigh, _i(nn), _i(jn), _i(vn),
+                                     ctypes.c_double(beta), ctypes.c_double(max_trans), ctypes.byref(eta),
+                                     ctypes.byref(lsv), ctypes.byref(mu), _d(me), ctypes.byref(acc), _d(log))
+        return dict(xyz=xyz, ls=lsv.value, ls_mu=mu.value, model_energy=me, accepted=acc.value, log=log, lists=lists)
+
+
 class RefOracle:
     """The reference's compiled Fortran (module energy), one system at a time.
 

@@ -266,3 +266,224 @@ void mwo_trial_moves(int nmoves, const int *imol, const double *trial,
         r[0] = keep[0]; r[1] = keep[1]; r[2] = keep[2];                                     /* mc_moves.F90:1186 */
     }
 }
+
+/* =========================================================================================
+ * the translation-move driver (mc_moves.F90:966-1213) with its helpers
+ * eta_weight (:893-964) and mu_to_bin (:2187-2215).  Restated from the cited lines; pinned so far
+ * only through the (pinned) local energies it calls -- the reference's own random stream comes from
+ * the Fortran intrinsic generator and cannot be replayed, so the driver is compared with the HIP
+ * implementation on a shared Philox stream.
+ * ========================================================================================= */
+#include <stdint.h>
+
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+static double u53(uint32_t a, uint32_t b)
+{
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);   /* [0,1) */
+}
+
+void mwo_move_uniforms(uint64_t seed, uint32_t walker, uint64_t move, double u[6])
+{
+    for (uint32_t call = 0; call < 3; ++call) {
+        uint32_t c[4] = { (uint32_t)move, (uint32_t)(move >> 32), walker, call };
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        u[2 * call]     = u53(c[0], c[1]);
+        u[2 * call + 1] = u53(c[2], c[3]);
+    }
+}
+
+/* r**n for integer n by repeated multiplication, as Fortran evaluates r_pos**Ns / r_pos**k */
+static double ipow(double r, int n)
+{
+    double acc = 1.0, b = r;
+    for (int e = n; e > 0; e >>= 1) { if (e & 1) acc *= b; b *= b; }
+    return acc;
+}
+
+static double gp_ratio(double a, double s, int Ns)           /* mc_moves.F90:583-596 */
+{
+    double r = 1.1;
+    for (int k = 1; ; ++k) {
+        const double tmpsum = a * (1.0 - ipow(r, Ns)) / (1.0 - r);
+        const double r_new = r * pow(s / tmpsum, 1.0 / (double)Ns);
+        if (fabs(r_new - r) <= 2.0 * 2.220446049250313e-16) break;
+        if (k > 1000000) break;
+        r = r_new;
+    }
+    return r;
+}
+
+void mwo_mu_grid(int nbins, double mu_min, double mu_max, double *mu_bin, double *binwidth, double gp[4])
+{
+    const double s_pos = fabs(mu_max) - 0.5, s_neg = fabs(mu_min) - 0.5;     /* :571-572 */
+    const double a_pos = 1.0, a_neg = 1.0;
+    const int Ns = nbins / 2;
+    const double r_pos = gp_ratio(a_pos, s_pos, Ns), r_neg = gp_ratio(a_neg, s_neg, Ns);
+    double mu_u = -0.5, mu_l;
+    int k = 0;
+    for (int ibin = nbins / 2; ibin >= 1; --ibin) {                          /* :625-633 */
+        mu_l = mu_u - a_neg * ipow(r_neg, k);
+        mu_bin[ibin - 1] = 0.5 * (mu_u + mu_l);
+        binwidth[ibin - 1] = mu_u - mu_l;
+        mu_u = mu_l; ++k;
+    }
+    mu_bin[nbins / 2] = 0.0; binwidth[nbins / 2] = 1.0;                      /* :636-637 */
+    mu_l = 0.5; k = 0;
+    for (int ibin = nbins / 2 + 2; ibin <= nbins; ++ibin) {                  /* :641-649 */
+        mu_u = mu_l + a_pos * ipow(r_pos, k);
+        mu_bin[ibin - 1] = 0.5 * (mu_u + mu_l);
+        binwidth[ibin - 1] = mu_u - mu_l;
+        mu_l = mu_u; ++k;
+    }
+    gp[0] = r_pos; gp[1] = a_pos; gp[2] = r_neg; gp[3] = a_neg;
+}
+
+int mwo_mu_to_bin(const mwo_eta *g, double mu)                               /* mc_moves.F90:2187-2215 */
+{
+    if (fabs(mu) <= 0.5) return g->nbins / 2 + 1;
+    if (mu > 0.0) {
+        const double arg = 1.0 - (mu - 0.5) * (1.0 - g->r_pos) / g->a_pos;
+        return g->nbins / 2 + 2 + (int)(log(arg) / log(g->r_pos));
+    }
+    const double arg = 1.0 - (fabs(mu) - 0.5) * (1.0 - g->r_neg) / g->a_neg;
+    return g->nbins / 2 - (int)(log(arg) / log(g->r_neg));
+}
+
+double mwo_eta_weight(const mwo_eta *g, double mu)                           /* mc_moves.F90:893-964 */
+{
+    if (mu < g->mu_lo) return 1.7976931348623157e308;                        /* huge(1.0_dp), :915-918 */
+    if (mu > g->mu_hi) return 1.7976931348623157e308;
+    const int k = mwo_mu_to_bin(g, mu);
+    const double *w = g->weight - 1, *mb = g->mu_bin - 1, *bw = g->binwidth - 1;   /* 1-based views */
+    if (!g->eta_interp) return w[k];
+    double gradient;
+    if (k == g->start_bin) {                                                 /* :929-933 */
+        gradient = 2.0 * (w[k + 1] - w[k]) / (bw[k] + bw[k + 1]);
+        return w[k] + (mu - mb[k]) * gradient;
+    }
+    if (k == g->end_bin) {                                                   /* :935-939 */
+        gradient = 2.0 * (w[k] - w[k - 1]) / (bw[k] + bw[k - 1]);
+        return w[k] + (mu - mb[k]) * gradient;
+    }
+    if (mu > mb[k]) {                                                        /* :942-945 */
+        gradient = 2.0 * (w[k + 1] - w[k]) / (bw[k] + bw[k + 1]);
+        return w[k] + (mu - mb[k]) * gradient;
+    }
+    gradient = 2.0 * (w[k] - w[k - 1]) / (bw[k] + bw[k - 1]);               /* :947-949 */
+    return w[k - 1] + (mu - mb[k - 1]) * gradient;
+}
+
+#define HM(m, r, c) ((m)[((c) - 1) * 3 + ((r) - 1)])     /* Fortran (r,c), column-major 3x3 */
+void mwo_recipmatrix(const double h[9], double rc[9])                        /* util.f90:43-77 */
+{
+    HM(rc,1,1) = HM(h,2,2)*HM(h,3,3) - HM(h,2,3)*HM(h,3,2);
+    HM(rc,1,2) = HM(h,2,3)*HM(h,3,1) - HM(h,2,1)*HM(h,3,3);
+    HM(rc,1,3) = HM(h,2,1)*HM(h,3,2) - HM(h,2,2)*HM(h,3,1);
+    HM(rc,2,1) = HM(h,1,3)*HM(h,3,2) - HM(h,1,2)*HM(h,3,3);
+    HM(rc,2,2) = HM(h,1,1)*HM(h,3,3) - HM(h,1,3)*HM(h,3,1);
+    HM(rc,2,3) = HM(h,1,2)*HM(h,3,1) - HM(h,1,1)*HM(h,3,2);
+    HM(rc,3,1) = HM(h,1,2)*HM(h,2,3) - HM(h,1,3)*HM(h,2,2);
+    HM(rc,3,2) = HM(h,1,3)*HM(h,2,1) - HM(h,1,1)*HM(h,2,3);
+    HM(rc,3,3) = HM(h,1,1)*HM(h,2,2) - HM(h,1,2)*HM(h,2,1);
+    const double vol = HM(h,1,1)*HM(rc,1,1) + HM(h,1,2)*HM(rc,1,2) + HM(h,1,3)*HM(rc,1,3);
+    const double Pi = 3.141592653589793238462643383279502884197;
+    for (int i = 0; i < 9; ++i) rc[i] = rc[i] * 2.0 * Pi / vol;
+}
+
+void mwo_sweep_translation(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0,
+                           int nlat, int n, double *xyz, const double *h,
+                           const double *ivect, int ivstride, int maxneigh,
+                           const int *nn, const int *jn, const int *vn,
+                           double beta, double max_trans, const mwo_eta *eta,
+                           int *ls_io, double *ls_mu_io, double *model_energy,
+                           long long *accepted, double *log)
+{
+    const double invPi = 1.0 / 3.141592653589793238462643383279502884197;     /* constants.f90:23 */
+    double recip[2][9];
+    for (int l = 0; l < nlat; ++l) mwo_recipmatrix(h + 9 * l, recip[l]);
+    int ls = *ls_io;                                                          /* 1-based */
+    double ls_mu = *ls_mu_io;
+    long long acc = 0;
+#define LAT(l, arr, stride) ((arr) + (size_t)(l) * (stride))
+    for (int mv = 0; mv < nmoves; ++mv) {
+        double u[6];
+        mwo_move_uniforms(seed, walker, move0 + (uint64_t)mv, u);
+        const int lsn = nlat == 2 ? 3 - ls : 1;                               /* partner_lattice, :866-868 */
+        int imol = (int)(u[0] * (double)n) + 1;                               /* :1001-1002 */
+        if (imol > n) imol = n;
+        double old_e[2] = {0, 0}, new_e[2] = {0, 0}, backup[2] = {0, 0}, deltaE[2] = {0, 0};
+        for (int l = 0; l < nlat; ++l) {                                      /* :1007-1018 */
+            old_e[l] = mwo_local_energy(imol, n, LAT(l, xyz, 3 * n), LAT(l, ivect, 3 * ivstride), maxneigh,
+                                        LAT(l, nn, n), LAT(l, jn, (size_t)n * maxneigh), LAT(l, vn, (size_t)n * maxneigh), NULL);
+            backup[l] = model_energy[l];
+            model_energy[l] = model_energy[l] - old_e[l];
+        }
+        double x = 2.0 * u[1] - 1.0, y = 2.0 * u[2] - 1.0, z = 2.0 * u[3] - 1.0;   /* :1021-1027 */
+        const double norm = 1.0 / sqrt(x * x + y * y + z * z);                /* :1029 */
+        x = x * norm; y = y * norm; z = z * norm;
+        const double r = u[4] * 2.0 - 1.0;                                    /* :1035 */
+        x = x * max_trans * r; y = y * max_trans * r; z = z * max_trans * r;  /* :1037-1039 */
+        const double *rc = recip[ls - 1];
+        double sx = HM(rc,1,1) * x + HM(rc,2,1) * y + HM(rc,3,1) * z;         /* :1042-1050 */
+        double sy = HM(rc,1,2) * x + HM(rc,2,2) * y + HM(rc,3,2) * z;
+        double sz = HM(rc,1,3) * x + HM(rc,2,3) * y + HM(rc,3,3) * z;
+        sx = sx * 0.5 * invPi; sy = sy * 0.5 * invPi; sz = sz * 0.5 * invPi;  /* :1052-1054 */
+        double transvec[2][3];
+        transvec[ls - 1][0] = x; transvec[ls - 1][1] = y; transvec[ls - 1][2] = z;
+        if (nlat == 2) {                                                      /* :1061-1067 */
+            const double *hn = h + 9 * (lsn - 1);
+            for (int d = 1; d <= 3; ++d)
+                transvec[lsn - 1][d - 1] = HM(hn,d,1) * sx + HM(hn,d,2) * sy + HM(hn,d,3) * sz;
+        }
+        for (int l = 0; l < nlat; ++l) {                                      /* :1076-1092 */
+            double *p = LAT(l, xyz, 3 * n) + 3 * (imol - 1);
+            p[0] += transvec[l][0]; p[1] += transvec[l][1]; p[2] += transvec[l][2];
+            new_e[l] = mwo_local_energy(imol, n, LAT(l, xyz, 3 * n), LAT(l, ivect, 3 * ivstride), maxneigh,
+                                        LAT(l, nn, n), LAT(l, jn, (size_t)n * maxneigh), LAT(l, vn, (size_t)n * maxneigh), NULL);
+            model_energy[l] = model_energy[l] + new_e[l];
+            deltaE[l] = new_e[l] - old_e[l];
+        }
+        double diffkT;
+        if (nlat == 1) {
+            diffkT = beta * deltaE[0];                                        /* :1106 */
+        } else {
+            const double eta_old = mwo_eta_weight(eta, ls_mu);                /* :1112-1116 */
+            ls_mu = ls_mu + (deltaE[0] - deltaE[1]) * beta;
+            const double eta_new = mwo_eta_weight(eta, ls_mu);
+            diffkT = deltaE[ls - 1] * beta + eta_new - eta_old;
+        }
+        const double zeta = u[5];                                             /* :1145 */
+        double pacc = exp(-diffkT);
+        if (pacc > 1.0) pacc = 1.0;
+        const int ok = zeta < pacc;                                           /* :1146 (false for NaN) */
+        if (ok) {
+            ++acc;
+        } else {                                                              /* :1182-1195 */
+            for (int l = 0; l < nlat; ++l) {
+                double *p = LAT(l, xyz, 3 * n) + 3 * (imol - 1);
+                p[0] -= transvec[l][0]; p[1] -= transvec[l][1]; p[2] -= transvec[l][2];
+                model_energy[l] = backup[l];
+            }
+            if (nlat == 2) ls_mu = ls_mu - (deltaE[0] - deltaE[1]) * beta;
+        }
+        if (log) {
+            double *q = log + 8 * (size_t)mv;
+            q[0] = imol; q[1] = ok; q[2] = old_e[0]; q[3] = new_e[0]; q[4] = old_e[1]; q[5] = new_e[1]; q[6] = ls_mu; q[7] = diffkT;
+        }
+    }
+#undef LAT
+    *ls_io = ls; *ls_mu_io = ls_mu; *accepted += acc;
+}

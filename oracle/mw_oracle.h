@@ -66,3 +66,51 @@ void mwo_trial_moves(int nmoves, const int *imol, const double *trial,
 }
 #endif
 #endif
+
+/* ---- next row of SURVEY.md 8(f): the translation-move driver ------------------------------ */
+#ifndef MW_ORACLE_SWEEP_H
+#define MW_ORACLE_SWEEP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Random numbers of one trial move: Philox4x32-10, counter = (move index lo/hi, walker, call 0..2),
+ * key = seed.  u[0] picks the molecule, u[1..3] the direction, u[4] the length, u[5] is the
+ * acceptance variate (the six draws of mc_water_translation, mc_moves.F90:1001,1021-1023,1035,1145).
+ * The reference draws from the Fortran intrinsic generator, whose stream is compiler specific; the
+ * device driver and this oracle share this counter-based stream instead. */
+void mwo_move_uniforms(uint64_t seed, uint32_t walker, uint64_t move, double u[6]);
+
+/* Overlap-parameter grid of mc_init (mc_moves.F90:571-656): geometric bin widths either side of a
+ * unit middle bin.  gp = {r_pos, a_pos, r_neg, a_neg}. */
+void mwo_mu_grid(int nbins, double mu_min, double mu_max, double *mu_bin, double *binwidth, double gp[4]);
+
+typedef struct {
+    int nbins, eta_interp, start_bin, end_bin;      /* 1-based bins, my_start_bin / my_end_bin */
+    double r_pos, a_pos, r_neg, a_neg;              /* mc_moves.F90:75-76 */
+    double mu_lo, mu_hi;                            /* my_mu_min / my_mu_max */
+    const double *weight, *mu_bin, *binwidth;       /* nbins each */
+} mwo_eta;
+
+int mwo_mu_to_bin(const mwo_eta *g, double mu);                 /* mc_moves.F90:2187-2215 */
+double mwo_eta_weight(const mwo_eta *g, double mu);             /* mc_moves.F90:893-964  */
+void mwo_recipmatrix(const double h[9], double recip[9]);       /* util.f90:43-77 (2 pi / V convention) */
+
+/* nmoves translation moves of one walker, exactly the sequence of mc_water_translation
+ * (mc_moves.F90:966-1213) with the moves numbered move0, move0+1, ...  Arrays hold nlat (1 or 2)
+ * lattices back to back: xyz[nlat][n][3], h[nlat][9], ivect[nlat][ivstride][3], nn[nlat][n],
+ * jn/vn[nlat][n][maxneigh].  *ls is the active lattice (1-based), model_energy[nlat] is edited the
+ * way the reference's caller does.  log (may be NULL) receives 8 doubles per move:
+ * imol, accepted, old1, new1, old2, new2, ls_mu after the move, diffkT. */
+void mwo_sweep_translation(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0,
+                           int nlat, int n, double *xyz, const double *h,
+                           const double *ivect, int ivstride, int maxneigh,
+                           const int *nn, const int *jn, const int *vn,
+                           double beta, double max_trans, const mwo_eta *eta,
+                           int *ls, double *ls_mu, double *model_energy,
+                           long long *accepted, double *log);
+#ifdef __cplusplus
+}
+#endif
+#endif

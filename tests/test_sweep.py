@@ -1,0 +1,164 @@
+"""The translation-move driver.
+
+CPU: the oracle's helpers against the reference formulas; GPU: the device-resident sweep against
+the oracle's restatement of mc_water_translation on the same Philox stream -- the same molecule
+picked, the same accept/reject decision and the same energies move by move, the same final
+positions, order parameter and accumulated energies."""
+import numpy as np
+import pytest
+
+from conftest import DE_ATOL, RTOL, load_golden
+
+
+@pytest.fixture(scope="module")
+def so():
+    from oracle import SweepOracle
+    return SweepOracle()
+
+
+def test_mu_grid_matches_python_restatement(so):
+    from mc_water_ls_mw_amd.sweep import MuGrid
+    g = MuGrid(101, -400.0, 400.0)
+    mb, bw, gp = so.mu_grid(101, -400.0, 400.0)
+    assert np.allclose(mb, g.mu_bin, rtol=1e-14, atol=1e-12) and np.allclose(bw, g.binwidth, rtol=1e-13)
+    assert gp[0] == pytest.approx(g.r_pos, rel=1e-15) and gp[2] == pytest.approx(g.r_neg, rel=1e-15)
+    # the bins tile [mu_min, mu_max]: half-widths accumulate to the range (mc_moves.F90:571-656)
+    assert bw.sum() == pytest.approx(800.0, rel=1e-12)
+    assert mb[50] == 0.0 and bw[50] == 1.0
+    edges = np.concatenate([[-400.0], -400.0 + np.cumsum(bw)])
+    for k in range(101):                                   # a bin's centre maps back to that bin
+        assert so.mu_to_bin(g, mb[k]) == k + 1
+        assert edges[k] < mb[k] < edges[k + 1]
+
+
+def test_eta_weight_interpolates_and_walls(so):
+    from mc_water_ls_mw_amd.sweep import MuGrid
+    g = MuGrid(101, -400.0, 400.0)
+    w = 0.01 * g.mu_bin ** 2 / 100.0
+    for k in (0, 10, 50, 77, 100):
+        assert so.eta_weight(g, w, True, g.mu_bin[k]) == pytest.approx(w[k], rel=1e-13, abs=1e-15)
+        assert so.eta_weight(g, w, False, g.mu_bin[k]) == w[k]
+    assert so.eta_weight(g, w, True, 400.5) == np.finfo(float).max      # huge(1.0_dp): hard wall
+    assert so.eta_weight(g, w, True, -400.5) == np.finfo(float).max
+    mid = 0.5 * (g.mu_bin[60] + g.mu_bin[61])
+    lo, hi = sorted((w[60], w[61]))
+    assert lo <= so.eta_weight(g, w, True, mid) <= hi
+
+
+def test_uniforms_are_a_counter_based_stream(so):
+    a = so.uniforms(12345, 3, 77)
+    assert np.array_equal(a, so.uniforms(12345, 3, 77))
+    assert not np.array_equal(a, so.uniforms(12345, 4, 77)) and not np.array_equal(a, so.uniforms(12346, 3, 77))
+    u = np.array([so.uniforms(1, 0, m) for m in range(4000)])
+    assert u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.01
+
+
+def test_oracle_sweep_keeps_the_energy_books(so, c_oracle):
+    """The accumulated model_energy (caller-side bookkeeping, mc_moves.F90:1013-1016,1087,1190) stays equal to a
+    fresh full-box energy as long as the list is fresh enough -- the reference's own drift check."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.sweep import KB
+    h, x = lat.ice_box("ih", (3, 2, 2), 0.1, seed=5)
+    r = so.sweep(150, seed=9, walker=0, move0=0, hs=[h], xs=[x], beta=1.0 / (KB * 220.0), max_trans=0.3)
+    assert 0 < r["accepted"] < 150
+    iv = c_oracle.ivects(h)
+    fresh = c_oracle.model_energy(r["xyz"][0], iv, *r["lists"][0])
+    assert abs(r["model_energy"][0] - fresh) < 1e-10
+
+
+def _farm(boxes, nlat, temperature, max_trans_ang, grid=None, weight=None):
+    from mc_water_ls_mw_amd.energy import load_boxes
+    from mc_water_ls_mw_amd.sweep import WalkerFarm
+    em = load_boxes([b[0] for b in boxes], [b[1] for b in boxes])
+    return em, WalkerFarm(em, nlat, temperature, max_trans_ang, grid=grid, weight=weight)
+
+
+def _compare(log_gpu, ref, farm_state, xyz_gpu):
+    assert np.array_equal(log_gpu[:, 0], ref["log"][:, 0])                     # same molecule every move
+    assert np.array_equal(log_gpu[:, 1], ref["log"][:, 1])                     # same accept / reject
+    for c in (2, 3, 4, 5):
+        assert np.all(np.abs(log_gpu[:, c] - ref["log"][:, c]) <= RTOL * np.abs(ref["log"][:, c]) + 1e-14)
+    assert np.all(np.abs((log_gpu[:, 3] - log_gpu[:, 2]) - (ref["log"][:, 3] - ref["log"][:, 2])) <= DE_ATOL)
+    assert np.all(np.abs(log_gpu[:, 6] - ref["log"][:, 6]) <= 1e-7 * (1 + np.abs(ref["log"][:, 6])))   # ls_mu = beta*dE sums
+    assert farm_state["accepted"] == ref["accepted"] and farm_state["ls"] == ref["ls"]
+    for l, x in enumerate(xyz_gpu):
+        assert np.abs(x - ref["xyz"][l]).max() < 1e-10
+        assert abs(farm_state["model_energy"][l] - ref["model_energy"][l]) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_single_box_walkers_follow_the_oracle(so):
+    from mc_water_ls_mw_amd import lattice as lat
+    h, x0 = lat.ice_box("ih", (3, 2, 2), 0.0)
+    boxes = [(h, lat.thermalise(x0, 0.12, 40 + w)) for w in range(6)]
+    em, farm = _farm(boxes, 1, 220.0, 1.1)
+    try:
+        for w in range(1, 7):
+            farm.set_state(w, 1, 0.0)
+        log = farm.sweep(120, seed=2024, move0=7, log=True)
+        # a second launch continues the same chains (move numbers go on)
+        log2 = farm.sweep(60, seed=2024, move0=127, log=True)
+        for w in range(6):
+            ref = so.sweep(180, 2024, w, 7, [h], [boxes[w][1]], farm.beta, farm.max_trans)
+            _compare(np.concatenate([log[w], log2[w]]), ref, farm.state(w + 1), [farm.positions(w + 1)])
+    finally:
+        em.energy_deinit()
+
+
+@pytest.mark.gpu
+def test_lattice_switch_walkers_follow_the_oracle(so):
+    """Two lattices per walker (Ic / Ih, the ice1_sample pair): fractional mapping of the move into the partner
+    lattice, order parameter, multicanonical weights with interpolation."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.sweep import MuGrid
+    z1, z2 = load_golden("ic48"), load_golden("ih48")
+    grid = MuGrid(101, -400.0, 400.0)
+    weight = 3.0 * np.exp(-(grid.mu_bin / 150.0) ** 2) + 0.002 * np.abs(grid.mu_bin)
+    boxes = []
+    for w in range(4):
+        boxes += [(z1["h"], lat.thermalise(z1["xyz"], 0.08, 60 + w)), (z2["h"], lat.thermalise(z2["xyz"], 0.08, 80 + w))]
+    em, farm = _farm(boxes, 2, 200.0, 1.1, grid=grid, weight=weight)
+    try:
+        mus = []
+        for w in range(1, 5):
+            ls = 1 + (w % 2)
+            mus.append((ls, farm.initial_mu(w)))
+            farm.set_state(w, ls, mus[-1][1])
+        log = farm.sweep(160, seed=77, move0=0, log=True)
+        for w in range(4):
+            ls, mu = mus[w]
+            ref = so.sweep(160, 77, w, 0, [z1["h"], z2["h"]], [boxes[2 * w][1], boxes[2 * w + 1][1]], farm.beta,
+                           farm.max_trans, grid=grid, weight=weight, ls=ls, ls_mu=mu,
+                           model_energy=[em.model_energy[2 * w], em.model_energy[2 * w + 1]])
+            _compare(log[w], ref, farm.state(w + 1), [farm.positions(2 * w + 1), farm.positions(2 * w + 2)])
+            assert 0 < ref["accepted"] < 160
+    finally:
+        em.energy_deinit()
+
+
+@pytest.mark.gpu
+def test_1536_pair_sweep_with_list_refresh(so, c_oracle):
+    """BASELINE.json configs[2]: the 1536-molecule Ic/Ih pair; sweep, rebuild the lists on the device at the
+    host's cadence (mc_moves.F90:218-222), sweep on -- and the oracle does the same."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.sweep import MuGrid
+    z1, z2 = load_golden("ic1536"), load_golden("ih1536")
+    x1, x2 = lat.thermalise(z1["xyz"], 0.1, 7), lat.thermalise(z2["xyz"], 0.1, 8)
+    grid = MuGrid(101, -8000.0, 8000.0)
+    em, farm = _farm([(z1["h"], x1), (z2["h"], x2)], 2, 200.0, 1.1, grid=grid)
+    try:
+        mu0 = farm.initial_mu(1)
+        farm.set_state(1, 1, mu0)
+        log_a = farm.sweep(100, seed=5, move0=0, log=True)[0]
+        em.build_neighbours_batch(1, 2)
+        log_b = farm.sweep(100, seed=5, move0=100, log=True)[0]
+        hs = [z1["h"], z2["h"]]
+        ra = so.sweep(100, 5, 0, 0, hs, [x1, x2], farm.beta, farm.max_trans, grid=grid, ls=1, ls_mu=mu0,
+                      model_energy=list(em.model_energy))
+        rb = so.sweep(100, 5, 0, 100, hs, [ra["xyz"][0], ra["xyz"][1]], farm.beta, farm.max_trans, grid=grid,
+                      ls=ra["ls"], ls_mu=ra["ls_mu"], model_energy=list(ra["model_energy"]))
+        rb["accepted"] += ra["accepted"]
+        rb["log"] = np.concatenate([ra["log"], rb["log"]])
+        _compare(np.concatenate([log_a, log_b]), rb, farm.state(1), [farm.positions(1), farm.positions(2)])
+    finally:
+        em.energy_deinit()
