@@ -80,7 +80,7 @@ struct Ctx {
     size_t swlog_cap = 0;
     // staged moves
     int mcap = 0, mn = 0;
-    int *d_mbox = nullptr, *d_mimol = nullptr;
+    int* d_mimol = nullptr;
     double *d_mtrial = nullptr, *d_meold = nullptr, *d_menew = nullptr;
     unsigned int* d_mcnt = nullptr;
     int* d_mperm = nullptr;        // sorted request -> caller's index
@@ -210,10 +210,9 @@ int ensure_moves(int n)
 {
     if (n <= g.mcap) return 0;
     HIPCHK(hipStreamSynchronize(g.stream));
-    if (g.d_mbox) { hipFree(g.d_mbox); hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); hipFree(g.d_mcnt); hipFree(g.d_mperm); }
+    if (g.d_mimol) { hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); hipFree(g.d_mcnt); hipFree(g.d_mperm); }
     int cap = 1024;
     while (cap < n) cap *= 2;
-    HIPCHK(hipMalloc(&g.d_mbox, sizeof(int) * cap));
     HIPCHK(hipMalloc(&g.d_mimol, sizeof(int) * cap));
     HIPCHK(hipMalloc(&g.d_mtrial, sizeof(double) * 3 * cap));
     HIPCHK(hipMalloc(&g.d_meold, sizeof(double) * cap));
@@ -433,7 +432,7 @@ int mw_finalize(void)
     hipFree(g.d_grid); hipFree(g.d_usegrid); hipFree(g.d_cellid); hipFree(g.d_shift); hipFree(g.d_sorted);
     hipFree(g.d_ccount); hipFree(g.d_cstart); hipFree(g.d_ccursor);
     hipFree(g.d_partial); hipFree(g.d_cpartial); hipFree(g.d_energy); hipFree(g.d_counts);
-    if (g.d_mbox) { hipFree(g.d_mbox); hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); hipFree(g.d_mcnt); hipFree(g.d_mperm); }
+    if (g.d_mimol) { hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); hipFree(g.d_mcnt); hipFree(g.d_mperm); }
     if (g.d_mwork) hipFree(g.d_mwork);
     hipHostFree(g.h_pin);
     for (int s = 0; s < kTimerSlots; ++s) {

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Throughput of the device-resident translation-move driver (many walkers, one wavefront each).
+Run on the GPU box: python tools/sweep_measurements.py"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402,F401
+
+from mc_water_ls_mw_amd import lattice as lat  # noqa: E402
+from mc_water_ls_mw_amd.energy import EnergyModule  # noqa: E402
+from mc_water_ls_mw_amd.sweep import MuGrid, WalkerFarm  # noqa: E402
+
+
+def farm_for(cells, nlat, walkers, sigma, temperature):
+    n = len(cells[0][1])
+    em = EnergyModule(n, walkers * nlat)
+    for w in range(walkers):
+        for l in range(nlat):
+            em.hmatrix[w * nlat + l] = cells[l][0]
+            em.ljr[w * nlat + l] = lat.thermalise(cells[l][1], sigma, 1000 * l + w)
+    em._chk(em.L.mw_init(0, em.nwater, em.num_lattices, em.maxneigh))
+    em._live = True
+    for b in range(1, walkers * nlat + 1):
+        em.volume[b - 1] = abs(np.linalg.det(em.hmatrix[b - 1]))
+        em.compute_ivects(b)
+        em._upload(b)
+    em.build_neighbours_batch(1, walkers * nlat)
+    em.model_energy_batch(1, walkers * nlat)
+    grid = MuGrid(101, -8000.0, 8000.0) if nlat == 2 else None
+    farm = WalkerFarm(em, nlat, temperature, 1.1, grid=grid)
+    for w in range(1, walkers + 1):
+        farm.set_state(w, 1, farm.initial_mu(w))
+    return em, farm
+
+
+def run(name, cells, nlat, walkers, nmoves, out):
+    em, farm = farm_for(cells, nlat, walkers, 0.1, 200.0)
+    farm.sweep_launch(20, seed=1, move0=0)
+    em.sync()
+    em.timer_start(0)
+    farm.sweep_launch(nmoves, seed=1, move0=20)
+    em.timer_stop(0)
+    ms = em.timer_ms(0)
+    acc = np.mean([farm.state(w)["accepted"] for w in range(1, min(walkers, 64) + 1)]) / (nmoves + 20)
+    # drift check of walker 1 against a fresh full-box energy (the reference's own consistency test)
+    st = farm.state(1)
+    fresh = em.model_energy_batch(1, nlat)
+    out[name] = {"walkers": walkers, "lattices": nlat, "molecules": len(cells[0][1]), "moves_per_walker": nmoves,
+                 "ms": ms, "moves_per_s": walkers * nmoves / (ms * 1e-3),
+                 "local_energy_evaluations_per_s": walkers * nmoves * 2 * nlat / (ms * 1e-3),
+                 "us_per_move_per_walker": ms * 1e3 / nmoves, "acceptance": acc,
+                 "drift_walker1_Ha": [st["model_energy"][l] - fresh[l] for l in range(nlat)]}
+    em.energy_deinit()
+
+
+out = {}
+g = lambda n: dict(np.load(os.path.join(ROOT, "tests", "golden", n + ".npz")))  # noqa: E731
+ic48, ih48 = g("ic48"), g("ih48")
+run("pair48 x 8192 walkers", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 8192, 480, out)
+ic1536, ih1536 = g("ic1536"), g("ih1536")
+run("pair1536 x 2048 walkers", [(ic1536["h"], ic1536["xyz"]), (ih1536["h"], ih1536["xyz"])], 2, 2048, 300, out)
+h, x = lat.ice_box("ih", (8, 8, 8), 0.0)
+run("ih4096 x 2048 walkers", [(h, x)], 1, 2048, 300, out)
+print(json.dumps(out, indent=1))
