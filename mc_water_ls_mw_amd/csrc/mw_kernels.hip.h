@@ -712,6 +712,8 @@ struct WaveScratch {
     double go[kCap], gn[kCap];                 // exp(gamma sigma/(r_ij - a sigma)) old / trial
     int j[kCap], kimg[kCap], flag[kCap];       // molecule, image, bit0 = in range (old), bit1 = (trial)
     int start[kCap + 2];                       // first slot of j's row in the end-to-end numbering
+    uint32_t qe[64];                           // queue of in-range third bodies: packed list entry ...
+    int qown[64];                              // ... and the rank of the neighbour j whose row it came from
 };
 static_assert(sizeof(WaveScratch) % 8 == 0, "scratch records must keep 8-byte alignment");
 
@@ -805,6 +807,43 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv,
     }
 
     // ---- i--j--k triplets (molint.F90:324-343): the rows of all in-range j, end to end --------
+    // Two stages.  SCAN: every slot gets the cheap part (gather, distance test); the ~1/3 that are in
+    // range are queued (entry + owner rank, 8 bytes) in the wave's scratch.  FLUSH: whenever 64 are
+    // queued (and at the end) one full pass does the expensive part -- rsqrt, reciprocal, exp and the two
+    // cosines -- with every lane busy, instead of three passes at one third occupancy.
+    int nq = 0;                                              // queued entries (wave-uniform)
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < nq) {
+            const uint32_t e2 = ws->qe[lane];
+            const int own = ws->qown[lane];
+            const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
+            const int kj = ws->kimg[own], fl = ws->flag[own];
+            double xk, yk, zk, kvx, kvy, kvz, sjx, sjy, sjz;
+            getpos(kk, xk, yk, zk);
+            getiv(k2, kvx, kvy, kvz);
+            getiv(kj, sjx, sjy, sjz);
+            const double pjx = ws->q[0][own], pjy = ws->q[1][own], pjz = ws->q[2][own];
+            const double bx = ((xk + kvx) + sjx) - pjx;                          // :332,334
+            const double by = ((yk + kvy) + sjy) - pjy;
+            const double bz = ((zk + kvz) + sjz) - pjz;
+            const double s2 = bx * bx + by * by + bz * bz;                       // :335 (in range: tested at scan)
+            double rk, gk, e1k;
+            pair_terms(s2, rk, e1k, gk);
+            if (fl & 1) {
+                const double ct = (-((pjx - xo) * bx + (pjy - yo) * by + (pjz - zo) * bz) * ws->rinvo[own]) * rk;   // :320,341,365
+                if (ct < 0.99) { const double d = ct - kCos0; t3o += ws->go[own] * (gk * (d * d)); ++nto; }
+            }
+            if (fl & 2) {
+                const double ct = (-((pjx - xn) * bx + (pjy - yn) * by + (pjz - zn) * bz) * ws->rinvn[own]) * rk;
+                if (ct < 0.99) { const double d = ct - kCos0; t3n += ws->gn[own] * (gk * (d * d)); ++ntn; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        nq = 0;
+    };
     for (int t0 = 0; t0 < T; t0 += 64) {
         const int t = t0 + lane;
         const bool valid = t < T;
@@ -814,7 +853,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv,
             const int cand = own + step;
             if (cand < cntU && ws->start[cand < kCap ? cand : kCap - 1] <= t) own = cand;
         }
-        const int jj = ws->j[own], kj = ws->kimg[own], fl = ws->flag[own];
+        const int jj = ws->j[own], kj = ws->kimg[own];
         const uint32_t e2 = valid ? LM[(size_t)jj * kRow + (t - ws->start[own])] : 0u;
         const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
         double xk, yk, zk, kvx, kvy, kvz, sjx, sjy, sjz;
@@ -829,28 +868,36 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv,
         const double boy_ = ((yk + kvy) + sjy) - pjy;
         const double boz_ = ((zk + kvz) + sjz) - pjz;
         const double s2o = box_ * box_ + boy_ * boy_ + boz_ * boz_;              // :335
-        double bnx = box_, bny = boy_, bnz = boz_, s2n = s2o;
-        if (selfmove) {   // an image of the molecule itself as third body: it moves too
-            bnx = ((xn + kvx) + sjx) - pjx; bny = ((yn + kvy) + sjy) - pjy; bnz = ((zn + kvz) + sjz) - pjz;
-            s2n = bnx * bnx + bny * bny + bnz * bnz;
-        }
-        const bool act = valid && !selfimg;
-        const bool ko = act && (s2o < kRcSq), kn = act && (s2n < kRcSq);         // :361
-        double rko = 0.0, gko = 0.0, e1k;
-        if (ko) pair_terms(s2o, rko, e1k, gko);
-        double rkn = rko, gkn = gko;
         if (__ballot(selfmove) != 0ull) {
-            if (selfmove && kn) pair_terms(s2n, rkn, e1k, gkn);
+            // an image of the molecule itself as third body moves with it: both geometries, in line (rare)
+            if (selfmove) {
+                const int fl = ws->flag[own];
+                const double bnx = ((xn + kvx) + sjx) - pjx, bny = ((yn + kvy) + sjy) - pjy, bnz = ((zn + kvz) + sjz) - pjz;
+                const double s2n = bnx * bnx + bny * bny + bnz * bnz;
+                double rk, gk, e1k;
+                if ((s2o < kRcSq) && (fl & 1)) {
+                    pair_terms(s2o, rk, e1k, gk);
+                    const double ct = (-((pjx - xo) * box_ + (pjy - yo) * boy_ + (pjz - zo) * boz_) * ws->rinvo[own]) * rk;
+                    if (ct < 0.99) { const double d = ct - kCos0; t3o += ws->go[own] * (gk * (d * d)); ++nto; }
+                }
+                if ((s2n < kRcSq) && (fl & 2)) {
+                    pair_terms(s2n, rk, e1k, gk);
+                    const double ct = (-((pjx - xn) * bnx + (pjy - yn) * bny + (pjz - zn) * bnz) * ws->rinvn[own]) * rk;
+                    if (ct < 0.99) { const double d = ct - kCos0; t3n += ws->gn[own] * (gk * (d * d)); ++ntn; }
+                }
+            }
         }
-        if (ko && (fl & 1)) {
-            const double ct = (-((pjx - xo) * box_ + (pjy - yo) * boy_ + (pjz - zo) * boz_) * ws->rinvo[own]) * rko;   // :320,341,365
-            if (ct < 0.99) { const double d = ct - kCos0; t3o += ws->go[own] * (gko * (d * d)); ++nto; }
+        const bool inq = valid && !self && (s2o < kRcSq);                        // :361; the k == i self term is dropped
+        const unsigned long long mq = __ballot(inq);
+        const int c = __popcll(mq);
+        if (nq + c > 64) flush();
+        if (inq) {
+            const int slot = nq + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mq, 0u));
+            ws->qe[slot] = e2; ws->qown[slot] = own;
         }
-        if (kn && (fl & 2)) {
-            const double ct = (-((pjx - xn) * bnx + (pjy - yn) * bny + (pjz - zn) * bnz) * ws->rinvn[own]) * rkn;
-            if (ct < 0.99) { const double d = ct - kCos0; t3n += ws->gn[own] * (gkn * (d * d)); ++ntn; }
-        }
+        nq += c;
     }
+    if (nq > 0) flush();
     __builtin_amdgcn_wave_barrier();                          // scratch is reused by the wave's next request
 
     double eo = acco + kLamEps * t3o, en = accn + kLamEps * t3n;                 // :397
