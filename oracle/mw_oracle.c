@@ -269,10 +269,11 @@ void mwo_trial_moves(int nmoves, const int *imol, const double *trial,
 
 /* =========================================================================================
  * the translation-move driver (mc_moves.F90:966-1213) with its helpers
- * eta_weight (:893-964) and mu_to_bin (:2187-2215).  Restated from the cited lines; pinned so far
- * only through the (pinned) local energies it calls -- the reference's own random stream comes from
- * the Fortran intrinsic generator and cannot be replayed, so the driver is compared with the HIP
- * implementation on a shared Philox stream.
+ * eta_weight (:893-964) and mu_to_bin (:2187-2215).  Restated from the cited lines.  PINNED against the
+ * reference program itself: oracle/_ref/mc_water_ref_rng is the reference's unmodified
+ * main/mc_moves/io/... with random_uniform_random interposed at link time (ref_wrap_rng.c) so that it
+ * draws this file's Philox stream; tests/test_sweep_pin.py replays its runs (single box; two lattices
+ * with interpolated weights) and lands on the same configuration to 1e-10 after ~2000 trial moves.
  * ========================================================================================= */
 #include <stdint.h>
 

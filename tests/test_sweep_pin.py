@@ -1,0 +1,163 @@
+"""CPU: pin the oracle of the translation-move driver (oracle/mw_oracle.c, mwo_sweep_translation,
+mwo_eta_weight, mwo_mu_to_bin, mwo_mu_grid, mwo_recipmatrix) against the REFERENCE PROGRAM itself.
+
+oracle/_ref/mc_water_ref_rng (build container only) is the reference's unmodified main/mc_moves/io/...
+with two link-time interpositions: the G2 stack scrub and a random_uniform_random that returns the
+oracle's counter-based Philox stream (oracle/ref_wrap_rng.c).  With volume and switch moves off, its
+mc_cycle is then exactly "nwater translation moves, lists rebuilt every list_update_int cycles"; the
+oracle replays that and must end at the same positions (read from the reference's checkpoint file, full
+double precision) having passed through the same energies (thermo file, 6 digits) -- single box, and the
+two-lattice Ic/Ih system with interpolated multicanonical weights (eta_weights.dat)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+RNG = os.path.join(ROOT, "oracle", "_ref", "mc_water_ref_rng")
+SEED = 424242          # oracle/ref_wrap_rng.c
+HART_TO_EV = 27.211396181
+AUP_TO_ATM = 2.90363081e8
+
+pytestmark = pytest.mark.skipif(not os.path.exists(RNG), reason="oracle/_ref/mc_water_ref_rng not built")
+
+
+def namelist(num_lattices, temperature, cycles, samplerun):
+    return f"""&potential
+model_type = "mW"
+/
+&thermal
+temperature = {temperature}
+pressure    = 1.0
+/
+&MonteCarlo
+mc_ensemble      = 'nvt'
+mc_max_trans     = 1.1
+mc_dv_max        = 0.924
+nbins            = 101
+mu_max           = +400
+mu_min           = -400
+mc_always_switch = .false.
+allow_switch     = .false.
+allow_vol        = .false.
+eta_interp       = .true.
+samplerun        = .{'true' if samplerun else 'false'}.
+/
+&config
+num_lattices = {num_lattices}
+nwater       = 48
+method       = 'xmol'
+ls           = 1
+/
+&bookkeeping
+list_update_int  = 10
+traj_output_int  = 100000
+file_output_int  = 1
+max_mc_cycles    = {cycles}
+eq_mc_cycles     = 1
+eq_adjust_mc     = .false.
+chkpt_dump_int   = {cycles}
+timer_qtime      = 172800
+timer_closetime  = 1800
+/
+"""
+
+
+def read_records(path):
+    recs, data = [], open(path, "rb").read()
+    off = 0
+    while off < len(data):
+        (n,) = struct.unpack_from("<i", data, off)
+        recs.append(data[off + 4:off + 4 + n])
+        off += 8 + n
+    return recs
+
+
+def run_reference(d, num_lattices, temperature, cycles, weight=None, grid=None):
+    from mc_water_ls_mw_amd import lattice as lat
+    os.makedirs(d)
+    open(os.path.join(d, "ice.input"), "w").write(namelist(num_lattices, temperature, cycles, weight is not None))
+    z1 = load_golden("ic48_t015")
+    h1, x1 = lat.read_xmol(_write(d, "input001.xmol", z1))
+    boxes = [(h1, x1)]
+    if num_lattices == 2:
+        z2 = load_golden("ih48_t020")
+        boxes.append(lat.read_xmol(_write(d, "input002.xmol", z2)))
+        with open(os.path.join(d, "eta_weights.dat"), "w") as fh:       # format of mc_moves.F90:738-770
+            fh.write("#Current energy increment =   0.500000007451E-01\n")
+            for mu, w in zip(grid.mu_bin, weight):
+                fh.write(f"  {float(mu)!r}        {float(w)!r}\n")
+    out = subprocess.run([RNG, "ice.input"], cwd=d, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-800:], out.stderr[-800:])
+    therm = [f for f in os.listdir(d) if f.endswith("_therm.dat")][0]
+    e_ev = np.array([float(ln.split()[1]) for ln in open(os.path.join(d, therm))])
+    chk = [f for f in os.listdir(d) if f.startswith("checkpoint")]
+    recs = read_records(os.path.join(d, sorted(chk)[-1]))
+    ljr = np.frombuffer(recs[-2], dtype="<f8").reshape(num_lattices, 48, 3)      # ljr(3,1,N,L), column-major
+    ls = struct.unpack("<i", recs[-1])[0]
+    assert struct.unpack("<i", recs[1])[0] == cycles
+    return boxes, e_ev, np.array(ljr), ls
+
+
+def _write(d, name, z):
+    from mc_water_ls_mw_amd import lattice as lat
+    p = os.path.join(d, name)
+    lat.write_xmol(p, z["h"], z["xyz"])
+    return p
+
+
+def replay(so, c_oracle, boxes, temperature, cycles, grid=None, weight=None):
+    """mc_cycle with translations only: lists rebuilt when mod(cycle, 10) == 0, then nwater moves."""
+    from mc_water_ls_mw_amd.sweep import KB
+    from mc_water_ls_mw_amd.lattice import ANG_TO_BOHR
+    beta = 1.0 / (KB * temperature)
+    hs = [b[0] for b in boxes]
+    xs = [np.array(b[1]) for b in boxes]
+    ivs = [c_oracle.ivects(h) for h in hs]
+    lists = [c_oracle.neighbours(xs[l], ivs[l]) for l in range(len(xs))]
+    me = [c_oracle.model_energy(xs[l], ivs[l], *lists[l]) for l in range(len(xs))]
+    ls, mu = 1, 0.0
+    if len(xs) == 2:                                            # mc_moves.F90:856-859
+        p = 1.0 / AUP_TO_ATM
+        v = [abs(np.linalg.det(h)) for h in hs]
+        mu = me[0] + p * v[0] - me[1] - p * v[1]
+        mu = mu * beta - 48.0 * np.log(v[0] / v[1])
+    energies = []
+    for cyc in range(1, cycles + 1):
+        if cyc % 10 == 0:                                       # mc_moves.F90:217-222
+            lists = [c_oracle.neighbours(xs[l], ivs[l]) for l in range(len(xs))]
+        r = so.sweep(48, SEED, 0, (cyc - 1) * 48, hs, xs, beta, 1.1 * ANG_TO_BOHR, grid=grid, weight=weight,
+                     ls=ls, ls_mu=mu, model_energy=me, lists=lists)
+        xs = [r["xyz"][l] for l in range(len(xs))]
+        me, ls, mu = list(r["model_energy"]), r["ls"], r["ls_mu"]
+        energies.append(me[ls - 1] * HART_TO_EV)
+    return np.array(xs), np.array(energies), ls
+
+
+@pytest.fixture(scope="module")
+def so():
+    from oracle import SweepOracle
+    return SweepOracle()
+
+
+def test_single_box_translation_moves_match_the_reference_program(tmp_path, so, c_oracle):
+    boxes, e_ref, ljr, ls = run_reference(str(tmp_path / "run"), 1, 220, 40)
+    xs, e_or, _ = replay(so, c_oracle, boxes, 220.0, 40)
+    assert np.abs(xs - ljr).max() < 1e-11                       # 1920 trial moves later: the same configuration
+    assert np.allclose(e_or, e_ref, rtol=2e-6, atol=2e-6)       # the thermo file holds 6-7 digits
+    assert np.abs(ljr[0] - boxes[0][1]).max() > 0.5             # ... and it did move
+
+
+def test_two_lattice_moves_and_weights_match_the_reference_program(tmp_path, so, c_oracle):
+    from mc_water_ls_mw_amd.sweep import MuGrid
+    grid = MuGrid(101, -400.0, 400.0)
+    weight = 3.0 * np.exp(-((grid.mu_bin - 60.0) / 120.0) ** 2) + 0.004 * np.abs(grid.mu_bin)
+    boxes, e_ref, ljr, ls = run_reference(str(tmp_path / "run"), 2, 200, 40, weight=weight, grid=grid)
+    xs, e_or, ls_or = replay(so, c_oracle, boxes, 200.0, 40, grid=grid, weight=weight)
+    assert ls == ls_or == 1
+    assert np.abs(xs - ljr).max() < 1e-10
+    assert np.allclose(e_or, e_ref, rtol=2e-6, atol=2e-6)
+    assert np.abs(ljr[1] - boxes[1][1]).max() > 0.5
