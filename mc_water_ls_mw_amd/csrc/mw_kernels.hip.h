@@ -408,37 +408,45 @@ struct AtomSum { double e; unsigned long long np, nt; };
 constexpr int kQCap = 12;   // in-range entries per molecule parked in LDS between the two phases
 
 // `queue` points at this thread's column of an LDS array [kQCap][BLOCK] (entry q at queue[q*BLOCK]:
-// consecutive threads, consecutive banks).
+// consecutive threads, consecutive banks).  The list is read eight slots at a time and ONE CHUNK
+// AHEAD: `cur` arrives holding this molecule's first eight entries; while a chunk is being tested the
+// next one -- of this molecule, or the first of the thread's next molecule `inext` -- is already in
+// flight, so the HBM latency of the list stream hides behind the LDS gathers and distance tests.
 template <int BLOCK, typename PosFn, typename IvFn>
-__device__ __forceinline__ AtomSum atom_energy(int i, int n, const uint32_t* __restrict__ L, int N,
-                                               uint32_t* __restrict__ queue, PosFn getpos, IvFn getiv)
+__device__ __forceinline__ AtomSum atom_energy(int i, int n, const uint32_t* __restrict__ L, int N, int S,
+                                               uint32_t* __restrict__ queue, PosFn getpos, IvFn getiv,
+                                               uint32_t (&cur)[8], int inext)
 {
     double xi, yi, zi;
     getpos(i, xi, yi, zi);
 
-    // phase 1: cheap distance test over all list slots.  The list is read eight slots at a time
-    // -- eight independent, coalesced loads in flight -- and the in-range entries are parked in LDS.
+    // phase 1: cheap distance test over all list slots; the in-range entries are parked in LDS.
     int cnt = 0;
     unsigned long long over = 0ull;             // in-range slots beyond the LDS queue (re-read later)
-    for (int s0 = 0; s0 < n; s0 += 8) {
-        uint32_t e[8];
+    for (int s0 = 0; s0 < n || s0 == 0; s0 += 8) {
+        uint32_t nxt[8];
+        const bool last = s0 + 8 >= n;
+        const int pi = last ? inext : i;                      // whose chunk comes next
+        const int ps = last ? 0 : s0 + 8;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) e[u] = (s0 + u < n) ? L[(size_t)(s0 + u) * N + i] : 0u;
+        for (int u = 0; u < 8; ++u) nxt[u] = (pi >= 0 && ps + u < S) ? L[(size_t)(ps + u) * N + pi] : 0u;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (s0 + u < n) {
                 double xj, yj, zj, ix, iy, iz;
-                getpos((int)(e[u] & kJMask), xj, yj, zj);
-                getiv((int)(e[u] >> kJBits), ix, iy, iz);
+                getpos((int)(cur[u] & kJMask), xj, yj, zj);
+                getiv((int)(cur[u] >> kJBits), ix, iy, iz);
                 const double dx = (xj + ix) - xi, dy = (yj + iy) - yi, dz = (zj + iz) - zi;   // molint.F90:447,450
                 const double r2 = dx * dx + dy * dy + dz * dz;
                 if (r2 < kRcSq) {                                                             // :454
-                    if (cnt < kQCap) queue[cnt * BLOCK] = e[u];
+                    if (cnt < kQCap) queue[cnt * BLOCK] = cur[u];
                     else over |= 1ull << (s0 + u);
                     ++cnt;
                 }
             }
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
     }
 
     // phase 2: pair term and moments over the in-range entries only
@@ -526,9 +534,20 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
     unsigned long long np = 0, nt = 0;
     const int a0 = split * chunk;
     const int a1 = min(N, a0 + chunk);
-    for (int i = a0 + tid; i < a1; i += BLOCK) {
-        AtomSum a = atom_energy<BLOCK>(i, NN[i], L, N, queue, getpos, getiv);
+    int i = a0 + tid;
+    uint32_t cur[8];
+    int n_cur = 0;
+    if (i < a1) {
+        n_cur = NN[i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = u < S ? L[(size_t)u * N + i] : 0u;
+    }
+    for (; i < a1; i += BLOCK) {
+        const int inext = i + BLOCK < a1 ? i + BLOCK : -1;
+        const int n_next = inext >= 0 ? NN[inext] : 0;          // one molecule ahead, like the list chunks
+        AtomSum a = atom_energy<BLOCK>(i, n_cur, L, N, S, queue, getpos, getiv, cur, inext);
         esum += a.e; np += a.np; nt += a.nt;
+        n_cur = n_next;
     }
 
     esum = wave_sum(esum); np = wave_sum_u64(np); nt = wave_sum_u64(nt);
