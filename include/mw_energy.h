@@ -149,6 +149,19 @@ int mw_sweep_configure(int nlat, double beta, double max_trans_bohr, int nbins, 
                        int start_bin, int end_bin, double r_pos, double a_pos, double r_neg, double a_neg,
                        double mu_lo, double mu_hi,
                        const double *weight, const double *mu_bin, const double *binwidth);
+/* The rest of a translation-only mc_cycle, per walker and on the device (two lattices): after every move
+ * mc_update_wl_bins (mc_moves.F90:1597-1689, default schedule) on the walker's own histogram /
+ * unbiased_hist / weight tables when `record` (mc_cycle_num >= eq_mc_cycles) -- with `samplerun` the
+ * weights stay fixed and the unbiased histogram accumulates, otherwise the visited bin's weight grows by
+ * av_binwidth*wl_factor/binwidth and the minimum is subtracted -- and, with `always_switch`, one
+ * mc_lattice_switch attempt (mc_moves.F90:1536-1594; `npt` selects its ensemble branch).  Each walker
+ * starts from the weight table given to mw_sweep_configure; the host synchronises the tables across
+ * walkers and GPUs (comms_allreduce_eta/hist/uhist semantics) through get/set_tables. */
+int mw_sweep_options(int record, int samplerun, int always_switch, int npt,
+                     double av_binwidth, double wl_factor, double log_unbiased_norm, double pressure);
+int mw_sweep_get_tables(int walker, double *weight, double *histogram, double *unbiased_hist);
+int mw_sweep_set_tables(int walker, const double *weight, const double *histogram, const double *unbiased_hist);
+int mw_sweep_get_switches(int walker, long long *switches);
 int mw_set_model_energy(int ils, double e);
 int mw_sweep_set_state(int walker, int ls, double ls_mu);
 int mw_sweep_get_state(int walker, int *ls, double *ls_mu, double *model_energy, long long *accepted);

@@ -72,7 +72,10 @@ struct Ctx {
     bool sweep_ready = false;
     mw::SweepParams sp;
     int nwalkers = 0;
-    double *d_sw_weight = nullptr, *d_sw_mubin = nullptr, *d_sw_binwidth = nullptr;
+    double *d_sw_mubin = nullptr, *d_sw_binwidth = nullptr;
+    double *d_wweight = nullptr, *d_whist = nullptr, *d_wuhist = nullptr;   // [walker][nbins]
+    unsigned long long* d_wswitch = nullptr;
+    double* d_volume = nullptr;                  // [box] |det hmatrix|
     int* d_wls = nullptr;
     double* d_wmu = nullptr;
     unsigned long long* d_wacc = nullptr;
@@ -372,6 +375,8 @@ int mw_init(int device, int nwater, int nboxes, int maxneigh)
     HIPCHK(hipMalloc(&g.d_ivect, nb * g.ivcap * 3 * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_nivect, nb * sizeof(int)));
     HIPCHK(hipMalloc(&g.d_hmat, nb * 9 * sizeof(double)));
+    HIPCHK(hipMalloc(&g.d_volume, nb * sizeof(double)));
+    HIPCHK(hipMemset(g.d_volume, 0, nb * sizeof(double)));
     HIPCHK(hipMemset(g.d_hmat, 0, nb * 9 * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_list, nb * N * (size_t)maxneigh * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.d_listm, nb * N * (size_t)mw::kRow * sizeof(uint32_t)));
@@ -425,8 +430,9 @@ int mw_finalize(void)
     hipSetDevice(g.device);
     hipStreamSynchronize(g.stream);
     hipFree(g.d_hmat);
-    if (g.d_sw_weight) { hipFree(g.d_sw_weight); hipFree(g.d_sw_mubin); hipFree(g.d_sw_binwidth); }
-    if (g.d_wls) { hipFree(g.d_wls); hipFree(g.d_wmu); hipFree(g.d_wacc); }
+    if (g.d_sw_mubin) { hipFree(g.d_sw_mubin); hipFree(g.d_sw_binwidth); hipFree(g.d_wweight); hipFree(g.d_whist); hipFree(g.d_wuhist); }
+    if (g.d_wls) { hipFree(g.d_wls); hipFree(g.d_wmu); hipFree(g.d_wacc); hipFree(g.d_wswitch); }
+    hipFree(g.d_volume);
     if (g.d_swlog) hipFree(g.d_swlog);
     hipFree(g.d_pos); hipFree(g.d_ivect); hipFree(g.d_nivect); hipFree(g.d_list); hipFree(g.d_listm); hipFree(g.d_nn); hipFree(g.d_stats);
     hipFree(g.d_grid); hipFree(g.d_usegrid); hipFree(g.d_cellid); hipFree(g.d_shift); hipFree(g.d_sorted);
@@ -469,6 +475,15 @@ int mw_set_cell(int ils, const double h[9], int* nivect_out)
     HIPCHK(hipMemcpyAsync(g.d_ivect + off, &g.h_ivect[off], iv.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipMemcpyAsync(g.d_nivect + (ils - 1), &g.h_nivect[ils - 1], sizeof(int), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipMemcpyAsync(g.d_hmat + 9 * (size_t)(ils - 1), h, 9 * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    {   // volume(ils) = |det hmatrix(:,:,ils)| as util_determinant expands it (util.f90:16-41; molint.F90:125)
+        const double* m = h;   // m[(c-1)*3 + (r-1)] = hmatrix(r,c)
+        double det = m[0] * (m[4] * m[8] - m[7] * m[5]);
+        det = det - m[3] * (m[1] * m[8] - m[7] * m[2]);
+        det = det + m[6] * (m[1] * m[5] - m[4] * m[2]);
+        const double vol = std::fabs(det);
+        HIPCHK(hipMemcpyAsync(g.d_volume + (ils - 1), &vol, sizeof(double), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
     g.h_grid[ils - 1] = make_grid(h, imv, g.cstride);
     g.h_usegrid[ils - 1] = (!g.force_brute && g.h_grid[ils - 1].nc[0] > 0) ? 1 : 0;
     if (!g.h_usegrid[ils - 1]) g.h_grid[ils - 1].nc[0] = 0;
@@ -772,22 +787,38 @@ int mw_sweep_configure(int nlat, double beta, double max_trans, int nbins, int e
     g.sp.beta = beta; g.sp.max_trans = max_trans;
     g.sp.r_pos = r_pos; g.sp.a_pos = a_pos; g.sp.r_neg = r_neg; g.sp.a_neg = a_neg; g.sp.mu_lo = mu_lo; g.sp.mu_hi = mu_hi;
     g.sp.nlat = nlat; g.sp.nbins = nbins; g.sp.eta_interp = eta_interp; g.sp.start_bin = start_bin; g.sp.end_bin = end_bin; g.sp.pad = 0;
-    if (g.d_sw_weight) { HIPCHK(hipFree(g.d_sw_weight)); HIPCHK(hipFree(g.d_sw_mubin)); HIPCHK(hipFree(g.d_sw_binwidth)); g.d_sw_weight = nullptr; }
+    g.sp.record = 0; g.sp.samplerun = 1; g.sp.always_switch = 0; g.sp.npt = 0;
+    g.sp.av_binwidth = 1.0; g.sp.wl_factor = 0.0; g.sp.log_unbiased_norm = 0.0; g.sp.pressure = 0.0;
+    if (g.d_sw_mubin) {
+        HIPCHK(hipFree(g.d_sw_mubin)); HIPCHK(hipFree(g.d_sw_binwidth));
+        HIPCHK(hipFree(g.d_wweight)); HIPCHK(hipFree(g.d_whist)); HIPCHK(hipFree(g.d_wuhist));
+        g.d_sw_mubin = nullptr;
+    }
     const size_t nb = (size_t)(nbins > 0 ? nbins : 1);
-    HIPCHK(hipMalloc(&g.d_sw_weight, nb * sizeof(double)));
+    const size_t nw = (size_t)(g.nbox / nlat);
     HIPCHK(hipMalloc(&g.d_sw_mubin, nb * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_sw_binwidth, nb * sizeof(double)));
+    HIPCHK(hipMalloc(&g.d_wweight, nw * nb * sizeof(double)));
+    HIPCHK(hipMalloc(&g.d_whist, nw * nb * sizeof(double)));
+    HIPCHK(hipMalloc(&g.d_wuhist, nw * nb * sizeof(double)));
+    HIPCHK(hipMemset(g.d_wweight, 0, nw * nb * sizeof(double)));
+    HIPCHK(hipMemset(g.d_whist, 0, nw * nb * sizeof(double)));
+    HIPCHK(hipMemset(g.d_wuhist, 0, nw * nb * sizeof(double)));
     if (nlat == 2) {
-        HIPCHK(hipMemcpy(g.d_sw_weight, weight, nb * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(g.d_sw_mubin, mu_bin, nb * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(g.d_sw_binwidth, binwidth, nb * sizeof(double), hipMemcpyHostToDevice));
+        std::vector<double> all(nw * nb);
+        for (size_t w = 0; w < nw; ++w) std::memcpy(&all[w * nb], weight, nb * sizeof(double));
+        HIPCHK(hipMemcpy(g.d_wweight, all.data(), all.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     g.nwalkers = g.nbox / nlat;
     if (!g.d_wls) {
         HIPCHK(hipMalloc(&g.d_wls, sizeof(int) * g.nbox));
         HIPCHK(hipMalloc(&g.d_wmu, sizeof(double) * g.nbox));
         HIPCHK(hipMalloc(&g.d_wacc, sizeof(unsigned long long) * g.nbox));
+        HIPCHK(hipMalloc(&g.d_wswitch, sizeof(unsigned long long) * g.nbox));
     }
+    HIPCHK(hipMemset(g.d_wswitch, 0, sizeof(unsigned long long) * g.nbox));
     std::vector<int> one((size_t)g.nbox, 1);
     HIPCHK(hipMemcpy(g.d_wls, one.data(), sizeof(int) * g.nbox, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(g.d_wmu, 0, sizeof(double) * g.nbox));
@@ -830,6 +861,52 @@ int mw_sweep_get_state(int walker, int* ls, double* ls_mu, double* model_energy,
     return 0;
 }
 
+int mw_sweep_options(int record, int samplerun, int always_switch, int npt,
+                     double av_binwidth, double wl_factor, double log_unbiased_norm, double pressure)
+{
+    if (check_live()) return 1;
+    if (!g.sweep_ready) return fail("mw_sweep_options: call mw_sweep_configure first");
+    if ((record || always_switch) && g.sp.nlat != 2) return fail("mw_sweep_options: histograms and lattice switches need two lattices");
+    g.sp.record = record ? 1 : 0; g.sp.samplerun = samplerun ? 1 : 0; g.sp.always_switch = always_switch ? 1 : 0; g.sp.npt = npt ? 1 : 0;
+    g.sp.av_binwidth = av_binwidth; g.sp.wl_factor = wl_factor; g.sp.log_unbiased_norm = log_unbiased_norm; g.sp.pressure = pressure;
+    return 0;
+}
+
+static int tables_io(int walker, double* weight, double* hist, double* uhist, bool put)
+{
+    if (check_live() || check_walker(walker, 1)) return 1;
+    const size_t nb = (size_t)g.sp.nbins, off = (size_t)(walker - 1) * nb;
+    double* dev[3] = {g.d_wweight + off, g.d_whist + off, g.d_wuhist + off};
+    double* host[3] = {weight, hist, uhist};
+    for (int t = 0; t < 3; ++t) {
+        if (!host[t]) continue;
+        if (put) HIPCHK(hipMemcpyAsync(dev[t], host[t], nb * sizeof(double), hipMemcpyHostToDevice, g.stream));
+        else     HIPCHK(hipMemcpyAsync(host[t], dev[t], nb * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+    }
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int mw_sweep_get_tables(int walker, double* weight, double* histogram, double* unbiased_hist)
+{
+    return tables_io(walker, weight, histogram, unbiased_hist, false);
+}
+
+int mw_sweep_set_tables(int walker, const double* weight, const double* histogram, const double* unbiased_hist)
+{
+    return tables_io(walker, const_cast<double*>(weight), const_cast<double*>(histogram), const_cast<double*>(unbiased_hist), true);
+}
+
+int mw_sweep_get_switches(int walker, long long* switches)
+{
+    if (check_live() || check_walker(walker, 1)) return 1;
+    unsigned long long v = 0;
+    HIPCHK(hipMemcpyAsync(&v, g.d_wswitch + (walker - 1), sizeof v, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    *switches = (long long)v;
+    return 0;
+}
+
 int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigned long long seed, unsigned long long move0, int want_log)
 {
     if (check_live() || check_walker(first_walker, count)) return 1;
@@ -848,8 +925,8 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
     }
     const size_t shmem = (size_t)g.sp.nlat * g.ivcap * 3 * sizeof(double);
     hipLaunchKernelGGL(mw::k_sweep_translation, dim3(count), dim3(64), shmem, g.stream, g.d_pos, g.d_hmat, g.d_ivect, g.d_nivect,
-                       g.d_listm, g.d_nn, g.d_energy, g.d_wls, g.d_wmu, g.d_wacc, g.sp, g.d_sw_weight, g.d_sw_mubin,
-                       g.d_sw_binwidth, g.N, g.ivcap, nmoves, seed, move0, first_walker - 1, dlog);
+                       g.d_listm, g.d_nn, g.d_energy, g.d_wls, g.d_wmu, g.d_wacc, g.d_wswitch, g.sp, g.d_wweight, g.d_whist, g.d_wuhist,
+                       g.d_sw_mubin, g.d_sw_binwidth, g.d_volume, g.N, g.ivcap, nmoves, seed, move0, first_walker - 1, dlog);
     HIPCHK(hipGetLastError());
     return 0;
 }

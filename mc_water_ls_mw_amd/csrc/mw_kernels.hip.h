@@ -1019,6 +1019,9 @@ struct SweepParams {
     double beta, max_trans;
     double r_pos, a_pos, r_neg, a_neg, mu_lo, mu_hi;
     int nlat, nbins, eta_interp, start_bin, end_bin, pad;
+    // the rest of a translation-only mc_cycle (all off by default)
+    int record, samplerun, always_switch, npt;      // mc_update_wl_bins active / fixed weights / switch after every move / ensemble
+    double av_binwidth, wl_factor, log_unbiased_norm, pressure;
 };
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
@@ -1048,7 +1051,7 @@ __device__ __forceinline__ int dev_mu_to_bin(const SweepParams& g, double mu)   
     return g.nbins / 2 - (int)(log(arg) / log(g.r_neg));
 }
 
-__device__ __forceinline__ double dev_eta_weight(const SweepParams& g, const double* __restrict__ weight,
+__device__ __forceinline__ double dev_eta_weight(const SweepParams& g, const double* weight,
                                                  const double* __restrict__ mu_bin, const double* __restrict__ binwidth,
                                                  double mu)                                // mc_moves.F90:893-964
 {
@@ -1080,15 +1083,20 @@ __device__ __forceinline__ void dev_recipmatrix(const double* __restrict__ h, do
     for (int i = 0; i < 9; ++i) rc[i] *= f;
 }
 
+// Per-walker tables (two lattices only): weight / histogram / unbiased_hist [walker][nbins]; every walker
+// reads its OWN weights in eta_weight, so Wang-Landau updates stay local until the host synchronises them
+// (comms_allreduce_eta/hist/uhist semantics, WalkerComms).
 __global__ __launch_bounds__(64)
 void k_sweep_translation(double* pos, const double* __restrict__ hmat, const double* __restrict__ ivect,
                          const int* __restrict__ nivect, const uint32_t* __restrict__ listm,
                          const int* __restrict__ nn, double* __restrict__ energy,
                          int* __restrict__ wls, double* __restrict__ wmu, unsigned long long* __restrict__ wacc,
-                         SweepParams sp, const double* __restrict__ weight, const double* __restrict__ mu_bin,
-                         const double* __restrict__ binwidth,
+                         unsigned long long* __restrict__ wswitch,
+                         SweepParams sp, double* wweight, double* whist, double* wuhist,
+                         const double* __restrict__ mu_bin, const double* __restrict__ binwidth,
+                         const double* __restrict__ volume,
                          int N, int ivcap, int nmoves, unsigned long long seed, unsigned long long move0,
-                         int walker0, double* __restrict__ log)
+                         int walker0, double* __restrict__ mvlog)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ WaveScratch ws;
@@ -1115,6 +1123,12 @@ void k_sweep_translation(double* pos, const double* __restrict__ hmat, const dou
     }
     __syncthreads();
 
+    // this walker's weight table (read by eta_weight, updated by mc_update_wl_bins) and histograms
+    double* weight = wweight + (size_t)wlk * sp.nbins;
+    double* hist = whist + (size_t)wlk * sp.nbins;
+    double* uhist = wuhist + (size_t)wlk * sp.nbins;
+    unsigned long long nsw = 0;
+
     int ls = wls[wlk];                       // active lattice, 1-based
     double ls_mu = wmu[wlk];
     double men[2] = {energy[box0], L == 2 ? energy[box0 + 1] : 0.0};
@@ -1123,7 +1137,7 @@ void k_sweep_translation(double* pos, const double* __restrict__ hmat, const dou
     for (int mv = 0; mv < nmoves; ++mv) {
         // six uniforms: lanes 0..2 run one Philox call each, the values are broadcast
         double ua = 0.0, ub = 0.0;
-        if (lane < 3) {
+        if (lane < 4) {
             const unsigned long long m = move0 + (unsigned long long)mv;
             uint32_t c[4] = {(uint32_t)m, (uint32_t)(m >> 32), (uint32_t)wlk, (uint32_t)lane};
             philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -1131,6 +1145,7 @@ void k_sweep_translation(double* pos, const double* __restrict__ hmat, const dou
         }
         const double u0 = readlane_f64(ua, 0), u1 = readlane_f64(ub, 0), u2 = readlane_f64(ua, 1);
         const double u3 = readlane_f64(ub, 1), u4 = readlane_f64(ua, 2), u5 = readlane_f64(ub, 2);
+        const double u6 = readlane_f64(ua, 3);          // lattice-switch variate (mc_moves.F90:1576)
 
         const int lsn = L == 2 ? 3 - ls : 1;
         int imol = (int)(u0 * (double)N) + 1;                                    // mc_moves.F90:1001-1002
@@ -1211,9 +1226,61 @@ void k_sweep_translation(double* pos, const double* __restrict__ hmat, const dou
             men[0] = bk0; men[1] = bk1;
             if (L == 2) ls_mu = ls_mu - (dE0 - dE1) * sp.beta;
         }
-        if (log && lane == 0) {
-            double* q = log + ((size_t)blockIdx.x * nmoves + mv) * 8;
-            q[0] = (double)imol; q[1] = ok ? 1.0 : 0.0; q[2] = eo[0]; q[3] = en[0]; q[4] = eo[1]; q[5] = en[1]; q[6] = ls_mu; q[7] = diffkT;
+        // the next move of this wavefront must see the committed position (and the weights written below)
+        int sw = 0;
+        if (L == 2 && sp.record) {                                                // mc_update_wl_bins, :1597-1689
+            const int k = dev_mu_to_bin(sp, ls_mu);
+            if (k >= 1 && k <= sp.nbins) {
+                const double bwk = binwidth[k - 1];
+                if (sp.samplerun) {
+                    const double etaw = dev_eta_weight(sp, weight, mu_bin, binwidth, ls_mu);
+                    if (lane == 0) {
+                        hist[k - 1] = hist[k - 1] + sp.av_binwidth / bwk;                        // :1621
+                        uhist[k - 1] = uhist[k - 1] + (sp.av_binwidth / bwk) * exp(etaw - sp.log_unbiased_norm);   // :1627-1629
+                    }
+                } else {
+                    // weight(k) += av_binwidth*wl_factor/binwidth(k); then subtract the minimum over the window (:1680-1685)
+                    double mn = 1.7976931348623157e308;
+                    for (int b = sp.start_bin - 1 + lane; b < sp.end_bin; b += 64) {
+                        double w = weight[b];
+                        if (b == k - 1) w = w + sp.av_binwidth * sp.wl_factor / bwk;
+                        mn = w < mn ? w : mn;
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(mn, off, 64); mn = o < mn ? o : mn; }
+                    for (int b = sp.start_bin - 1 + lane; b < sp.end_bin; b += 64) {
+                        double w = weight[b];
+                        if (b == k - 1) w = w + sp.av_binwidth * sp.wl_factor / bwk;
+                        weight[b] = w - mn;
+                    }
+                    if (lane == 0) hist[k - 1] = hist[k - 1] + sp.av_binwidth / bwk;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+        }
+        if (L == 2 && sp.always_switch) {                                         // mc_lattice_switch, :1536-1594
+            const int lsw = 3 - ls;
+            const double eta_w = dev_eta_weight(sp, weight, mu_bin, binwidth, ls_mu);
+            const double deta = eta_w - eta_w;                                    // new_eta - old_eta, :1557-1558
+            const double Els = ls == 1 ? men[0] : men[1], Elsn = ls == 1 ? men[1] : men[0];
+            const double V1 = volume[box0], V2 = volume[box0 + 1];
+            const double Vls = ls == 1 ? V1 : V2, Vlsn = ls == 1 ? V2 : V1;
+            double dk;
+            if (sp.npt) dk = sp.beta * Elsn - sp.beta * Els + sp.beta * sp.pressure * (Vlsn - Vls) - (double)N * log(Vlsn / Vls) + deta;
+            else        dk = sp.beta * Elsn - sp.beta * Els + deta;
+            double cmp = exp(-dk);
+            cmp = cmp > 1.0 ? 1.0 : cmp;
+            if (u6 < cmp) {
+                double mu = (men[0] + sp.pressure * V1) - (men[1] + sp.pressure * V2);          // :1581-1583
+                mu = mu * sp.beta - (double)N * log(V1 / V2);
+                ls_mu = mu; ls = lsw; sw = 1; ++nsw;
+            }
+        }
+        if (mvlog && lane == 0) {
+            double* q = mvlog + ((size_t)blockIdx.x * nmoves + mv) * 8;
+            q[0] = (double)imol; q[1] = (ok ? 1.0 : 0.0) + 2.0 * sw; q[2] = eo[0]; q[3] = en[0]; q[4] = eo[1]; q[5] = en[1]; q[6] = ls_mu; q[7] = diffkT;
         }
         // the next move of this wavefront must see the committed position
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1221,7 +1288,7 @@ void k_sweep_translation(double* pos, const double* __restrict__ hmat, const dou
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     if (lane == 0) {
-        wls[wlk] = ls; wmu[wlk] = ls_mu; wacc[wlk] += acc;
+        wls[wlk] = ls; wmu[wlk] = ls_mu; wacc[wlk] += acc; wswitch[wlk] += nsw;
         energy[box0] = men[0];
         if (L == 2) energy[box0 + 1] = men[1];
     }

@@ -92,6 +92,45 @@ class WalkerFarm:
             ctypes.c_double(g.a_neg), ctypes.c_double(g.my_mu_min), ctypes.c_double(g.my_mu_max),
             self.weight.ctypes.data_as(_dp), mb.ctypes.data_as(_dp), bw.ctypes.data_as(_dp)))
 
+    def options(self, record=False, samplerun=True, always_switch=False, npt=False, wl_factor=0.0,
+                log_unbiased_norm=0.0):
+        """Switch on the rest of a translation-only mc_cycle (two lattices): mc_update_wl_bins after every
+        move (``record``; ``samplerun`` keeps the weights fixed) and a lattice-switch attempt after every move
+        (``always_switch``, mc_moves.F90:243-248)."""
+        self.em._chk(self.L.mw_sweep_options(int(record), int(samplerun), int(always_switch), int(npt),
+                                             ctypes.c_double(self.grid.av_binwidth), ctypes.c_double(wl_factor),
+                                             ctypes.c_double(log_unbiased_norm), ctypes.c_double(self.pressure)))
+
+    def tables(self, walker):
+        """(weight, histogram, unbiased_hist) of one walker."""
+        nb = self.grid.nbins
+        w, h, u = np.zeros(nb), np.zeros(nb), np.zeros(nb)
+        self.em._chk(self.L.mw_sweep_get_tables(walker, w.ctypes.data_as(_dp), h.ctypes.data_as(_dp), u.ctypes.data_as(_dp)))
+        return w, h, u
+
+    def set_tables(self, walker, weight=None, histogram=None, unbiased_hist=None):
+        args = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (weight, histogram, unbiased_hist)]
+        self.em._chk(self.L.mw_sweep_set_tables(walker, *[None if a is None else a.ctypes.data_as(_dp) for a in args]))
+
+    def switches(self, walker):
+        v = ctypes.c_longlong(0)
+        self.em._chk(self.L.mw_sweep_get_switches(walker, ctypes.byref(v)))
+        return v.value
+
+    def synchronise(self, comms):
+        """The mpi_sync_int block of mc_cycle (mc_moves.F90:258-276) for a farm: every walker is a 'rank' of the
+        reference; the increments of all walkers of this GPU are summed on the host, then over the GPUs by
+        ``comms`` (WalkerComms, one all-reduce), and every walker receives the synchronised tables."""
+        nb = self.grid.nbins
+        tabs = [self.tables(w) for w in range(1, self.nwalkers + 1)]
+        last = (comms.eta_last_sync, comms.hist_last_sync, comms.uhist_last_sync)
+        # a rank's contribution = sum over its walkers of (table - last): hand WalkerComms `last + that sum`
+        summed = [last[t] + sum(tab[t] - last[t] for tab in tabs) for t in range(3)]
+        comms.sync(summed[0], summed[1], summed[2])
+        for w in range(1, self.nwalkers + 1):
+            self.set_tables(w, summed[0], summed[1], summed[2])
+        return summed
+
     def initial_mu(self, walker):
         """ls_mu as mc_init / mc_lattice_switch form it (mc_moves.F90:1581-1583), without leshift."""
         if self.nlat == 1:

@@ -121,6 +121,12 @@ class _Eta(ctypes.Structure):
                 ("weight", _dp), ("mu_bin", _dp), ("binwidth", _dp)]
 
 
+class _CycleOpts(ctypes.Structure):
+    _fields_ = [("record", ctypes.c_int), ("samplerun", ctypes.c_int), ("always_switch", ctypes.c_int), ("npt", ctypes.c_int),
+                ("av_binwidth", ctypes.c_double), ("wl_factor", ctypes.c_double), ("log_unbiased_norm", ctypes.c_double),
+                ("pressure", ctypes.c_double), ("volume", ctypes.c_double * 2)]
+
+
 class SweepOracle:
     """mc_water_translation restated on the CPU (oracle/mw_oracle.c, mwo_sweep_translation)."""
 
@@ -181,6 +187,46 @@ class SweepOracle:
                                      ctypes.c_double(beta), ctypes.c_double(max_trans), ctypes.byref(eta),
                                      ctypes.byref(lsv), ctypes.byref(mu), _d(me), ctypes.byref(acc), _d(log))
         return dict(xyz=xyz, ls=lsv.value, ls_mu=mu.value, model_energy=me, accepted=acc.value, log=log, lists=lists)
+
+    def cycle(self, nmoves, seed, walker, move0, hs, xs, beta, max_trans, grid, weight, histogram, unbiased_hist,
+              eta_interp=True, ls=1, ls_mu=0.0, model_energy=None, lists=None, record=True, samplerun=True,
+              always_switch=True, npt=False, wl_factor=0.0, log_unbiased_norm=0.0, pressure=0.0, maxneigh=MAXNEIGH):
+        """mwo_sweep_cycle: translations + mc_update_wl_bins + lattice-switch attempts.  weight / histogram /
+        unbiased_hist are copied; the updated tables come back in the result."""
+        nlat, n = len(xs), len(xs[0])
+        xyz = np.ascontiguousarray(np.stack(xs), dtype=np.float64).copy()
+        h = np.ascontiguousarray(np.stack(hs), dtype=np.float64)
+        ivs = [self.C.ivects(hh) for hh in hs]
+        ivstride = max(len(v) for v in ivs)
+        iv = np.zeros((nlat, ivstride, 3))
+        for l, v in enumerate(ivs):
+            iv[l, :len(v)] = v
+        if lists is None:
+            lists = [self.C.neighbours(xs[l], ivs[l], maxneigh) for l in range(nlat)]
+        nn = np.ascontiguousarray(np.stack([t[0] for t in lists]))
+        jn = np.ascontiguousarray(np.stack([t[1] for t in lists]))
+        vn = np.ascontiguousarray(np.stack([t[2] for t in lists]))
+        if model_energy is None:
+            model_energy = [self.C.model_energy(xs[l], ivs[l], *lists[l]) for l in range(nlat)]
+        me = np.ascontiguousarray(model_energy, dtype=np.float64).copy()
+        w = np.ascontiguousarray(weight, dtype=np.float64).copy()
+        hi = np.ascontiguousarray(histogram, dtype=np.float64).copy()
+        uh = np.ascontiguousarray(unbiased_hist, dtype=np.float64).copy()
+        mb, bw = np.ascontiguousarray(grid.mu_bin), np.ascontiguousarray(grid.binwidth)
+        eta = _Eta(grid.nbins, int(eta_interp), grid.start_bin, grid.end_bin, grid.r_pos, grid.a_pos, grid.r_neg,
+                   grid.a_neg, grid.my_mu_min, grid.my_mu_max, _d(w), _d(mb), _d(bw))      # eta reads the live weights
+        vol = (ctypes.c_double * 2)(*[abs(np.linalg.det(hh)) for hh in hs])
+        opt = _CycleOpts(int(record), int(samplerun), int(always_switch), int(npt), grid.av_binwidth, wl_factor,
+                         log_unbiased_norm, pressure, vol)
+        lsv, mu, acc, sw = ctypes.c_int(ls), ctypes.c_double(ls_mu), ctypes.c_longlong(0), ctypes.c_longlong(0)
+        log = np.zeros((nmoves, 8))
+        self.L.mwo_sweep_cycle(nmoves, ctypes.c_uint64(seed), ctypes.c_uint32(walker), ctypes.c_uint64(move0),
+                               nlat, n, _d(xyz), _d(h), _d(iv), ivstride, maxneigh, _i(nn), _i(jn), _i(vn),
+                               ctypes.c_double(beta), ctypes.c_double(max_trans), ctypes.byref(eta), ctypes.byref(opt),
+                               _d(hi), _d(uh), _d(w), ctypes.byref(lsv), ctypes.byref(mu), _d(me),
+                               ctypes.byref(acc), ctypes.byref(sw), _d(log))
+        return dict(xyz=xyz, ls=lsv.value, ls_mu=mu.value, model_energy=me, accepted=acc.value, switches=sw.value,
+                    log=log, lists=lists, weight=w, histogram=hi, unbiased_hist=uh)
 
 
 class RefOracle:

@@ -296,6 +296,16 @@ static double u53(uint32_t a, uint32_t b)
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);   /* [0,1) */
 }
 
+void mwo_move_uniforms8(uint64_t seed, uint32_t walker, uint64_t move, double u[8])
+{
+    for (uint32_t call = 0; call < 4; ++call) {
+        uint32_t c[4] = { (uint32_t)move, (uint32_t)(move >> 32), walker, call };
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        u[2 * call]     = u53(c[0], c[1]);
+        u[2 * call + 1] = u53(c[2], c[3]);
+    }
+}
+
 void mwo_move_uniforms(uint64_t seed, uint32_t walker, uint64_t move, double u[6])
 {
     for (uint32_t call = 0; call < 3; ++call) {
@@ -404,6 +414,60 @@ void mwo_recipmatrix(const double h[9], double rc[9])                        /* 
     for (int i = 0; i < 9; ++i) rc[i] = rc[i] * 2.0 * Pi / vol;
 }
 
+/* mc_update_wl_bins, mc_moves.F90:1597-1689 (default schedule) */
+static void update_wl_bins(const mwo_eta *eta, const mwo_cycle_opts *o, double ls_mu,
+                           double *histogram, double *unbiased_hist, double *weight)
+{
+    if (!o->record) return;                                                   /* :1614 */
+    const int k = mwo_mu_to_bin(eta, ls_mu);                                  /* :1616 */
+    if (k < 1 || k > eta->nbins) return;                                      /* :1619 */
+    histogram[k - 1] = histogram[k - 1] + o->av_binwidth / eta->binwidth[k - 1];          /* :1621 */
+    if (o->samplerun) {                                                       /* :1625-1631 */
+        const double incr = o->av_binwidth / eta->binwidth[k - 1];
+        unbiased_hist[k - 1] = unbiased_hist[k - 1] + incr * exp(mwo_eta_weight(eta, ls_mu) - o->log_unbiased_norm);
+        return;
+    }
+    const double incr = o->wl_factor;                                         /* :1677 */
+    weight[k - 1] = weight[k - 1] + o->av_binwidth * incr / eta->binwidth[k - 1];           /* :1680 */
+    double minbin = weight[eta->start_bin - 1];                               /* :1682-1685 */
+    for (int i = eta->start_bin; i <= eta->end_bin; ++i) if (weight[i - 1] < minbin) minbin = weight[i - 1];
+    for (int i = eta->start_bin; i <= eta->end_bin; ++i) weight[i - 1] = weight[i - 1] - minbin;
+}
+
+/* mc_lattice_switch, mc_moves.F90:1536-1594 (leshift off); returns 1 if accepted */
+static int lattice_switch(const mwo_eta *eta, const mwo_cycle_opts *o, double beta, int n, double x,
+                          const double *model_energy, int *ls, double *ls_mu)
+{
+    const int lsn = 3 - *ls;                                                  /* :1555 */
+    const double old_eta = mwo_eta_weight(eta, *ls_mu), new_eta = mwo_eta_weight(eta, *ls_mu);   /* :1557-1558 */
+    const double *E = model_energy - 1, *V = o->volume - 1;                   /* 1-based views */
+    double diffkT;
+    if (o->npt)                                                               /* :1561-1563 */
+        diffkT = beta * E[lsn] - beta * E[*ls] + beta * o->pressure * (V[lsn] - V[*ls])
+                 - (double)n * log(V[lsn] / V[*ls]) + new_eta - old_eta;
+    else                                                                      /* :1568 */
+        diffkT = beta * E[lsn] - beta * E[*ls] + new_eta - old_eta;
+    double compare = exp(-diffkT);
+    if (compare > 1.0) compare = 1.0;
+    if (x < compare) {                                                        /* :1576-1590 */
+        double mu = (E[1] + o->pressure * V[1]) - (E[2] + o->pressure * V[2]);
+        mu = mu * beta - (double)n * log(V[1] / V[2]);
+        *ls_mu = mu;
+        *ls = lsn;
+        return 1;
+    }
+    return 0;
+}
+
+static void sweep_impl(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0,
+                       int nlat, int n, double *xyz, const double *h,
+                       const double *ivect, int ivstride, int maxneigh,
+                       const int *nn, const int *jn, const int *vn,
+                       double beta, double max_trans, const mwo_eta *eta, const mwo_cycle_opts *opt,
+                       double *histogram, double *unbiased_hist, double *weight,
+                       int *ls_io, double *ls_mu_io, double *model_energy,
+                       long long *accepted, long long *switches, double *log);
+
 void mwo_sweep_translation(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0,
                            int nlat, int n, double *xyz, const double *h,
                            const double *ivect, int ivstride, int maxneigh,
@@ -411,6 +475,32 @@ void mwo_sweep_translation(int nmoves, uint64_t seed, uint32_t walker, uint64_t 
                            double beta, double max_trans, const mwo_eta *eta,
                            int *ls_io, double *ls_mu_io, double *model_energy,
                            long long *accepted, double *log)
+{
+    sweep_impl(nmoves, seed, walker, move0, nlat, n, xyz, h, ivect, ivstride, maxneigh, nn, jn, vn, beta, max_trans,
+               eta, NULL, NULL, NULL, NULL, ls_io, ls_mu_io, model_energy, accepted, NULL, log);
+}
+
+void mwo_sweep_cycle(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0,
+                     int nlat, int n, double *xyz, const double *h,
+                     const double *ivect, int ivstride, int maxneigh,
+                     const int *nn, const int *jn, const int *vn,
+                     double beta, double max_trans, const mwo_eta *eta, const mwo_cycle_opts *opt,
+                     double *histogram, double *unbiased_hist, double *weight,
+                     int *ls_io, double *ls_mu_io, double *model_energy,
+                     long long *accepted, long long *switches, double *log)
+{
+    sweep_impl(nmoves, seed, walker, move0, nlat, n, xyz, h, ivect, ivstride, maxneigh, nn, jn, vn, beta, max_trans,
+               eta, opt, histogram, unbiased_hist, weight, ls_io, ls_mu_io, model_energy, accepted, switches, log);
+}
+
+static void sweep_impl(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0,
+                       int nlat, int n, double *xyz, const double *h,
+                       const double *ivect, int ivstride, int maxneigh,
+                       const int *nn, const int *jn, const int *vn,
+                       double beta, double max_trans, const mwo_eta *eta, const mwo_cycle_opts *opt,
+                       double *histogram, double *unbiased_hist, double *weight,
+                       int *ls_io, double *ls_mu_io, double *model_energy,
+                       long long *accepted, long long *switches, double *log)
 {
     const double invPi = 1.0 / 3.141592653589793238462643383279502884197;     /* constants.f90:23 */
     double recip[2][9];
@@ -420,8 +510,8 @@ void mwo_sweep_translation(int nmoves, uint64_t seed, uint32_t walker, uint64_t 
     long long acc = 0;
 #define LAT(l, arr, stride) ((arr) + (size_t)(l) * (stride))
     for (int mv = 0; mv < nmoves; ++mv) {
-        double u[6];
-        mwo_move_uniforms(seed, walker, move0 + (uint64_t)mv, u);
+        double u[8];
+        mwo_move_uniforms8(seed, walker, move0 + (uint64_t)mv, u);            /* u[0..5] as mwo_move_uniforms */
         const int lsn = nlat == 2 ? 3 - ls : 1;                               /* partner_lattice, :866-868 */
         int imol = (int)(u[0] * (double)n) + 1;                               /* :1001-1002 */
         if (imol > n) imol = n;
@@ -480,9 +570,17 @@ void mwo_sweep_translation(int nmoves, uint64_t seed, uint32_t walker, uint64_t 
             }
             if (nlat == 2) ls_mu = ls_mu - (deltaE[0] - deltaE[1]) * beta;
         }
+        int sw = 0;
+        if (opt && nlat == 2) {
+            update_wl_bins(eta, opt, ls_mu, histogram, unbiased_hist, weight);                 /* mc_moves.F90:230 */
+            if (opt->always_switch) {                                                          /* :243-248 */
+                sw = lattice_switch(eta, opt, beta, n, u[6], model_energy, &ls, &ls_mu);
+                if (sw && switches) ++*switches;
+            }
+        }
         if (log) {
             double *q = log + 8 * (size_t)mv;
-            q[0] = imol; q[1] = ok; q[2] = old_e[0]; q[3] = new_e[0]; q[4] = old_e[1]; q[5] = new_e[1]; q[6] = ls_mu; q[7] = diffkT;
+            q[0] = imol; q[1] = ok + 2 * sw; q[2] = old_e[0]; q[3] = new_e[0]; q[4] = old_e[1]; q[5] = new_e[1]; q[6] = ls_mu; q[7] = diffkT;
         }
     }
 #undef LAT

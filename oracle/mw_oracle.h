@@ -114,3 +114,36 @@ void mwo_sweep_translation(int nmoves, uint64_t seed, uint32_t walker, uint64_t 
 }
 #endif
 #endif
+
+/* ---- the rest of a translation-only mc_cycle: histogram / weight update and lattice switch -------- */
+#ifndef MW_ORACLE_CYCLE_H
+#define MW_ORACLE_CYCLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct {
+    int record;                 /* mc_cycle_num >= eq_mc_cycles: mc_update_wl_bins is active (mc_moves.F90:1614) */
+    int samplerun;              /* fixed weights: accumulate the unbiased histogram instead of updating weights */
+    int always_switch;          /* mc_always_switch: a lattice-switch attempt after every move (mc_moves.F90:243-248) */
+    int npt;                    /* mc_ensemble == 'npt' in mc_lattice_switch (mc_moves.F90:1560-1571) */
+    double av_binwidth, wl_factor, log_unbiased_norm, pressure;
+    double volume[2];
+} mwo_cycle_opts;
+
+/* Like mwo_sweep_translation, plus after every move mc_update_wl_bins (mc_moves.F90:1597-1689, default
+ * schedule: no Swetnam / 1-over-t variants) on this walker's histogram / unbiased_hist / weight arrays
+ * (nbins each; `eta->weight` must point at the same `weight` array) and, with always_switch, one
+ * mc_lattice_switch attempt (mc_moves.F90:1536-1594).  Uniforms per move: mwo_move_uniforms8. */
+void mwo_move_uniforms8(uint64_t seed, uint32_t walker, uint64_t move, double u[8]);
+void mwo_sweep_cycle(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0,
+                     int nlat, int n, double *xyz, const double *h,
+                     const double *ivect, int ivstride, int maxneigh,
+                     const int *nn, const int *jn, const int *vn,
+                     double beta, double max_trans, const mwo_eta *eta, const mwo_cycle_opts *opt,
+                     double *histogram, double *unbiased_hist, double *weight,
+                     int *ls, double *ls_mu, double *model_energy,
+                     long long *accepted, long long *switches, double *log);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -162,3 +162,83 @@ def test_1536_pair_sweep_with_list_refresh(so, c_oracle):
         _compare(np.concatenate([log_a, log_b]), rb, farm.state(1), [farm.positions(1), farm.positions(2)])
     finally:
         em.energy_deinit()
+
+
+def _cycle_case(so, samplerun, wl_factor, weight_fn, seed):
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.sweep import MuGrid
+    z1, z2 = load_golden("ic48"), load_golden("ih48")
+    grid = MuGrid(101, -400.0, 400.0)
+    weight = weight_fn(grid)
+    boxes = []
+    for w in range(5):
+        boxes += [(z1["h"], lat.thermalise(z1["xyz"], 0.06, 160 + w)), (z2["h"], lat.thermalise(z2["xyz"], 0.06, 180 + w))]
+    em, farm = _farm(boxes, 2, 200.0, 1.1, grid=grid, weight=weight)
+    try:
+        farm.options(record=True, samplerun=samplerun, always_switch=True, npt=False, wl_factor=wl_factor)
+        mus = [farm.initial_mu(w) for w in range(1, 6)]
+        for w in range(1, 6):
+            farm.set_state(w, 1, mus[w - 1])
+        log = farm.sweep(200, seed=seed, move0=0, log=True)
+        nsw = 0
+        for w in range(5):
+            ref = so.cycle(200, seed, w, 0, [z1["h"], z2["h"]], [boxes[2 * w][1], boxes[2 * w + 1][1]], farm.beta,
+                           farm.max_trans, grid, weight, np.zeros(101), np.zeros(101), ls=1, ls_mu=mus[w],
+                           model_energy=[em.model_energy[2 * w], em.model_energy[2 * w + 1]], record=True,
+                           samplerun=samplerun, always_switch=True, wl_factor=wl_factor)
+            _compare(log[w], ref, farm.state(w + 1), [farm.positions(2 * w + 1), farm.positions(2 * w + 2)])
+            wt, hi, uh = farm.tables(w + 1)
+            assert np.allclose(hi, ref["histogram"], rtol=1e-13, atol=1e-13) and hi.sum() > 0
+            assert np.allclose(wt, ref["weight"], rtol=1e-11, atol=1e-12)
+            assert np.allclose(uh, ref["unbiased_hist"], rtol=1e-9, atol=1e-300)
+            assert farm.switches(w + 1) == ref["switches"]
+            nsw += ref["switches"]
+        return nsw
+    finally:
+        em.energy_deinit()
+
+
+@pytest.mark.gpu
+def test_wang_landau_cycle_on_device_follows_the_oracle(so):
+    """Weight generation: every walker grows its own weights (Wang-Landau), attempts a switch after every move."""
+    _cycle_case(so, samplerun=False, wl_factor=float(np.float32(0.05)), weight_fn=lambda g: np.zeros(g.nbins), seed=31)
+
+
+@pytest.mark.gpu
+def test_sampling_cycle_with_switches_on_device_follows_the_oracle(so):
+    nsw = _cycle_case(so, samplerun=True, wl_factor=0.0, weight_fn=lambda g: 0.03 * np.abs(g.mu_bin), seed=32)
+    assert nsw >= 0
+
+
+@pytest.mark.gpu
+def test_farm_synchronise_sums_the_walkers_increments(so):
+    """The mpi_sync_int step for a farm: all walkers end with last + the sum of every walker's increment."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.comms import WalkerComms
+    from mc_water_ls_mw_amd.sweep import MuGrid
+    z1, z2 = load_golden("ic48"), load_golden("ih48")
+    grid = MuGrid(101, -400.0, 400.0)
+    boxes = []
+    for w in range(3):
+        boxes += [(z1["h"], lat.thermalise(z1["xyz"], 0.05, 260 + w)), (z2["h"], lat.thermalise(z2["xyz"], 0.05, 280 + w))]
+    em, farm = _farm(boxes, 2, 200.0, 1.1, grid=grid, weight=np.zeros(101))
+    try:
+        farm.options(record=True, samplerun=False, always_switch=True, wl_factor=0.05)
+        for w in range(1, 4):
+            farm.set_state(w, 1, farm.initial_mu(w))
+        comms = WalkerComms(101)
+        farm.sweep(96, seed=3)
+        before = [farm.tables(w) for w in range(1, 4)]
+        wt, hi, uh = farm.synchronise(comms)
+        assert np.allclose(hi, sum(b[1] for b in before)) and np.allclose(wt, sum(b[0] for b in before))
+        assert hi.sum() > 0 and wt.max() > 0
+        for w in range(1, 4):
+            t = farm.tables(w)
+            assert np.array_equal(t[0], wt) and np.array_equal(t[1], hi)
+        farm.sweep(48, seed=3, move0=96)
+        mid = [farm.tables(w) for w in range(1, 4)]
+        wt2, hi2, _ = farm.synchronise(comms)
+        assert np.allclose(hi2, hi + sum(m[1] - hi for m in mid))
+        assert np.allclose(wt2, wt + sum(m[0] - wt for m in mid))
+    finally:
+        em.energy_deinit()

@@ -25,7 +25,7 @@ AUP_TO_ATM = 2.90363081e8
 pytestmark = pytest.mark.skipif(not os.path.exists(RNG), reason="oracle/_ref/mc_water_ref_rng not built")
 
 
-def namelist(num_lattices, temperature, cycles, samplerun):
+def namelist(num_lattices, temperature, cycles, samplerun, always_switch=False):
     return f"""&potential
 model_type = "mW"
 /
@@ -40,7 +40,7 @@ mc_dv_max        = 0.924
 nbins            = 101
 mu_max           = +400
 mu_min           = -400
-mc_always_switch = .false.
+mc_always_switch = .{'true' if always_switch else 'false'}.
 allow_switch     = .false.
 allow_vol        = .false.
 eta_interp       = .true.
@@ -76,21 +76,25 @@ def read_records(path):
     return recs
 
 
-def run_reference(d, num_lattices, temperature, cycles, weight=None, grid=None):
+def run_reference(d, num_lattices, temperature, cycles, weight=None, grid=None, samplerun=None, always_switch=False,
+                  tables=False):
     from mc_water_ls_mw_amd import lattice as lat
     os.makedirs(d)
-    open(os.path.join(d, "ice.input"), "w").write(namelist(num_lattices, temperature, cycles, weight is not None))
+    samplerun = (weight is not None) if samplerun is None else samplerun
+    open(os.path.join(d, "ice.input"), "w").write(namelist(num_lattices, temperature, cycles, samplerun, always_switch))
     z1 = load_golden("ic48_t015")
     h1, x1 = lat.read_xmol(_write(d, "input001.xmol", z1))
     boxes = [(h1, x1)]
     if num_lattices == 2:
         z2 = load_golden("ih48_t020")
         boxes.append(lat.read_xmol(_write(d, "input002.xmol", z2)))
+    if weight is not None:
         with open(os.path.join(d, "eta_weights.dat"), "w") as fh:       # format of mc_moves.F90:738-770
             fh.write("#Current energy increment =   0.500000007451E-01\n")
             for mu, w in zip(grid.mu_bin, weight):
                 fh.write(f"  {float(mu)!r}        {float(w)!r}\n")
-    out = subprocess.run([RNG, "ice.input"], cwd=d, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, MW_WRAP_CALLS_PER_MOVE="8" if always_switch else "7")
+    out = subprocess.run([RNG, "ice.input"], cwd=d, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, (out.stdout[-800:], out.stderr[-800:])
     therm = [f for f in os.listdir(d) if f.endswith("_therm.dat")][0]
     e_ev = np.array([float(ln.split()[1]) for ln in open(os.path.join(d, therm))])
@@ -99,6 +103,10 @@ def run_reference(d, num_lattices, temperature, cycles, weight=None, grid=None):
     ljr = np.frombuffer(recs[-2], dtype="<f8").reshape(num_lattices, 48, 3)      # ljr(3,1,N,L), column-major
     ls = struct.unpack("<i", recs[-1])[0]
     assert struct.unpack("<i", recs[1])[0] == cycles
+    if tables:      # records: nwater, cycle, (max_trans, dv_max), wl_factor, histogram, weight, wl_invt_active, [uhist], ...
+        hist = np.frombuffer(recs[4], dtype="<f8").copy()
+        wgt = np.frombuffer(recs[5], dtype="<f8").copy()
+        return boxes, e_ev, np.array(ljr), ls, hist, wgt
     return boxes, e_ev, np.array(ljr), ls
 
 
@@ -161,3 +169,61 @@ def test_two_lattice_moves_and_weights_match_the_reference_program(tmp_path, so,
     assert np.abs(xs - ljr).max() < 1e-10
     assert np.allclose(e_or, e_ref, rtol=2e-6, atol=2e-6)
     assert np.abs(ljr[1] - boxes[1][1]).max() > 0.5
+
+
+def replay_cycle(so, c_oracle, boxes, temperature, cycles, grid, weight, samplerun, wl_factor):
+    """mc_cycle with translations, mc_update_wl_bins and a lattice-switch attempt after every move."""
+    from mc_water_ls_mw_amd.lattice import ANG_TO_BOHR
+    from mc_water_ls_mw_amd.sweep import KB
+    beta = 1.0 / (KB * temperature)
+    hs = [b[0] for b in boxes]
+    xs = [np.array(b[1]) for b in boxes]
+    ivs = [c_oracle.ivects(h) for h in hs]
+    lists = [c_oracle.neighbours(xs[l], ivs[l]) for l in range(2)]
+    me = [c_oracle.model_energy(xs[l], ivs[l], *lists[l]) for l in range(2)]
+    p = 1.0 / AUP_TO_ATM
+    v = [abs(np.linalg.det(h)) for h in hs]
+    mu = me[0] + p * v[0] - me[1] - p * v[1]
+    mu = mu * beta - 48.0 * np.log(v[0] / v[1])
+    ls, w, hi, uh = 1, np.array(weight, dtype=float), np.zeros(grid.nbins), np.zeros(grid.nbins)
+    energies, nsw = [], 0
+    for cyc in range(1, cycles + 1):
+        if cyc % 10 == 0:
+            lists = [c_oracle.neighbours(xs[l], ivs[l]) for l in range(2)]
+        r = so.cycle(48, SEED, 0, (cyc - 1) * 48, hs, xs, beta, 1.1 * ANG_TO_BOHR, grid, w, hi, uh, ls=ls, ls_mu=mu,
+                     model_energy=me, lists=lists, record=True, samplerun=samplerun, always_switch=True, npt=False,
+                     wl_factor=wl_factor, pressure=p)
+        xs = [r["xyz"][0], r["xyz"][1]]
+        me, ls, mu, w, hi, uh = list(r["model_energy"]), r["ls"], r["ls_mu"], r["weight"], r["histogram"], r["unbiased_hist"]
+        nsw += r["switches"]
+        energies.append(me[ls - 1] * HART_TO_EV)
+    return np.array(xs), np.array(energies), ls, w, hi, nsw
+
+
+def test_wang_landau_weight_generation_matches_the_reference_program(tmp_path, so, c_oracle):
+    """examples/ice1_gen_weights in miniature: no weights file, Wang-Landau updates of the visited bin after
+    every move (wl_factor = 0.05 as a single-precision literal, userparams.f90:32), lattice-switch attempt after
+    every move.  The reference's checkpoint holds histogram and weights: both must be reproduced."""
+    from mc_water_ls_mw_amd.sweep import MuGrid
+    grid = MuGrid(101, -400.0, 400.0)
+    boxes, e_ref, ljr, ls, hist, wgt = run_reference(str(tmp_path / "run"), 2, 200, 40, samplerun=False,
+                                                     always_switch=True, tables=True)
+    xs, e_or, ls_or, w, hi, nsw = replay_cycle(so, c_oracle, boxes, 200.0, 40, grid, np.zeros(101), False,
+                                               float(np.float32(0.05)))
+    assert np.abs(xs - ljr).max() < 1e-10 and ls == ls_or
+    assert np.allclose(e_or, e_ref, rtol=2e-6, atol=2e-6)
+    assert hist.sum() > 0 and np.allclose(hi, hist, rtol=1e-12, atol=1e-12)
+    assert wgt.max() > 0 and np.allclose(w, wgt, rtol=1e-11, atol=1e-12)
+
+
+def test_sampling_run_with_switches_matches_the_reference_program(tmp_path, so, c_oracle):
+    """examples/ice1_sample in miniature: fixed weights, histogram accumulation, switch attempt after every move."""
+    from mc_water_ls_mw_amd.sweep import MuGrid
+    grid = MuGrid(101, -400.0, 400.0)
+    weight = 0.02 * np.abs(grid.mu_bin)          # pulls mu towards 0, where lattice switches are accepted
+    boxes, e_ref, ljr, ls, hist, wgt = run_reference(str(tmp_path / "run"), 2, 200, 40, weight=weight, grid=grid,
+                                                     samplerun=True, always_switch=True, tables=True)
+    xs, e_or, ls_or, w, hi, nsw = replay_cycle(so, c_oracle, boxes, 200.0, 40, grid, weight, True, 0.0)
+    assert np.abs(xs - ljr).max() < 1e-10 and ls == ls_or
+    assert np.allclose(e_or, e_ref, rtol=2e-6, atol=2e-6)
+    assert np.allclose(hi, hist, rtol=1e-12, atol=1e-12) and np.allclose(w, wgt, rtol=1e-13)
