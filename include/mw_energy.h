@@ -161,6 +161,10 @@ int mw_sweep_options(int record, int samplerun, int always_switch, int npt,
                      double av_binwidth, double wl_factor, double log_unbiased_norm, double pressure);
 int mw_sweep_get_tables(int walker, double *weight, double *histogram, double *unbiased_hist);
 int mw_sweep_set_tables(int walker, const double *weight, const double *histogram, const double *unbiased_hist);
+/* The same for `count` consecutive walkers in one transfer: arrays of count x nbins doubles. */
+int mw_sweep_get_tables_range(int first_walker, int count, double *weight, double *histogram, double *unbiased_hist);
+int mw_sweep_set_tables_range(int first_walker, int count, const double *weight, const double *histogram,
+                              const double *unbiased_hist);
 int mw_sweep_get_switches(int walker, long long *switches);
 int mw_set_model_energy(int ils, double e);
 int mw_sweep_set_state(int walker, int ls, double ls_mu);

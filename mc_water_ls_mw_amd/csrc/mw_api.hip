@@ -897,6 +897,28 @@ int mw_sweep_set_tables(int walker, const double* weight, const double* histogra
     return tables_io(walker, const_cast<double*>(weight), const_cast<double*>(histogram), const_cast<double*>(unbiased_hist), true);
 }
 
+int mw_sweep_get_tables_range(int first_walker, int count, double* weight, double* histogram, double* unbiased_hist)
+{
+    if (check_live() || check_walker(first_walker, count)) return 1;
+    const size_t nb = (size_t)g.sp.nbins, off = (size_t)(first_walker - 1) * nb, bytes = (size_t)count * nb * sizeof(double);
+    if (weight) HIPCHK(hipMemcpyAsync(weight, g.d_wweight + off, bytes, hipMemcpyDeviceToHost, g.stream));
+    if (histogram) HIPCHK(hipMemcpyAsync(histogram, g.d_whist + off, bytes, hipMemcpyDeviceToHost, g.stream));
+    if (unbiased_hist) HIPCHK(hipMemcpyAsync(unbiased_hist, g.d_wuhist + off, bytes, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int mw_sweep_set_tables_range(int first_walker, int count, const double* weight, const double* histogram, const double* unbiased_hist)
+{
+    if (check_live() || check_walker(first_walker, count)) return 1;
+    const size_t nb = (size_t)g.sp.nbins, off = (size_t)(first_walker - 1) * nb, bytes = (size_t)count * nb * sizeof(double);
+    if (weight) HIPCHK(hipMemcpyAsync(g.d_wweight + off, weight, bytes, hipMemcpyHostToDevice, g.stream));
+    if (histogram) HIPCHK(hipMemcpyAsync(g.d_whist + off, histogram, bytes, hipMemcpyHostToDevice, g.stream));
+    if (unbiased_hist) HIPCHK(hipMemcpyAsync(g.d_wuhist + off, unbiased_hist, bytes, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
 int mw_sweep_get_switches(int walker, long long* switches)
 {
     if (check_live() || check_walker(walker, 1)) return 1;

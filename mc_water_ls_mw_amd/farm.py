@@ -1,0 +1,121 @@
+"""Replica farm: many multicanonical walkers per GPU, one process per GPU, periodic delta all-reduce of the
+weight / histogram tables -- BASELINE.json configs[3] (examples/ice1_gen_weights) on the device-resident driver.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        -m mc_water_ls_mw_amd.farm --walkers 1024 --cycles 500
+
+Per cycle, as mc_cycle does (mc_moves.F90:117-321) with volume moves off: rebuild the Verlet lists every
+``list_update_int`` cycles, ``nwater`` translation moves per walker (each followed by mc_update_wl_bins and a
+lattice-switch attempt), and every ``mpi_sync_int`` cycles the synchronisation of weights and histograms over all
+walkers of all GPUs (comms_allreduce_eta/hist, comms_mpi.f90:244-277,461-494).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+
+
+def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=400.0, wl_factor=0.05,
+        list_update_int=10, mpi_sync_int=250, sigma_ang=0.05, seed=2025, device=0, comms=None, rank=0,
+        samplerun=False, weight=None):
+    """Run `cycles` MC cycles of `walkers` two-lattice walkers on this GPU.  Returns a dict of results."""
+    from . import lattice as lat
+    from .energy import EnergyModule
+    from .sweep import MuGrid, WalkerFarm
+
+    n = len(x_pair[0])
+    em = EnergyModule(n, 2 * walkers, device=device)
+    for w in range(walkers):
+        for l in range(2):
+            em.hmatrix[2 * w + l] = h_pair[l]
+            em.ljr[2 * w + l] = lat.thermalise(x_pair[l], sigma_ang, 7919 * (rank * walkers + w) + l)
+    em._chk(em.L.mw_init(device, n, 2 * walkers, em.maxneigh))
+    em._live = True
+    try:
+        for b in range(1, 2 * walkers + 1):
+            em.volume[b - 1] = abs(np.linalg.det(em.hmatrix[b - 1]))
+            em.compute_ivects(b)
+            em._upload(b)
+        em.build_neighbours_batch(1, 2 * walkers)
+        em.model_energy_batch(1, 2 * walkers)
+        grid = MuGrid(nbins, -mu_range, mu_range)
+        farm = WalkerFarm(em, 2, temperature, 1.1, grid=grid, weight=weight)
+        farm.options(record=True, samplerun=samplerun, always_switch=True, npt=False, wl_factor=wl_factor)
+        for w in range(1, walkers + 1):
+            farm.set_state(w, 1, farm.initial_mu(w))
+        t0 = time.perf_counter()
+        synced = None
+        for cyc in range(1, cycles + 1):
+            if cyc % list_update_int == 0:                         # mc_moves.F90:217-222
+                em.build_neighbours_batch(1, 2 * walkers)      # checked: fails loudly on list overflow
+            farm.sweep_launch(n, seed=seed + rank, move0=(cyc - 1) * n)
+            if comms is not None and cyc % mpi_sync_int == 0:      # mc_moves.F90:258-276
+                em.sync()
+                synced = farm.synchronise(comms)
+        em.sync()
+        wall = time.perf_counter() - t0
+        states = [farm.state(w) for w in range(1, min(walkers, 32) + 1)]
+        fresh = em.model_energy_batch(1, 2)
+        out = dict(walkers=walkers, cycles=cycles, molecules=n, moves=walkers * cycles * n, wall_s=wall,
+                   moves_per_s=walkers * cycles * n / wall,
+                   acceptance=float(np.mean([s["accepted"] for s in states])) / (cycles * n),
+                   switches_per_walker=float(np.mean([farm.switches(w) for w in range(1, min(walkers, 32) + 1)])),
+                   drift_walker1_Ha=[states[0]["model_energy"][l] - fresh[l] for l in range(2)],
+                   histogram_total=None if synced is None else float(synced[1].sum()),
+                   weight_max=None if synced is None else float(synced[0].max()))
+        out["tables"] = synced
+        return out
+    finally:
+        em.energy_deinit()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--walkers", type=int, default=512)
+    ap.add_argument("--cycles", type=int, default=100)
+    ap.add_argument("--sync", type=int, default=25)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--share-device", action="store_true")
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    from .comms import WalkerComms
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    z1, z2 = np.load(os.path.join(gold, "ic48.npz")), np.load(os.path.join(gold, "ih48.npz"))
+    comms = WalkerComms(101, device=torch.device("cuda", local) if (world > 1 and args.backend == "nccl") else None)
+    res = run([z1["h"], z2["h"]], [z1["xyz"], z2["xyz"]], args.walkers, args.cycles, mpi_sync_int=args.sync,
+              device=local, comms=comms, rank=rank)
+    tabs = res.pop("tables")
+    if world > 1:
+        t = torch.tensor(np.concatenate(tabs[:2]), dtype=torch.float64,
+                         device=torch.device("cuda", local) if args.backend == "nccl" else "cpu")
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        res["ranks_agree"] = bool(torch.equal(lo, hi))
+        agg = torch.tensor([res["moves_per_s"]], dtype=torch.float64, device=t.device)
+        dist.all_reduce(agg)
+        res["moves_per_s_all_ranks"] = float(agg.item())
+    if rank == 0:
+        res["world"] = world
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -121,14 +121,15 @@ class WalkerFarm:
         """The mpi_sync_int block of mc_cycle (mc_moves.F90:258-276) for a farm: every walker is a 'rank' of the
         reference; the increments of all walkers of this GPU are summed on the host, then over the GPUs by
         ``comms`` (WalkerComms, one all-reduce), and every walker receives the synchronised tables."""
-        nb = self.grid.nbins
-        tabs = [self.tables(w) for w in range(1, self.nwalkers + 1)]
+        nb, nw = self.grid.nbins, self.nwalkers
+        tabs = [np.zeros((nw, nb)) for _ in range(3)]
+        self.em._chk(self.L.mw_sweep_get_tables_range(1, nw, *[t.ctypes.data_as(_dp) for t in tabs]))
         last = (comms.eta_last_sync, comms.hist_last_sync, comms.uhist_last_sync)
         # a rank's contribution = sum over its walkers of (table - last): hand WalkerComms `last + that sum`
-        summed = [last[t] + sum(tab[t] - last[t] for tab in tabs) for t in range(3)]
+        summed = [last[t] + (tabs[t] - last[t][None, :]).sum(axis=0) for t in range(3)]
         comms.sync(summed[0], summed[1], summed[2])
-        for w in range(1, self.nwalkers + 1):
-            self.set_tables(w, summed[0], summed[1], summed[2])
+        rep = [np.ascontiguousarray(np.broadcast_to(summed[t], (nw, nb))) for t in range(3)]
+        self.em._chk(self.L.mw_sweep_set_tables_range(1, nw, *[r.ctypes.data_as(_dp) for r in rep]))
         return summed
 
     def initial_mu(self, walker):

@@ -242,3 +242,49 @@ def test_farm_synchronise_sums_the_walkers_increments(so):
         assert np.allclose(wt2, wt + sum(m[0] - wt for m in mid))
     finally:
         em.energy_deinit()
+
+
+@pytest.mark.gpu
+def test_weight_generation_farm_runs_and_keeps_its_books():
+    """configs[3] in miniature on one GPU: 64 Ic/Ih walkers, 30 cycles, lists every 10, sync every 10."""
+    from mc_water_ls_mw_amd.comms import WalkerComms
+    from mc_water_ls_mw_amd.farm import run
+    z1, z2 = load_golden("ic48"), load_golden("ih48")
+    res = run([z1["h"], z2["h"]], [z1["xyz"], z2["xyz"]], walkers=64, cycles=30, mpi_sync_int=10, comms=WalkerComms(101))
+    assert 0.02 < res["acceptance"] < 0.9
+    assert max(abs(d) for d in res["drift_walker1_Ha"]) < 1e-9          # the reference's own consistency check
+    wt, hi, _ = res["tables"]
+    assert hi.sum() > 0 and wt.max() > 0 and np.all(wt >= 0.0)
+
+
+@pytest.mark.gpu
+def test_farm_loop_equals_oracle_replay_including_stale_list_drift(so, c_oracle):
+    """Without synchronisation a farm walker is an isolated chain: 60 cycles of farm.run (lists rebuilt every 10
+    cycles on the device) against the oracle replaying the same cycles.  With 1.1 A moves molecules outrun the
+    Verlet skin between rebuilds, so the accumulated energy drifts away from a fresh full-box energy -- in the
+    reference's algorithm itself; device and oracle must show the same drift."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.farm import run
+    from mc_water_ls_mw_amd.sweep import KB, MuGrid
+    z1, z2 = load_golden("ic48"), load_golden("ih48")
+    hs, cycles, seed = [z1["h"], z2["h"]], 60, 2025
+    res = run(hs, [z1["xyz"], z2["xyz"]], walkers=4, cycles=cycles, comms=None, seed=seed, wl_factor=0.05)
+    grid = MuGrid(101, -400.0, 400.0)
+    beta = 1.0 / (KB * 200.0)
+    xs = [lat.thermalise(z1["xyz"], 0.05, 0), lat.thermalise(z2["xyz"], 0.05, 1)]     # farm.run: walker 0 of rank 0
+    ivs = [c_oracle.ivects(h) for h in hs]
+    lists = [c_oracle.neighbours(xs[l], ivs[l]) for l in range(2)]
+    me = [c_oracle.model_energy(xs[l], ivs[l], *lists[l]) for l in range(2)]
+    v = [abs(np.linalg.det(h)) for h in hs]
+    mu = (me[0] - me[1]) * beta - 48.0 * np.log(v[0] / v[1])
+    ls, w, hi, uh = 1, np.zeros(101), np.zeros(101), np.zeros(101)
+    for cyc in range(1, cycles + 1):
+        if cyc % 10 == 0:
+            lists = [c_oracle.neighbours(xs[l], ivs[l]) for l in range(2)]
+        r = so.cycle(48, seed, 0, (cyc - 1) * 48, hs, xs, beta, 1.1 * lat.ANG_TO_BOHR, grid, w, hi, uh, ls=ls, ls_mu=mu,
+                     model_energy=me, lists=lists, record=True, samplerun=False, always_switch=True, wl_factor=0.05)
+        xs, me, ls, mu, w, hi, uh = [r["xyz"][0], r["xyz"][1]], list(r["model_energy"]), r["ls"], r["ls_mu"], r["weight"], r["histogram"], r["unbiased_hist"]
+    fresh = [c_oracle.model_energy(xs[l], ivs[l], *lists[l]) for l in range(2)]
+    drift_oracle = [me[l] - fresh[l] for l in range(2)]
+    for l in range(2):
+        assert abs(res["drift_walker1_Ha"][l] - drift_oracle[l]) < 1e-9
