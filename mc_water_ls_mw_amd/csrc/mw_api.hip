@@ -945,8 +945,25 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
         }
         dlog = g.d_swlog;
     }
-    const size_t shmem = (size_t)g.sp.nlat * g.ivcap * 3 * sizeof(double);
-    hipLaunchKernelGGL(mw::k_sweep_translation, dim3(count), dim3(64), shmem, g.stream, g.d_pos, g.d_hmat, g.d_ivect, g.d_nivect,
+    const size_t iv_bytes = (size_t)g.sp.nlat * g.ivcap * 3 * sizeof(double);
+    const size_t pos_bytes = (size_t)g.sp.nlat * g.N * 3 * sizeof(double);
+    const bool ldspos = pos_bytes <= 16 * 1024;        // small systems: the walker's positions stay in LDS (8 walkers per CU)
+    // the reference's own system sizes: list rows (<= 32 entries) and row lengths in LDS as well
+    bool ldslist = false;
+    const size_t list_bytes = (size_t)g.sp.nlat * g.N * (32 * sizeof(uint32_t) + sizeof(int));
+    if (ldspos && iv_bytes + pos_bytes + list_bytes <= 17 * 1024) {
+        std::vector<int> st((size_t)count * g.sp.nlat * 2);
+        HIPCHK(hipMemcpyAsync(st.data(), g.d_stats + 2 * (size_t)(first_walker - 1) * g.sp.nlat, st.size() * sizeof(int),
+                              hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        int mx = 0;
+        for (size_t b = 0; b < st.size() / 2; ++b) mx = std::max(mx, st[2 * b + 1]);
+        ldslist = mx <= 32;                          // stats = {min nn, max nn} of the last list build of each box
+    }
+    const size_t shmem = iv_bytes + (ldspos ? pos_bytes : 0) + (ldslist ? list_bytes : 0);
+    auto kern = ldslist ? mw::k_sweep_translation<true, true>
+                        : (ldspos ? mw::k_sweep_translation<true, false> : mw::k_sweep_translation<false, false>);
+    hipLaunchKernelGGL(kern, dim3(count), dim3(64), shmem, g.stream, g.d_pos, g.d_hmat, g.d_ivect, g.d_nivect,
                        g.d_listm, g.d_nn, g.d_energy, g.d_wls, g.d_wmu, g.d_wacc, g.d_wswitch, g.sp, g.d_wweight, g.d_whist, g.d_wuhist,
                        g.d_sw_mubin, g.d_sw_binwidth, g.d_volume, g.N, g.ivcap, nmoves, seed, move0, first_walker - 1, dlog);
     HIPCHK(hipGetLastError());

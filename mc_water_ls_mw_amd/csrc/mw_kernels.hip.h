@@ -737,22 +737,23 @@ struct WaveScratch {
 static_assert(sizeof(WaveScratch) % 8 == 0, "scratch records must keep 8-byte alignment");
 
 // Returns false (nothing written) when the request needs the plain routine.
-template <typename PosFn, typename IvFn>
-__device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv,
-                                                 const uint32_t* __restrict__ LM, const int* __restrict__ NN,
+// `row(j, s)` returns list entry s of molecule j and `nnof(j)` its row length: global memory (molecule-major
+// list) or, for small systems in the sweep driver, LDS copies.
+template <typename PosFn, typename IvFn, typename RowFn, typename NnFn>
+__device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn row, NnFn nnof,
                                                  WaveScratch* __restrict__ ws,
                                                  int i, double xo, double yo, double zo,
                                                  double xn, double yn, double zn, int lane, MoveRes& res)
 {
     // ---- pass 0: imol's own row, one slot per lane ----------------------------------------
-    const int n_i = NN[i];
+    const int n_i = nnof(i);
     const bool has = lane < n_i;
-    const uint32_t e = has ? LM[(size_t)i * kRow + lane] : 0u;
+    const uint32_t e = has ? row(i, lane) : 0u;
     const int j = (int)(e & kJMask), kimg = (int)(e >> kJBits);
     double xj, yj, zj, jvx, jvy, jvz;
     getpos(j, xj, yj, zj);
     getiv(kimg, jvx, jvy, jvz);
-    const int nnj = has ? NN[j] : 0;
+    const int nnj = has ? nnof(j) : 0;
     const double qx = xj + jvx, qy = yj + jvy, qz = zj + jvz;                 // molint.F90:269
     const double aox = qx - xo, aoy = qy - yo, aoz = qz - zo;                 // :272 (old position)
     const double anx = qx - xn, any_ = qy - yn, anz = qz - zn;                //      (trial position)
@@ -873,7 +874,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv,
             if (cand < cntU && ws->start[cand < kCap ? cand : kCap - 1] <= t) own = cand;
         }
         const int jj = ws->j[own], kj = ws->kimg[own];
-        const uint32_t e2 = valid ? LM[(size_t)jj * kRow + (t - ws->start[own])] : 0u;
+        const uint32_t e2 = valid ? row(jj, t - ws->start[own]) : 0u;
         const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
         double xk, yk, zk, kvx, kvy, kvz, sjx, sjy, sjz;
         getpos(kk, xk, yk, zk);
@@ -987,7 +988,9 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
         const bool ownimage = __ballot((int)(e & kJMask) == i && lane < n_i) != 0ull;
 
         MoveRes r;
-        const bool fast = !ownimage && move_energy_wave(getpos, getiv, LM, NN, ws, i, xo, yo, zo, xn, yn, zn, lane, r);
+        auto row = [&](int jx, int sl) { return LM[(size_t)jx * kRow + sl]; };
+        auto nnof = [&](int jx) { return NN[jx]; };
+        const bool fast = !ownimage && move_energy_wave(getpos, getiv, row, nnof, ws, i, xo, yo, zo, xn, yn, zn, lane, r);
         if (!fast) {
             Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
             Override tr; tr.idx = i; tr.x = xn; tr.y = yn; tr.z = zn;
@@ -1086,6 +1089,7 @@ __device__ __forceinline__ void dev_recipmatrix(const double* __restrict__ h, do
 // Per-walker tables (two lattices only): weight / histogram / unbiased_hist [walker][nbins]; every walker
 // reads its OWN weights in eta_weight, so Wang-Landau updates stay local until the host synchronises them
 // (comms_allreduce_eta/hist/uhist semantics, WalkerComms).
+template <bool LDSPOS, bool LDSLIST>
 __global__ __launch_bounds__(64)
 void k_sweep_translation(double* pos, const double* __restrict__ hmat, const double* __restrict__ ivect,
                          const int* __restrict__ nivect, const uint32_t* __restrict__ listm,
@@ -1106,11 +1110,28 @@ void k_sweep_translation(double* pos, const double* __restrict__ hmat, const dou
     const int box0 = wlk * L;
     const double invPi = 1.0 / 3.141592653589793238462643383279502884197;
 
-    // image vectors of the walker's lattices in LDS: siv[l][ivcap][3]
+    // image vectors of the walker's lattices in LDS: siv[l][ivcap][3]; with LDSPOS (small systems) the walker's
+    // positions live there too for the whole launch -- spos[l][N][3] -- and every gather is an LDS read
     double* siv = smem;
+    double* spos = smem + (size_t)L * ivcap * 3;
     for (int l = 0; l < L; ++l) {
         const int niv = nivect[box0 + l];
         for (int t = lane; t < niv * 3; t += 64) siv[(size_t)l * ivcap * 3 + t] = ivect[(size_t)(box0 + l) * ivcap * 3 + t];
+        if (LDSPOS) {
+            const double* Pg = pos + (size_t)(box0 + l) * N * 3;
+            for (int t = lane; t < 3 * N; t += 64) spos[(size_t)l * N * 3 + t] = Pg[t];
+        }
+    }
+    // LDSLIST (the reference's own system sizes, ~48 molecules): list rows (32 entries each) and row lengths too,
+    // so that nothing in the move loop waits on global memory.  Rows longer than 32 keep the global list.
+    uint32_t* srow = reinterpret_cast<uint32_t*>(spos + (LDSPOS ? (size_t)L * N * 3 : 0));
+    int* snn = reinterpret_cast<int*>(srow + (LDSLIST ? (size_t)L * N * 32 : 0));
+    if (LDSLIST) {
+        for (int l = 0; l < L; ++l) {
+            const uint32_t* LMg = listm + (size_t)(box0 + l) * N * kRow;
+            for (int t = lane; t < N * 32; t += 64) srow[(size_t)l * N * 32 + t] = LMg[(size_t)(t >> 5) * kRow + (t & 31)];
+            for (int t = lane; t < N; t += 64) snn[l * N + t] = nn[(size_t)(box0 + l) * N + t];
+        }
     }
     __shared__ double srecip[2][9];          // recip_matrix(:,:,ils) of the walker's lattices
     if (lane == 0) {
@@ -1179,15 +1200,20 @@ void k_sweep_translation(double* pos, const double* __restrict__ hmat, const dou
             const int* NN = nn + (size_t)(box0 + l) * N;
             const double* IVl = siv + (size_t)l * ivcap * 3;
             auto getiv = [&](int k, double& a, double& b, double& c) { a = IVl[3 * k]; b = IVl[3 * k + 1]; c = IVl[3 * k + 2]; };
-            auto getpos = [&](int j, double& a, double& b, double& c) { const double* p = P + 3 * (size_t)j; a = p[0]; b = p[1]; c = p[2]; };
+            const double* Pl = LDSPOS ? (spos + (size_t)l * N * 3) : P;
+            auto getpos = [&](int j, double& a, double& b, double& c) { const double* p = Pl + 3 * (size_t)j; a = p[0]; b = p[1]; c = p[2]; };
             double xo, yo, zo;
             getpos(i, xo, yo, zo);
             pn[l][0] = xo + tv[l][0]; pn[l][1] = yo + tv[l][1]; pn[l][2] = zo + tv[l][2];   // :1079
-            const int n_i = NN[i];
-            const uint32_t e = lane < n_i ? LM[(size_t)i * kRow + lane] : 0xffffffffu;
+            const uint32_t* SR = srow + (size_t)l * N * 32;
+            const int* SN = snn + l * N;
+            auto row = [&](int jx, int sl) { return LDSLIST ? SR[jx * 32 + sl] : LM[(size_t)jx * kRow + sl]; };
+            auto nnof = [&](int jx) { return LDSLIST ? SN[jx] : NN[jx]; };
+            const int n_i = nnof(i);
+            const uint32_t e = lane < n_i ? row(i, lane) : 0xffffffffu;
             const bool ownimage = __ballot((int)(e & kJMask) == i && lane < n_i) != 0ull;
             MoveRes res;
-            const bool fast = !ownimage && move_energy_wave(getpos, getiv, LM, NN, &ws, i, xo, yo, zo,
+            const bool fast = !ownimage && move_energy_wave(getpos, getiv, row, nnof, &ws, i, xo, yo, zo,
                                                             pn[l][0], pn[l][1], pn[l][2], lane, res);
             if (!fast) {
                 Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
@@ -1220,6 +1246,10 @@ void k_sweep_translation(double* pos, const double* __restrict__ hmat, const dou
                 for (int l = 0; l < 2; ++l) if (l < L) {
                     double* P = pos + ((size_t)(box0 + l) * N + i) * 3;
                     P[0] = pn[l][0]; P[1] = pn[l][1]; P[2] = pn[l][2];
+                    if (LDSPOS) {
+                        double* S = spos + ((size_t)l * N + i) * 3;
+                        S[0] = pn[l][0]; S[1] = pn[l][1]; S[2] = pn[l][2];
+                    }
                 }
             }
         } else {                                                                  // :1182-1195
