@@ -225,3 +225,58 @@ def test_neighbour_overflow_fails_loudly():
         load_boxes([z["h"]], [z["xyz"]], maxneigh=20)
     from mc_water_ls_mw_amd.energy import load_library
     load_library().mw_finalize()
+
+
+def test_full_size_properties_4096(c_oracle):
+    """Size-independent properties at BASELINE.json's full size (4096 molecules), no oracle energy needed:
+    E/N of the ideal crystal equals E/N of a 96-molecule crystal of the same cell (replication invariance);
+    sum_i local = 2 E2 + 3 E3 with model = E2 + E3 (G4) holds with E3 > 0; interaction counts of the ideal
+    crystal are exactly 4N pairs + 6N triplets; old/new local energies are invariant under a whole-cell
+    translation of all molecules (positions are unwrapped, images are not)."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.energy import load_boxes
+    h_s, x_s = lat.ice_box("ih", (3, 2, 2), 0.0)
+    h_b, x_b = lat.ice_box("ih", (8, 8, 8), 0.0)
+    em = load_boxes([h_s], [x_s])
+    e_small = em.model_energy[0] / len(x_s)
+    em.energy_deinit()
+    x_t = lat.thermalise(x_b, 0.15, 99)
+    em = load_boxes([h_b, h_b, h_b], [x_b, x_t, x_t + 2 * h_b[0] - h_b[2]])
+    try:
+        assert em.model_energy[0] / 4096 == pytest.approx(e_small, rel=1e-13)
+        assert em.model_energy_counts(1) == (4 * 4096, 6 * 4096)
+        assert em.model_energy[2] == pytest.approx(em.model_energy[1], rel=1e-12)      # rigid whole-cell shift
+        loc = em.local_energy_batch(2, np.arange(1, 4097))
+        e3 = loc.sum() - 2 * em.model_energy[1]
+        e2 = em.model_energy[1] - e3
+        assert e3 > 0 and e2 < 0 and loc.sum() == pytest.approx(2 * e2 + 3 * e3, rel=1e-13)
+        p, t = em.model_energy_counts(2)
+        imol = np.arange(1, 4097, 7)
+        eo, en = em.delta_energy_batch(2, imol, x_t[imol - 1] + 0.3)
+        eo3, en3 = em.delta_energy_batch(3, imol, x_t[imol - 1] + 0.3 + 2 * h_b[0] - h_b[2])
+        assert np.allclose(eo, eo3, rtol=1e-11) and np.allclose(en, en3, rtol=1e-11)
+        assert np.allclose(eo, loc[imol - 1], rtol=1e-13)
+    finally:
+        em.energy_deinit()
+
+
+def test_engine_lifecycle_and_argument_errors():
+    from mc_water_ls_mw_amd.energy import EnergyModule, MwError, load_library
+    z = load_golden("ic48")
+    L = load_library()
+    em = EnergyModule(48, 1)
+    em.hmatrix[0], em.ljr[0] = z["h"], z["xyz"]
+    em.energy_init()
+    try:
+        assert L.mw_init(0, 48, 1, 50) != 0 and b"already initialised" in L.mw_last_error()
+        with pytest.raises(MwError, match="outside"):
+            em.compute_local_real_energy(49, 1)
+        with pytest.raises(MwError, match="outside"):
+            em.compute_model_energy(2)
+        with pytest.raises(MwError, match="outside"):
+            em.delta_energy_batch(1, np.array([0], dtype=np.int32), np.zeros((1, 3)))
+        assert em.local_energy_batch(1, np.zeros(0, dtype=np.int32)).shape == (0,)     # empty batch is fine
+    finally:
+        em.energy_deinit()
+    em.energy_deinit()                                                                 # idempotent
+    assert L.mw_is_initialised() == 0
