@@ -188,6 +188,35 @@ class SweepOracle:
                                      ctypes.byref(lsv), ctypes.byref(mu), _d(me), ctypes.byref(acc), _d(log))
         return dict(xyz=xyz, ls=lsv.value, ls_mu=mu.value, model_energy=me, accepted=acc.value, log=log, lists=lists)
 
+    def full(self, st, nmoves, seed, walker, move0, transP, dv_max, beta, max_trans, grid, weight, histogram,
+             unbiased_hist, eta_interp=True, record=True, samplerun=True, always_switch=True, npt=True, wl_factor=0.0,
+             log_unbiased_norm=0.0, pressure=0.0):
+        """mwo_sweep_full on a FullSweepState (updated in place); weight/histogram/unbiased_hist arrays are updated in place."""
+        nn = np.ascontiguousarray(np.stack([t[0] for t in st.lists]))
+        jn = np.ascontiguousarray(np.stack([t[1] for t in st.lists]))
+        vn = np.ascontiguousarray(np.stack([t[2] for t in st.lists]))
+        mb, bw = np.ascontiguousarray(grid.mu_bin), np.ascontiguousarray(grid.binwidth)
+        eta = _Eta(grid.nbins, int(eta_interp), grid.start_bin, grid.end_bin, grid.r_pos, grid.a_pos, grid.r_neg,
+                   grid.a_neg, grid.my_mu_min, grid.my_mu_max, _d(weight), _d(mb), _d(bw))
+        vol = (ctypes.c_double * 2)(*[float(st.volume[l]) if l < st.nlat else 0.0 for l in range(2)])
+        opt = _CycleOpts(int(record), int(samplerun), int(always_switch), int(npt), grid.av_binwidth, wl_factor,
+                         log_unbiased_norm, pressure, vol)
+        lsv, mu = ctypes.c_int(st.ls), ctypes.c_double(st.ls_mu)
+        acc, sw = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        nvol = np.zeros(2, dtype=np.int64)
+        log = np.zeros((nmoves, 8))
+        self.L.mwo_sweep_full(nmoves, ctypes.c_uint64(seed), ctypes.c_uint32(walker), ctypes.c_uint64(move0),
+                              ctypes.c_double(transP), ctypes.c_double(dv_max), st.nlat, st.n, _d(st.xyz), _d(st.h),
+                              _d(st.volume), _d(st.ivect), st.ivstride, _i(st.nivect), st.maxneigh, _i(nn), _i(jn), _i(vn),
+                              ctypes.c_double(beta), ctypes.c_double(max_trans), ctypes.byref(eta), ctypes.byref(opt),
+                              _d(histogram), _d(unbiased_hist), _d(weight), ctypes.byref(lsv), ctypes.byref(mu),
+                              _d(st.model_energy), ctypes.byref(acc), ctypes.byref(sw), nn.ctypes.data_as(_lp) if False else nvol.ctypes.data_as(_lp), _d(log))
+        st.ls, st.ls_mu = lsv.value, mu.value
+        st.accepted += acc.value
+        st.switches += sw.value
+        st.nvol += nvol
+        return log
+
     def cycle(self, nmoves, seed, walker, move0, hs, xs, beta, max_trans, grid, weight, histogram, unbiased_hist,
               eta_interp=True, ls=1, ls_mu=0.0, model_energy=None, lists=None, record=True, samplerun=True,
               always_switch=True, npt=False, wl_factor=0.0, log_unbiased_norm=0.0, pressure=0.0, maxneigh=MAXNEIGH):
@@ -227,6 +256,34 @@ class SweepOracle:
                                ctypes.byref(acc), ctypes.byref(sw), _d(log))
         return dict(xyz=xyz, ls=lsv.value, ls_mu=mu.value, model_energy=me, accepted=acc.value, switches=sw.value,
                     log=log, lists=lists, weight=w, histogram=hi, unbiased_hist=uh)
+
+
+class FullSweepState:
+    """Mutable walker state for SweepOracle.full (cells change under volume moves)."""
+
+    def __init__(self, C, hs, xs, maxneigh=MAXNEIGH):
+        self.nlat, self.n, self.maxneigh = len(xs), len(xs[0]), maxneigh
+        self.xyz = np.ascontiguousarray(np.stack(xs), dtype=np.float64).copy()
+        self.h = np.ascontiguousarray(np.stack(hs), dtype=np.float64).copy()
+        self.volume = np.array([abs(np.linalg.det(hh)) for hh in hs])
+        self.ivstride = 64
+        self.ivect = np.zeros((self.nlat, self.ivstride, 3))
+        self.nivect = np.zeros(self.nlat, dtype=np.int32)
+        for l in range(self.nlat):
+            v = C.ivects(self.h[l])
+            self.ivect[l, :len(v)] = v
+            self.nivect[l] = len(v)
+        self.rebuild_lists(C)
+        self.model_energy = np.array([C.model_energy(self.xyz[l], self.iv(l), *self.lists[l]) for l in range(self.nlat)])
+        self.ls, self.ls_mu = 1, 0.0
+        self.accepted = self.switches = 0
+        self.nvol = np.zeros(2, dtype=np.int64)
+
+    def iv(self, l):
+        return np.ascontiguousarray(self.ivect[l, :self.nivect[l]])
+
+    def rebuild_lists(self, C):
+        self.lists = [C.neighbours(self.xyz[l], self.iv(l), self.maxneigh) for l in range(self.nlat)]
 
 
 class RefOracle:

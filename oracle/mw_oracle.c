@@ -586,3 +586,139 @@ static void sweep_impl(int nmoves, uint64_t seed, uint32_t walker, uint64_t move
 #undef LAT
     *ls_io = ls; *ls_mu_io = ls_mu; *accepted += acc;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * mc_volume, mc_moves.F90:1216-1534 (MINU and leshift off; ref_ljr, which only chain synchronisation
+ * reads, is not carried).
+ * ------------------------------------------------------------------------------------------------ */
+static double det3(const double *m)                                           /* util.f90:16-41 */
+{
+    double det = HM(m,1,1) * (HM(m,2,2) * HM(m,3,3) - HM(m,2,3) * HM(m,3,2));
+    det = det - HM(m,1,2) * (HM(m,2,1) * HM(m,3,3) - HM(m,2,3) * HM(m,3,1));
+    det = det + HM(m,1,3) * (HM(m,2,1) * HM(m,3,2) - HM(m,2,2) * HM(m,3,1));
+    return det;
+}
+
+/* positions -> fractional coordinates with `recip`, back to Cartesian with `hnew`; ljr += (that - ljr), :1288-1316 */
+static void rescale_positions(int n, double *xyz, const double *recip, const double *hnew)
+{
+    const double invPi = 1.0 / 3.141592653589793238462643383279502884197;
+    for (int i = 0; i < n; ++i) {
+        double *p = xyz + 3 * i;
+        const double o0 = p[0], o1 = p[1], o2 = p[2];
+        double s0 = HM(recip,1,1) * o0 + HM(recip,2,1) * o1 + HM(recip,3,1) * o2;
+        double s1 = HM(recip,1,2) * o0 + HM(recip,2,2) * o1 + HM(recip,3,2) * o2;
+        double s2 = HM(recip,1,3) * o0 + HM(recip,2,3) * o1 + HM(recip,3,3) * o2;
+        s0 = s0 * 0.5 * invPi; s1 = s1 * 0.5 * invPi; s2 = s2 * 0.5 * invPi;
+        double t[3];
+        for (int d = 1; d <= 3; ++d) t[d - 1] = HM(hnew,d,1) * s0 + HM(hnew,d,2) * s1 + HM(hnew,d,3) * s2;
+        t[0] = t[0] - o0; t[1] = t[1] - o1; t[2] = t[2] - o2;
+        p[0] = p[0] + t[0]; p[1] = p[1] + t[1]; p[2] = p[2] + t[2];
+    }
+}
+
+int mwo_volume_move(const double u[4], int nlat, int n, double *xyz, double *h, double *volume,
+                    double *ivect, int ivstride, int *nivect, int maxneigh,
+                    const int *nn, const int *jn, const int *vn,
+                    double beta, double dv_max, double pressure, const mwo_eta *eta,
+                    int ls, double *ls_mu, double *model_energy)
+{
+    double backup_e[2], old_e[2], new_e[2], deltaE[2] = {0, 0}, old_vol[2], old_h[2][9], old_recip[2][9], recip[2][9];
+    for (int l = 0; l < nlat; ++l) {                                          /* :1243-1262 */
+        backup_e[l] = model_energy[l]; old_e[l] = model_energy[l];
+        mwo_recipmatrix(h + 9 * l, recip[l]);
+        for (int t = 0; t < 9; ++t) { old_h[l][t] = h[9 * l + t]; old_recip[l][t] = recip[l][t]; }
+        old_vol[l] = volume[l];
+    }
+    const int idim = (int)(u[0] * 3.0) + 1;                                   /* :1269-1272 */
+    const int jdim = (int)(u[1] * 3.0) + 1;
+    double delta[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    HM(delta, idim, jdim) = (2.0 * u[2] - 1.0) * dv_max;                      /* :1276-1278 */
+    HM(delta, jdim, idim) = HM(delta, idim, jdim);
+    for (int l = 0; l < nlat; ++l) for (int t = 0; t < 9; ++t) h[9 * l + t] = h[9 * l + t] + delta[t];   /* :1281-1282 */
+    for (int l = 0; l < nlat; ++l) {                                          /* :1285-1358 */
+        rescale_positions(n, xyz + (size_t)3 * n * l, recip[l], h + 9 * l);
+        volume[l] = fabs(det3(h + 9 * l));
+        mwo_recipmatrix(h + 9 * l, recip[l]);
+        const int niv = mwo_compute_ivects(h + 9 * l, ivect + (size_t)3 * ivstride * l, ivstride);
+        if (niv < 0) return -1;
+        nivect[l] = niv;
+        new_e[l] = mwo_model_energy(n, xyz + (size_t)3 * n * l, ivect + (size_t)3 * ivstride * l, maxneigh,
+                                    nn + (size_t)n * l, jn + (size_t)n * maxneigh * l, vn + (size_t)n * maxneigh * l, NULL);
+        model_energy[l] = new_e[l];
+    }
+    for (int l = 0; l < nlat; ++l) deltaE[l] = new_e[l] - old_e[l];           /* :1361 */
+    double old_eta = 0.0, new_eta = 0.0;
+    if (nlat == 2) {                                                          /* :1363-1371 */
+        old_eta = mwo_eta_weight(eta, *ls_mu);
+        double mu = (model_energy[0] + pressure * volume[0]) - (model_energy[1] + pressure * volume[1]);
+        mu = mu * beta - (double)n * log(volume[0] / volume[1]);
+        *ls_mu = mu;
+        new_eta = mwo_eta_weight(eta, *ls_mu);
+    }
+    const double x = u[3];                                                    /* :1378 */
+    const double diffkT = beta * deltaE[ls - 1] + new_eta - old_eta + beta * pressure * (volume[ls - 1] - old_vol[ls - 1])
+                          - (double)n * log(volume[ls - 1] / old_vol[ls - 1]);   /* :1381-1382 */
+    double compare = exp(-diffkT);
+    if (compare > 1.0) compare = 1.0;
+    if (x < compare) return 1;                                                /* :1410 */
+    /* rejected, :1426-1530 */
+    for (int l = 0; l < nlat; ++l) {
+        volume[l] = old_vol[l];
+        for (int t = 0; t < 9; ++t) h[9 * l + t] = old_h[l][t];
+    }
+    for (int l = 0; l < nlat; ++l) rescale_positions(n, xyz + (size_t)3 * n * l, recip[l], h + 9 * l);   /* recip is the NEW one here */
+    for (int l = 0; l < nlat; ++l) {
+        const int niv = mwo_compute_ivects(h + 9 * l, ivect + (size_t)3 * ivstride * l, ivstride);       /* :1510-1512 */
+        if (niv < 0) return -1;
+        nivect[l] = niv;
+        model_energy[l] = backup_e[l];                                        /* :1514 */
+    }
+    if (nlat == 2) {                                                          /* :1516-1520 */
+        double mu = (model_energy[0] + pressure * volume[0]) - (model_energy[1] + pressure * volume[1]);
+        mu = mu * beta - (double)n * log(volume[0] / volume[1]);
+        *ls_mu = mu;
+    }
+    (void)old_recip;
+    return 0;
+}
+
+void mwo_sweep_full(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0, double transP, double dv_max,
+                    int nlat, int n, double *xyz, double *h, double *volume,
+                    double *ivect, int ivstride, int *nivect, int maxneigh,
+                    const int *nn, const int *jn, const int *vn,
+                    double beta, double max_trans, const mwo_eta *eta, mwo_cycle_opts *opt,
+                    double *histogram, double *unbiased_hist, double *weight,
+                    int *ls, double *ls_mu, double *model_energy,
+                    long long *accepted, long long *switches, long long *nvol, double *log)
+{
+    for (int mv = 0; mv < nmoves; ++mv) {
+        double u[8];
+        mwo_move_uniforms8(seed, walker, move0 + (uint64_t)mv, u);
+        if (u[7] < transP) {                                                  /* mc_moves.F90:226-231 */
+            opt->volume[0] = volume[0]; if (nlat == 2) opt->volume[1] = volume[1];
+            sweep_impl(1, seed, walker, move0 + (uint64_t)mv, nlat, n, xyz, h, ivect, ivstride, maxneigh, nn, jn, vn,
+                       beta, max_trans, eta, opt, histogram, unbiased_hist, weight, ls, ls_mu, model_energy,
+                       accepted, switches, log ? log + 8 * (size_t)mv : NULL);
+        } else {                                                              /* :232-235 */
+            const int ok = mwo_volume_move(u, nlat, n, xyz, h, volume, ivect, ivstride, nivect, maxneigh, nn, jn, vn,
+                                           beta, dv_max, opt->pressure, eta, *ls, ls_mu, model_energy);
+            if (nvol) { ++nvol[0]; if (ok == 1) ++nvol[1]; }
+            int sw = 0;
+            if (nlat == 2) {
+                opt->volume[0] = volume[0]; opt->volume[1] = volume[1];
+                update_wl_bins(eta, opt, *ls_mu, histogram, unbiased_hist, weight);                    /* :234 */
+                if (opt->always_switch) {                                                              /* :243-248 */
+                    sw = lattice_switch(eta, opt, beta, n, u[6], model_energy, ls, ls_mu);
+                    if (sw && switches) ++*switches;
+                }
+            }
+            if (log) {
+                double *q = log + 8 * (size_t)mv;
+                q[0] = 0.0; q[1] = 4 + (ok == 1) + 2 * sw; q[2] = model_energy[0]; q[3] = volume[0];
+                q[4] = nlat == 2 ? model_energy[1] : 0.0; q[5] = nlat == 2 ? volume[1] : 0.0; q[6] = *ls_mu; q[7] = 0.0;
+            }
+        }
+    }
+}

@@ -147,3 +147,39 @@ void mwo_sweep_cycle(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0,
 }
 #endif
 #endif
+
+/* ---- volume move (mc_volume, mc_moves.F90:1216-1534; MINU / leshift off; ref_ljr not carried) ------- */
+#ifndef MW_ORACLE_VOLUME_H
+#define MW_ORACLE_VOLUME_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* One volume move of a walker: u[0], u[1] pick the symmetric hmatrix element, u[2] its change, u[3] is the
+ * acceptance variate (mc_moves.F90:1269-1275,1378).  Both lattices' cells get the same change, all positions are
+ * rescaled through fractional coordinates (:1285-1349), image vectors are rebuilt and the full-box energies
+ * recomputed WITH THE EXISTING LISTS (:1351-1358); on rejection cell, positions (mapped back through the new
+ * reciprocal matrix, :1413-1506), image vectors, energies and ls_mu are restored the way the reference does.
+ * h[nlat][9], volume[nlat], ivect[nlat][ivstride][3] and nivect[nlat] are updated in place.  Returns 1 if accepted,
+ * 0 if rejected, -1 if a lattice would need more than ivstride image vectors. */
+int mwo_volume_move(const double u[4], int nlat, int n, double *xyz, double *h, double *volume,
+                    double *ivect, int ivstride, int *nivect, int maxneigh,
+                    const int *nn, const int *jn, const int *vn,
+                    double beta, double dv_max, double pressure, const mwo_eta *eta,
+                    int ls, double *ls_mu, double *model_energy);
+
+/* A full mc_cycle move sequence: per move u[7] of mwo_move_uniforms8 chooses translation (u[7] < transP) or
+ * volume move; translations as mwo_sweep_cycle, volume moves as mwo_volume_move with u[0..3]; after either,
+ * mc_update_wl_bins and (always_switch) a lattice-switch attempt with u[6] (mc_moves.F90:224-250).
+ * nvol (may be NULL) counts volume moves attempted / accepted in nvol[0], nvol[1]. */
+void mwo_sweep_full(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0, double transP, double dv_max,
+                    int nlat, int n, double *xyz, double *h, double *volume,
+                    double *ivect, int ivstride, int *nivect, int maxneigh,
+                    const int *nn, const int *jn, const int *vn,
+                    double beta, double max_trans, const mwo_eta *eta, mwo_cycle_opts *opt,
+                    double *histogram, double *unbiased_hist, double *weight,
+                    int *ls, double *ls_mu, double *model_energy,
+                    long long *accepted, long long *switches, long long *nvol, double *log);
+#ifdef __cplusplus
+}
+#endif
+#endif

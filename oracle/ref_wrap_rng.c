@@ -19,20 +19,39 @@
 
 #define MW_WRAP_SEED 424242ULL
 
-static unsigned long long mw_wrap_calls = 0;
+/* State machine over the reference's call order inside one mc_cycle move (mc_moves.F90:224-250):
+ *   1 draw  xi, the move type            -> u[7]; translation if xi < transP, else volume move
+ *   translation: 6 draws (:1001,1021-1023,1035,1145) -> u[0..5]
+ *   volume move: 4 draws (:1269,1271,1274,1378)      -> u[0..3]
+ *   with mc_always_switch: 1 draw in mc_lattice_switch (:1576) -> u[6]
+ * Environment: MW_WRAP_TRANSP = transP of the run (default 1: translations only),
+ *              MW_WRAP_SWITCH = 1 if mc_always_switch (MW_WRAP_CALLS_PER_MOVE=8 is accepted as a synonym). */
+static unsigned long long mw_move = 0;
+static int mw_phase = -1;           /* -1: not configured; 0: expect xi; 1..: index into the move's draws */
+static int mw_ndraws = 0, mw_switch = 0;
+static double mw_transp = 1.0, mw_u[8];
 
 double __wrap__QMrandomPrandom_uniform_random(void)
 {
-    static unsigned long long per_move = 0;
-    if (per_move == 0) {
-        const char *e = getenv("MW_WRAP_CALLS_PER_MOVE");
-        per_move = (e && atoi(e) == 8) ? 8ULL : 7ULL;
+    if (mw_phase < 0) {
+        const char *e = getenv("MW_WRAP_TRANSP");
+        if (e) mw_transp = atof(e);
+        e = getenv("MW_WRAP_SWITCH");
+        if (e && atoi(e) == 1) mw_switch = 1;
+        e = getenv("MW_WRAP_CALLS_PER_MOVE");
+        if (e && atoi(e) == 8) mw_switch = 1;
+        mw_phase = 0;
     }
-    const unsigned long long c = mw_wrap_calls++;
-    const unsigned long long move = c / per_move;
-    const int slot = (int)(c % per_move);
-    double u[8];
-    if (slot == 0) return 0.0;
-    mwo_move_uniforms8(MW_WRAP_SEED, 0u, move, u);
-    return u[slot - 1];
+    if (mw_phase == 0) {
+        mwo_move_uniforms8(MW_WRAP_SEED, 0u, mw_move, mw_u);
+        mw_ndraws = (mw_u[7] < mw_transp) ? 6 : 4;
+        mw_phase = 1;
+        return mw_u[7];
+    }
+    double v;
+    if (mw_phase <= mw_ndraws) v = mw_u[mw_phase - 1];
+    else v = mw_u[6];                                   /* the lattice-switch variate */
+    if (mw_phase == mw_ndraws + mw_switch) { mw_phase = 0; ++mw_move; }
+    else ++mw_phase;
+    return v;
 }

@@ -25,7 +25,8 @@ AUP_TO_ATM = 2.90363081e8
 pytestmark = pytest.mark.skipif(not os.path.exists(RNG), reason="oracle/_ref/mc_water_ref_rng not built")
 
 
-def namelist(num_lattices, temperature, cycles, samplerun, always_switch=False):
+def namelist(num_lattices, temperature, cycles, samplerun, always_switch=False, npt=False, vol_prob=None):
+    volume_lines = "allow_vol        = .false." if not npt else f"mc_vol_prob      = {vol_prob}"
     return f"""&potential
 model_type = "mW"
 /
@@ -34,7 +35,7 @@ temperature = {temperature}
 pressure    = 1.0
 /
 &MonteCarlo
-mc_ensemble      = 'nvt'
+mc_ensemble      = '{'npt' if npt else 'nvt'}'
 mc_max_trans     = 1.1
 mc_dv_max        = 0.924
 nbins            = 101
@@ -42,7 +43,7 @@ mu_max           = +400
 mu_min           = -400
 mc_always_switch = .{'true' if always_switch else 'false'}.
 allow_switch     = .false.
-allow_vol        = .false.
+{volume_lines}
 eta_interp       = .true.
 samplerun        = .{'true' if samplerun else 'false'}.
 /
@@ -77,11 +78,11 @@ def read_records(path):
 
 
 def run_reference(d, num_lattices, temperature, cycles, weight=None, grid=None, samplerun=None, always_switch=False,
-                  tables=False):
+                  tables=False, npt=False, vol_prob=None, transP=1.0):
     from mc_water_ls_mw_amd import lattice as lat
     os.makedirs(d)
     samplerun = (weight is not None) if samplerun is None else samplerun
-    open(os.path.join(d, "ice.input"), "w").write(namelist(num_lattices, temperature, cycles, samplerun, always_switch))
+    open(os.path.join(d, "ice.input"), "w").write(namelist(num_lattices, temperature, cycles, samplerun, always_switch, npt, vol_prob))
     z1 = load_golden("ic48_t015")
     h1, x1 = lat.read_xmol(_write(d, "input001.xmol", z1))
     boxes = [(h1, x1)]
@@ -93,7 +94,7 @@ def run_reference(d, num_lattices, temperature, cycles, weight=None, grid=None, 
             fh.write("#Current energy increment =   0.500000007451E-01\n")
             for mu, w in zip(grid.mu_bin, weight):
                 fh.write(f"  {float(mu)!r}        {float(w)!r}\n")
-    env = dict(os.environ, MW_WRAP_CALLS_PER_MOVE="8" if always_switch else "7")
+    env = dict(os.environ, MW_WRAP_SWITCH="1" if always_switch else "0", MW_WRAP_TRANSP=repr(float(transP)))
     out = subprocess.run([RNG, "ice.input"], cwd=d, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, (out.stdout[-800:], out.stderr[-800:])
     therm = [f for f in os.listdir(d) if f.endswith("_therm.dat")][0]
@@ -101,6 +102,7 @@ def run_reference(d, num_lattices, temperature, cycles, weight=None, grid=None, 
     chk = [f for f in os.listdir(d) if f.startswith("checkpoint")]
     recs = read_records(os.path.join(d, sorted(chk)[-1]))
     ljr = np.frombuffer(recs[-2], dtype="<f8").reshape(num_lattices, 48, 3)      # ljr(3,1,N,L), column-major
+    run_reference.hmatrix = np.frombuffer(recs[-4], dtype="<f8").reshape(num_lattices, 3, 3).copy()   # hmatrix(3,3,L)
     ls = struct.unpack("<i", recs[-1])[0]
     assert struct.unpack("<i", recs[1])[0] == cycles
     if tables:      # records: nwater, cycle, (max_trans, dv_max), wl_factor, histogram, weight, wl_invt_active, [uhist], ...
@@ -227,3 +229,34 @@ def test_sampling_run_with_switches_matches_the_reference_program(tmp_path, so, 
     assert np.abs(xs - ljr).max() < 1e-10 and ls == ls_or
     assert np.allclose(e_or, e_ref, rtol=2e-6, atol=2e-6)
     assert np.allclose(hi, hist, rtol=1e-12, atol=1e-12) and np.allclose(w, wgt, rtol=1e-13)
+
+
+def test_npt_run_with_volume_moves_matches_the_reference_program(tmp_path, so, c_oracle):
+    """The whole move set of mc_cycle: translations, volume moves (cell change, all positions rescaled through
+    fractional coordinates, full-box energies with the existing lists, restore on rejection), Wang-Landau updates and
+    a lattice-switch attempt after every move -- NPT, two lattices, 40 cycles with ~1 move in 6 a volume move."""
+    from mc_water_ls_mw_amd.lattice import ANG_TO_BOHR
+    from mc_water_ls_mw_amd.sweep import KB, MuGrid
+    from oracle import FullSweepState
+    grid = MuGrid(101, -400.0, 400.0)
+    vol_prob = 0.1
+    transP = 0.5 / (0.5 + vol_prob + 0.0)                      # mc_moves.F90:157-166
+    boxes, e_ref, ljr, ls, hist, wgt = run_reference(str(tmp_path / "run"), 2, 200, 40, samplerun=False, always_switch=True,
+                                                     tables=True, npt=True, vol_prob=vol_prob, transP=transP)
+    beta, p = 1.0 / (KB * 200.0), 1.0 / AUP_TO_ATM
+    st = FullSweepState(c_oracle, [b[0] for b in boxes], [b[1] for b in boxes])
+    mu = st.model_energy[0] + p * st.volume[0] - st.model_energy[1] - p * st.volume[1]
+    st.ls_mu = mu * beta - 48.0 * np.log(st.volume[0] / st.volume[1])
+    w, hi, uh = np.zeros(101), np.zeros(101), np.zeros(101)
+    energies = []
+    for cyc in range(1, 41):
+        if cyc % 10 == 0:                                      # compute_neighbours also rebuilds the image vectors
+            st.rebuild_lists(c_oracle)
+        so.full(st, 48, SEED, 0, (cyc - 1) * 48, transP, 0.924 * ANG_TO_BOHR, beta, 1.1 * ANG_TO_BOHR, grid, w, hi, uh,
+                record=True, samplerun=False, always_switch=True, npt=True, wl_factor=float(np.float32(0.05)), pressure=p)
+        energies.append(st.model_energy[st.ls - 1] * HART_TO_EV)
+    assert st.nvol[0] > 100 and 0 < st.nvol[1] < st.nvol[0]                   # volume moves happened, some accepted
+    assert np.abs(st.h - run_reference.hmatrix).max() < 1e-10                 # the same cell ...
+    assert np.abs(st.xyz - ljr).max() < 1e-9 and st.ls == ls                  # ... the same configuration
+    assert np.allclose(np.array(energies), e_ref, rtol=2e-6, atol=2e-6)
+    assert np.allclose(hi, hist, rtol=1e-12, atol=1e-12) and np.allclose(w, wgt, rtol=1e-10, atol=1e-11)
