@@ -159,6 +159,16 @@ int mw_sweep_configure(int nlat, double beta, double max_trans_bohr, int nbins, 
  * walkers and GPUs (comms_allreduce_eta/hist/uhist semantics) through get/set_tables. */
 int mw_sweep_options(int record, int samplerun, int always_switch, int npt,
                      double av_binwidth, double wl_factor, double log_unbiased_norm, double pressure);
+/* Volume moves inside the sweep (mc_volume, mc_moves.F90:1216-1534; ref_ljr not carried): per move the stream's
+ * eighth number chooses a translation (< transP, mc_moves.F90:157-166,226-235) or a volume move: one symmetric
+ * hmatrix element of both lattices changes by at most dv_max, every position is rescaled through fractional
+ * coordinates, image vectors are rebuilt and the full-box energies recomputed with the existing lists, all on the
+ * device; pressure and ensemble come from mw_sweep_options.  Default: translations only.  After sweeps with volume
+ * moves call mw_sweep_sync_cells before rebuilding lists: it reads the cells back (h_out, count x 9, may be NULL)
+ * and refreshes the host-side image vectors / neighbour-grid descriptors exactly as mw_set_cell does. */
+int mw_sweep_moves(double transP, double dv_max_bohr);
+int mw_sweep_get_volume_moves(int walker, long long *attempted, long long *accepted);
+int mw_sweep_sync_cells(int first_ils, int count, double *h_out);
 int mw_sweep_get_tables(int walker, double *weight, double *histogram, double *unbiased_hist);
 int mw_sweep_set_tables(int walker, const double *weight, const double *histogram, const double *unbiased_hist);
 /* The same for `count` consecutive walkers in one transfer: arrays of count x nbins doubles. */

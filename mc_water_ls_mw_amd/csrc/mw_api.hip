@@ -75,6 +75,8 @@ struct Ctx {
     double *d_sw_mubin = nullptr, *d_sw_binwidth = nullptr;
     double *d_wweight = nullptr, *d_whist = nullptr, *d_wuhist = nullptr;   // [walker][nbins]
     unsigned long long* d_wswitch = nullptr;
+    unsigned long long* d_wvol = nullptr;        // [walker][2] volume moves attempted / accepted
+    int* d_wflag = nullptr;                      // [walker] a volume move needed more image vectors than ivcap
     double* d_volume = nullptr;                  // [box] |det hmatrix|
     int* d_wls = nullptr;
     double* d_wmu = nullptr;
@@ -431,7 +433,7 @@ int mw_finalize(void)
     hipStreamSynchronize(g.stream);
     hipFree(g.d_hmat);
     if (g.d_sw_mubin) { hipFree(g.d_sw_mubin); hipFree(g.d_sw_binwidth); hipFree(g.d_wweight); hipFree(g.d_whist); hipFree(g.d_wuhist); }
-    if (g.d_wls) { hipFree(g.d_wls); hipFree(g.d_wmu); hipFree(g.d_wacc); hipFree(g.d_wswitch); }
+    if (g.d_wls) { hipFree(g.d_wls); hipFree(g.d_wmu); hipFree(g.d_wacc); hipFree(g.d_wswitch); hipFree(g.d_wvol); hipFree(g.d_wflag); }
     hipFree(g.d_volume);
     if (g.d_swlog) hipFree(g.d_swlog);
     hipFree(g.d_pos); hipFree(g.d_ivect); hipFree(g.d_nivect); hipFree(g.d_list); hipFree(g.d_listm); hipFree(g.d_nn); hipFree(g.d_stats);
@@ -789,6 +791,7 @@ int mw_sweep_configure(int nlat, double beta, double max_trans, int nbins, int e
     g.sp.nlat = nlat; g.sp.nbins = nbins; g.sp.eta_interp = eta_interp; g.sp.start_bin = start_bin; g.sp.end_bin = end_bin; g.sp.pad = 0;
     g.sp.record = 0; g.sp.samplerun = 1; g.sp.always_switch = 0; g.sp.npt = 0;
     g.sp.av_binwidth = 1.0; g.sp.wl_factor = 0.0; g.sp.log_unbiased_norm = 0.0; g.sp.pressure = 0.0;
+    g.sp.transP = 2.0; g.sp.dv_max = 0.0;       // translations only until mw_sweep_moves says otherwise
     if (g.d_sw_mubin) {
         HIPCHK(hipFree(g.d_sw_mubin)); HIPCHK(hipFree(g.d_sw_binwidth));
         HIPCHK(hipFree(g.d_wweight)); HIPCHK(hipFree(g.d_whist)); HIPCHK(hipFree(g.d_wuhist));
@@ -817,7 +820,11 @@ int mw_sweep_configure(int nlat, double beta, double max_trans, int nbins, int e
         HIPCHK(hipMalloc(&g.d_wmu, sizeof(double) * g.nbox));
         HIPCHK(hipMalloc(&g.d_wacc, sizeof(unsigned long long) * g.nbox));
         HIPCHK(hipMalloc(&g.d_wswitch, sizeof(unsigned long long) * g.nbox));
+        HIPCHK(hipMalloc(&g.d_wvol, sizeof(unsigned long long) * 2 * g.nbox));
+        HIPCHK(hipMalloc(&g.d_wflag, sizeof(int) * g.nbox));
     }
+    HIPCHK(hipMemset(g.d_wvol, 0, sizeof(unsigned long long) * 2 * g.nbox));
+    HIPCHK(hipMemset(g.d_wflag, 0, sizeof(int) * g.nbox));
     HIPCHK(hipMemset(g.d_wswitch, 0, sizeof(unsigned long long) * g.nbox));
     std::vector<int> one((size_t)g.nbox, 1);
     HIPCHK(hipMemcpy(g.d_wls, one.data(), sizeof(int) * g.nbox, hipMemcpyHostToDevice));
@@ -869,6 +876,48 @@ int mw_sweep_options(int record, int samplerun, int always_switch, int npt,
     if ((record || always_switch) && g.sp.nlat != 2) return fail("mw_sweep_options: histograms and lattice switches need two lattices");
     g.sp.record = record ? 1 : 0; g.sp.samplerun = samplerun ? 1 : 0; g.sp.always_switch = always_switch ? 1 : 0; g.sp.npt = npt ? 1 : 0;
     g.sp.av_binwidth = av_binwidth; g.sp.wl_factor = wl_factor; g.sp.log_unbiased_norm = log_unbiased_norm; g.sp.pressure = pressure;
+    return 0;
+}
+
+int mw_sweep_moves(double transP, double dv_max_bohr)
+{
+    if (check_live()) return 1;
+    if (!g.sweep_ready) return fail("mw_sweep_moves: call mw_sweep_configure first");
+    if (!(transP > 0.0)) return fail("mw_sweep_moves: transP = %g must be positive", transP);
+    g.sp.transP = transP; g.sp.dv_max = dv_max_bohr;
+    return 0;
+}
+
+int mw_sweep_get_volume_moves(int walker, long long* attempted, long long* accepted)
+{
+    if (check_live() || check_walker(walker, 1)) return 1;
+    unsigned long long v[2];
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(v, g.d_wvol + 2 * (size_t)(walker - 1), sizeof v, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(&flag, g.d_wflag + (walker - 1), sizeof(int), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    if (attempted) *attempted = (long long)v[0];
+    if (accepted) *accepted = (long long)v[1];
+    if (flag) return fail("mw_sweep: a volume move of walker %d shrank a cell below what %d image vectors cover", walker, g.ivcap);
+    return 0;
+}
+
+// After volume moves on the device the host mirrors of the cells (image vectors, neighbour-grid descriptors)
+// are stale: read the cells back and rebuild them exactly as mw_set_cell does.  Call before rebuilding lists.
+int mw_sweep_sync_cells(int first_ils, int count, double* h_out)
+{
+    if (check_live() || check_range(first_ils, count)) return 1;
+    std::vector<double> h((size_t)count * 9);
+    std::vector<int> flags((size_t)g.nbox, 0);
+    HIPCHK(hipMemcpyAsync(h.data(), g.d_hmat + 9 * (size_t)(first_ils - 1), h.size() * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+    if (g.d_wflag) HIPCHK(hipMemcpyAsync(flags.data(), g.d_wflag, sizeof(int) * g.nbox, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (int w = 0; w < g.nbox; ++w)
+        if (flags[(size_t)w]) return fail("mw_sweep: a volume move of walker %d shrank a cell below what %d image vectors cover", w + 1, g.ivcap);
+    for (int b = 0; b < count; ++b) {
+        if (mw_set_cell(first_ils + b, &h[(size_t)b * 9], nullptr)) return 1;
+        if (h_out) std::memcpy(h_out + (size_t)b * 9, &h[(size_t)b * 9], 9 * sizeof(double));
+    }
     return 0;
 }
 
@@ -961,11 +1010,15 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
         ldslist = mx <= 32;                          // stats = {min nn, max nn} of the last list build of each box
     }
     const size_t shmem = iv_bytes + (ldspos ? pos_bytes : 0) + (ldslist ? list_bytes : 0);
-    auto kern = ldslist ? mw::k_sweep_translation<true, true>
-                        : (ldspos ? mw::k_sweep_translation<true, false> : mw::k_sweep_translation<false, false>);
+    const bool withvol = g.sp.transP < 1.0;          // volume moves: the build that carries the out-of-line mc_volume
+    auto kern = withvol ? (ldslist ? mw::k_sweep_translation<true, true, true>
+                                   : (ldspos ? mw::k_sweep_translation<true, false, true> : mw::k_sweep_translation<false, false, true>))
+                        : (ldslist ? mw::k_sweep_translation<true, true, false>
+                                   : (ldspos ? mw::k_sweep_translation<true, false, false> : mw::k_sweep_translation<false, false, false>));
     hipLaunchKernelGGL(kern, dim3(count), dim3(64), shmem, g.stream, g.d_pos, g.d_hmat, g.d_ivect, g.d_nivect,
-                       g.d_listm, g.d_nn, g.d_energy, g.d_wls, g.d_wmu, g.d_wacc, g.d_wswitch, g.sp, g.d_wweight, g.d_whist, g.d_wuhist,
-                       g.d_sw_mubin, g.d_sw_binwidth, g.d_volume, g.N, g.ivcap, nmoves, seed, move0, first_walker - 1, dlog);
+                       g.d_listm, g.d_list, g.d_nn, g.d_energy, g.d_wls, g.d_wmu, g.d_wacc, g.d_wswitch, g.sp, g.d_wweight, g.d_whist, g.d_wuhist,
+                       g.d_sw_mubin, g.d_sw_binwidth, g.d_volume, g.d_wvol, g.d_wflag, g.N, g.S, g.ivcap, nmoves, seed, move0,
+                       first_walker - 1, dlog);
     HIPCHK(hipGetLastError());
     return 0;
 }

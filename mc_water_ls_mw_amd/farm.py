@@ -21,7 +21,7 @@ import numpy as np
 
 def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=400.0, wl_factor=0.05,
         list_update_int=10, mpi_sync_int=250, sigma_ang=0.05, seed=2025, device=0, comms=None, rank=0,
-        samplerun=False, weight=None):
+        samplerun=False, weight=None, npt=False, pressure_atm=1.0):
     """Run `cycles` MC cycles of `walkers` two-lattice walkers on this GPU.  Returns a dict of results."""
     from . import lattice as lat
     from .energy import EnergyModule
@@ -43,14 +43,18 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         em.build_neighbours_batch(1, 2 * walkers)
         em.model_energy_batch(1, 2 * walkers)
         grid = MuGrid(nbins, -mu_range, mu_range)
-        farm = WalkerFarm(em, 2, temperature, 1.1, grid=grid, weight=weight)
-        farm.options(record=True, samplerun=samplerun, always_switch=True, npt=False, wl_factor=wl_factor)
+        farm = WalkerFarm(em, 2, temperature, 1.1, grid=grid, weight=weight, pressure_au=pressure_atm / 2.90363081e8)
+        farm.options(record=True, samplerun=samplerun, always_switch=True, npt=npt, wl_factor=wl_factor)
+        if npt:                                                    # io.f90:171-172: vol 1/N against trans 0.5
+            farm.moves(trans_prob=0.5, vol_prob=1.0 / n, dv_max_ang=0.924)
         for w in range(1, walkers + 1):
             farm.set_state(w, 1, farm.initial_mu(w))
         t0 = time.perf_counter()
         synced = None
         for cyc in range(1, cycles + 1):
             if cyc % list_update_int == 0:                         # mc_moves.F90:217-222
+                if npt:
+                    farm.sync_cells()                              # device-side volume moves changed the cells
                 em.build_neighbours_batch(1, 2 * walkers)      # checked: fails loudly on list overflow
             farm.sweep_launch(n, seed=seed + rank, move0=(cyc - 1) * n)
             if comms is not None and cyc % mpi_sync_int == 0:      # mc_moves.F90:258-276
@@ -65,6 +69,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                    acceptance=float(np.mean([s["accepted"] for s in states])) / (cycles * n),
                    switches_per_walker=float(np.mean([farm.switches(w) for w in range(1, min(walkers, 32) + 1)])),
                    drift_walker1_Ha=[states[0]["model_energy"][l] - fresh[l] for l in range(2)],
+                   volume_moves_walker1=farm.volume_moves(1) if npt else None,
                    histogram_total=None if synced is None else float(synced[1].sum()),
                    weight_max=None if synced is None else float(synced[0].max()))
         out["tables"] = synced
@@ -80,6 +85,7 @@ def main():
     ap.add_argument("--sync", type=int, default=25)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--share-device", action="store_true")
+    ap.add_argument("--npt", action="store_true", help="volume moves too (mc_ensemble = 'npt')")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -98,7 +104,7 @@ def main():
     z1, z2 = np.load(os.path.join(gold, "ic48.npz")), np.load(os.path.join(gold, "ih48.npz"))
     comms = WalkerComms(101, device=torch.device("cuda", local) if (world > 1 and args.backend == "nccl") else None)
     res = run([z1["h"], z2["h"]], [z1["xyz"], z2["xyz"]], args.walkers, args.cycles, mpi_sync_int=args.sync,
-              device=local, comms=comms, rank=rank)
+              device=local, comms=comms, rank=rank, npt=args.npt)
     tabs = res.pop("tables")
     if world > 1:
         t = torch.tensor(np.concatenate(tabs[:2]), dtype=torch.float64,

@@ -101,6 +101,31 @@ class WalkerFarm:
                                              ctypes.c_double(self.grid.av_binwidth), ctypes.c_double(wl_factor),
                                              ctypes.c_double(log_unbiased_norm), ctypes.c_double(self.pressure)))
 
+    def moves(self, trans_prob=0.5, vol_prob=0.0, dv_max_ang=0.924):
+        """Move mix of mc_cycle (mc_moves.F90:157-166): transP = trans/(trans + vol); volume moves change one
+        symmetric cell element by at most dv_max."""
+        from .lattice import ANG_TO_BOHR
+        self.transP = trans_prob / (trans_prob + vol_prob)
+        self.dv_max = dv_max_ang * ANG_TO_BOHR
+        self.em._chk(self.L.mw_sweep_moves(ctypes.c_double(self.transP), ctypes.c_double(self.dv_max)))
+
+    def volume_moves(self, walker):
+        a, b = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        self.em._chk(self.L.mw_sweep_get_volume_moves(walker, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def sync_cells(self):
+        """Bring the host's hmatrix / volume / image vectors / grid descriptors up to date after device-side
+        volume moves (call before rebuilding neighbour lists)."""
+        nb = self.em.num_lattices
+        h = np.zeros((nb, 3, 3))
+        self.em._chk(self.L.mw_sweep_sync_cells(1, nb, h.ctypes.data_as(_dp)))
+        self.em.hmatrix[:] = h
+        for b in range(nb):
+            self.em.volume[b] = abs(np.linalg.det(h[b]))
+            self.em._stale[b] = False       # positions on the device are the authoritative ones here
+        return h
+
     def tables(self, walker):
         """(weight, histogram, unbiased_hist) of one walker."""
         nb = self.grid.nbins

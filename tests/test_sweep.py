@@ -288,3 +288,69 @@ def test_farm_loop_equals_oracle_replay_including_stale_list_drift(so, c_oracle)
     drift_oracle = [me[l] - fresh[l] for l in range(2)]
     for l in range(2):
         assert abs(res["drift_walker1_Ha"][l] - drift_oracle[l]) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nlat", [2, 1])
+def test_npt_sweep_with_volume_moves_on_device_follows_the_oracle(so, c_oracle, nlat):
+    """The whole move set on the device: translations, volume moves (both cells change, positions rescaled, image
+    vectors rebuilt, full-box energies with the existing lists, restore on rejection), Wang-Landau updates, lattice
+    switches; lists rebuilt in between after mw_sweep_sync_cells.  Walker by walker against mwo_sweep_full."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.sweep import MuGrid
+    from oracle import FullSweepState
+    z1, z2 = load_golden("ic48"), load_golden("ih48")
+    grid = MuGrid(101, -400.0, 400.0)
+    boxes, nw = [], 4
+    for w in range(nw):
+        boxes.append((z1["h"], lat.thermalise(z1["xyz"], 0.06, 360 + w)))
+        if nlat == 2:
+            boxes.append((z2["h"], lat.thermalise(z2["xyz"], 0.06, 380 + w)))
+    p_au = 1.0 / 2.90363081e8
+    from mc_water_ls_mw_amd.energy import load_boxes
+    from mc_water_ls_mw_amd.sweep import WalkerFarm
+    em = load_boxes([b[0] for b in boxes], [b[1] for b in boxes])
+    farm = WalkerFarm(em, nlat, 200.0, 1.1, grid=grid, weight=np.zeros(101), pressure_au=p_au)
+    try:
+        if nlat == 2:
+            farm.options(record=True, samplerun=False, always_switch=True, npt=True, wl_factor=0.05)
+        else:
+            em._chk(em.L.mw_sweep_options(0, 1, 0, 1, __import__("ctypes").c_double(grid.av_binwidth),
+                                          __import__("ctypes").c_double(0.0), __import__("ctypes").c_double(0.0),
+                                          __import__("ctypes").c_double(p_au)))
+        farm.moves(trans_prob=0.5, vol_prob=0.1, dv_max_ang=0.924)
+        mus = [farm.initial_mu(w) for w in range(1, nw + 1)]
+        for w in range(1, nw + 1):
+            farm.set_state(w, 1, mus[w - 1])
+        e0 = em.model_energy.copy()
+        log_a = farm.sweep(96, seed=11, move0=0, log=True)
+        farm.sync_cells()
+        em.build_neighbours_batch(1, nlat * nw)
+        log_b = farm.sweep(96, seed=11, move0=96, log=True)
+        hdev = farm.sync_cells()
+        for w in range(nw):
+            bx = boxes[nlat * w:nlat * w + nlat]
+            st = FullSweepState(c_oracle, [b[0] for b in bx], [b[1] for b in bx])
+            st.model_energy[:] = e0[nlat * w:nlat * w + nlat]
+            st.ls_mu = mus[w]
+            wt, hi, uh = np.zeros(101), np.zeros(101), np.zeros(101)
+            kw = dict(record=nlat == 2, samplerun=False, always_switch=nlat == 2, npt=True, wl_factor=0.05, pressure=p_au)
+            la = so.full(st, 96, 11, w, 0, farm.transP, farm.dv_max, farm.beta, farm.max_trans, grid, wt, hi, uh, **kw)
+            st.rebuild_lists(c_oracle)
+            lb = so.full(st, 96, 11, w, 96, farm.transP, farm.dv_max, farm.beta, farm.max_trans, grid, wt, hi, uh, **kw)
+            ref, dev = np.concatenate([la, lb]), np.concatenate([log_a[w], log_b[w]])
+            assert np.array_equal(dev[:, 0], ref[:, 0]) and np.array_equal(dev[:, 1], ref[:, 1])     # molecule, outcome flags
+            assert st.nvol[0] > 10
+            assert farm.volume_moves(w + 1) == (int(st.nvol[0]), int(st.nvol[1]))
+            assert np.allclose(dev[:, 2:7], ref[:, 2:7], rtol=1e-9, atol=1e-9)
+            for l in range(nlat):
+                assert np.abs(hdev[nlat * w + l] - st.h[l]).max() < 1e-11
+                assert np.abs(farm.positions(nlat * w + l + 1) - st.xyz[l]).max() < 1e-9
+            s = farm.state(w + 1)
+            assert s["ls"] == st.ls and s["accepted"] == st.accepted
+            assert np.allclose(s["model_energy"], st.model_energy, rtol=0, atol=1e-9)
+            if nlat == 2:
+                t = farm.tables(w + 1)
+                assert np.allclose(t[0], wt, rtol=1e-10, atol=1e-11) and np.allclose(t[1], hi, rtol=1e-12)
+    finally:
+        em.energy_deinit()
