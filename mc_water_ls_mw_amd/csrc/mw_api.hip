@@ -914,10 +914,26 @@ int mw_sweep_sync_cells(int first_ils, int count, double* h_out)
     HIPCHK(hipStreamSynchronize(g.stream));
     for (int w = 0; w < g.nbox; ++w)
         if (flags[(size_t)w]) return fail("mw_sweep: a volume move of walker %d shrank a cell below what %d image vectors cover", w + 1, g.ivcap);
+    // host mirrors for every box, then four bulk uploads (the device already holds these image vectors: same arithmetic)
     for (int b = 0; b < count; ++b) {
-        if (mw_set_cell(first_ils + b, &h[(size_t)b * 9], nullptr)) return 1;
+        const int box = first_ils - 1 + b;
+        std::vector<double> iv;
+        int imv[3] = {1, 1, 1};
+        const int n = host_ivects(&h[(size_t)b * 9], iv, imv);
+        if (n < 0 || n > g.ivcap) return fail("mw_sweep_sync_cells: box %d needs %d image vectors (capacity %d)", box + 1, n, g.ivcap);
+        std::memcpy(&g.h_ivect[(size_t)box * g.ivcap * 3], iv.data(), iv.size() * sizeof(double));
+        g.h_nivect[box] = n;
+        g.h_grid[box] = make_grid(&h[(size_t)b * 9], imv, g.cstride);
+        g.h_usegrid[box] = (!g.force_brute && g.h_grid[box].nc[0] > 0) ? 1 : 0;
+        if (!g.h_usegrid[box]) g.h_grid[box].nc[0] = 0;
         if (h_out) std::memcpy(h_out + (size_t)b * 9, &h[(size_t)b * 9], 9 * sizeof(double));
     }
+    const size_t b0 = (size_t)(first_ils - 1);
+    HIPCHK(hipMemcpyAsync(g.d_ivect + b0 * g.ivcap * 3, &g.h_ivect[b0 * g.ivcap * 3], sizeof(double) * 3 * g.ivcap * count, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.d_nivect + b0, &g.h_nivect[b0], sizeof(int) * count, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.d_grid + b0, &g.h_grid[b0], sizeof(mw::GridDesc) * count, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.d_usegrid + b0, &g.h_usegrid[b0], sizeof(int) * count, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
     return 0;
 }
 
