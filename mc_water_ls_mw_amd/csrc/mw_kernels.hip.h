@@ -1208,7 +1208,7 @@ __device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, 
     return esum;
 }
 
-__device__ __attribute__((noinline))
+__device__ __forceinline__
 int volume_move_wave(const VolCtx& c, const SweepParams& sp, const double* weight, const double* __restrict__ mu_bin,
                      const double* __restrict__ binwidth, double u0, double u1, double u2, double u3,
                      int ls, double& ls_mu, double men[2], int lane)
