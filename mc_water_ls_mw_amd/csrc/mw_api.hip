@@ -82,6 +82,8 @@ struct Ctx {
     double* d_wmu = nullptr;
     unsigned long long* d_wacc = nullptr;
     double* d_swlog = nullptr;
+    unsigned long long list_version = 1, nnmax_version = 0;   // lists rebuilt <-> cached max row length
+    int nnmax_cached = 0;
     size_t swlog_cap = 0;
     // staged moves
     int mcap = 0, mn = 0;
@@ -274,6 +276,7 @@ int launch_model_energy(int first, int count)
 int launch_build(int first, int count)
 {
     const int box0 = first - 1;
+    ++g.list_version;
     // stats: {min, max} per box
     std::vector<int> init((size_t)count * 2);
     for (int b = 0; b < count; ++b) { init[2 * b] = 0x7fffffff; init[2 * b + 1] = 0; }
@@ -1017,13 +1020,16 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
     bool ldslist = false;
     const size_t list_bytes = (size_t)g.sp.nlat * g.N * (32 * sizeof(uint32_t) + sizeof(int));
     if (ldspos && iv_bytes + pos_bytes + list_bytes <= 17 * 1024) {
-        std::vector<int> st((size_t)count * g.sp.nlat * 2);
-        HIPCHK(hipMemcpyAsync(st.data(), g.d_stats + 2 * (size_t)(first_walker - 1) * g.sp.nlat, st.size() * sizeof(int),
-                              hipMemcpyDeviceToHost, g.stream));
-        HIPCHK(hipStreamSynchronize(g.stream));
-        int mx = 0;
-        for (size_t b = 0; b < st.size() / 2; ++b) mx = std::max(mx, st[2 * b + 1]);
-        ldslist = mx <= 32;                          // stats = {min nn, max nn} of the last list build of each box
+        if (g.nnmax_version != g.list_version) {     // once per list rebuild: the longest row of ANY box
+            std::vector<int> st((size_t)g.nbox * 2);
+            HIPCHK(hipMemcpyAsync(st.data(), g.d_stats, st.size() * sizeof(int), hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipStreamSynchronize(g.stream));
+            int mx = 0;
+            for (size_t b = 0; b < st.size() / 2; ++b) mx = std::max(mx, st[2 * b + 1]);
+            g.nnmax_cached = mx;                     // stats = {min nn, max nn} of the last list build of each box
+            g.nnmax_version = g.list_version;
+        }
+        ldslist = g.nnmax_cached <= 32;
     }
     const size_t shmem = iv_bytes + (ldspos ? pos_bytes : 0) + (ldslist ? list_bytes : 0);
     const bool withvol = g.sp.transP < 1.0;          // volume moves: the build that carries the out-of-line mc_volume
