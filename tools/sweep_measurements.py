@@ -60,12 +60,16 @@ def run(name, cells, nlat, walkers, nmoves, out):
     em.energy_deinit()
 
 
+only = os.environ.get("MW_SWEEP_CASE")
 out = {}
 g = lambda n: dict(np.load(os.path.join(ROOT, "tests", "golden", n + ".npz")))  # noqa: E731
 ic48, ih48 = g("ic48"), g("ih48")
-run("pair48 x 8192 walkers", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 8192, 480, out)
+if only in (None, "pair48"):
+    run("pair48 x 8192 walkers", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 8192, 480, out)
 ic1536, ih1536 = g("ic1536"), g("ih1536")
-run("pair1536 x 2048 walkers", [(ic1536["h"], ic1536["xyz"]), (ih1536["h"], ih1536["xyz"])], 2, 2048, 300, out)
+if only in (None, "pair1536"):
+    run("pair1536 x 2048 walkers", [(ic1536["h"], ic1536["xyz"]), (ih1536["h"], ih1536["xyz"])], 2, 2048, 300, out)
 h, x = lat.ice_box("ih", (8, 8, 8), 0.0)
-run("ih4096 x 2048 walkers", [(h, x)], 1, 2048, 300, out)
+if only in (None, "ih4096"):
+    run("ih4096 x 2048 walkers", [(h, x)], 1, 2048, 300, out)
 print(json.dumps(out, indent=1))
