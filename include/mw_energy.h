@@ -66,6 +66,9 @@ int mw_get_ivects(int ils, double *out, int max_vectors, int *nivect_out);
 /* Mirror all positions of box ils: xyz = &ljr(1,1,1,ils), nwater x 3 AoS. */
 int mw_upload_positions(int ils, const double *xyz);
 int mw_download_positions(int ils, double *xyz);
+/* The same for `count` consecutive boxes in one transfer (count x nwater x 3). */
+int mw_upload_positions_range(int first_ils, int count, const double *xyz);
+int mw_download_positions_range(int first_ils, int count, double *xyz);
 /* Mirror one molecule (trial move, silent revert: mc_moves.F90:1079,1186). */
 int mw_patch_position(int ils, int imol, const double r[3]);
 

@@ -530,6 +530,25 @@ int mw_download_positions(int ils, double* xyz)
     return 0;
 }
 
+int mw_upload_positions_range(int first_ils, int count, const double* xyz)
+{
+    if (check_live() || check_range(first_ils, count)) return 1;
+    if (!xyz) return fail("mw_upload_positions_range: null pointer");
+    const size_t per = (size_t)g.N * 3;
+    HIPCHK(hipMemcpyAsync(g.d_pos + (size_t)(first_ils - 1) * per, xyz, per * count * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int mw_download_positions_range(int first_ils, int count, double* xyz)
+{
+    if (check_live() || check_range(first_ils, count)) return 1;
+    const size_t per = (size_t)g.N * 3;
+    HIPCHK(hipMemcpyAsync(xyz, g.d_pos + (size_t)(first_ils - 1) * per, per * count * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
 int mw_patch_position(int ils, int imol, const double r[3])
 {
     if (check_live() || check_box(ils) || check_mol(imol)) return 1;

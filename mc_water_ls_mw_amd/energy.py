@@ -36,6 +36,7 @@ _fp = ctypes.POINTER(ctypes.c_float)
 ABI_SYMBOLS = (
     "mw_init", "mw_finalize", "mw_is_initialised", "mw_last_error", "mw_constants",
     "mw_set_cell", "mw_get_ivects", "mw_upload_positions", "mw_download_positions", "mw_patch_position",
+    "mw_upload_positions_range", "mw_download_positions_range",
     "mw_build_neighbours", "mw_build_neighbours_batch", "mw_get_neighbours",
     "mw_model_energy", "mw_model_energy_batch", "mw_model_energy_counts",
     "mw_model_energy_counts_total", "mw_neighbour_total",

@@ -126,6 +126,50 @@ class WalkerFarm:
             self.em._stale[b] = False       # positions on the device are the authoritative ones here
         return h
 
+    # -- chain synchronisation (mc_check_chain_synchronisation, mc_moves.F90:2217-2416) -------------------------
+    def set_reference(self):
+        """Remember the reference configuration (ref_hmatrix / ref_ljr of init.f90:90,106) from the host's current
+        hmatrix / ljr.  The reference keeps rescaling ref_ljr in every volume move; since that preserves fractional
+        coordinates, the fractional reference positions are kept instead and ref_ljr = hmatrix . s_ref at any time."""
+        self._ref_h = np.array(self.em.hmatrix, dtype=np.float64)
+        self._s_ref = np.einsum("bnd,bdk->bnk", self.em.ljr, np.linalg.inv(self._ref_h))
+
+    def chain_synchronise(self):
+        """Re-impose lattice 2 of every walker from its lattice 1 (rare: every latt_sync_int = 10^4 cycles, so this is
+        host arithmetic over bulk transfers): cell 2 = ref cell 2 + (cell 1 - ref cell 1), molecule positions =
+        reference fractional position + lattice 1's fractional displacement; then image vectors, full-box energies (on
+        the device) and ls_mu."""
+        if self.nlat != 2:
+            raise ValueError("chain synchronisation needs two lattices")
+        if not hasattr(self, "_s_ref"):
+            raise ValueError("call set_reference() at the start of the run")
+        em, nb, n = self.em, self.em.num_lattices, self.em.nwater
+        h = self.sync_cells()                                              # current cells, host mirrors refreshed
+        x = np.zeros((nb, n, 3))
+        em._chk(self.L.mw_download_positions_range(1, nb, x.ctypes.data_as(_dp)))
+        h1, h2_old, r1, r2 = h[0::2], h[1::2], self._ref_h[0::2], self._ref_h[1::2]
+        h2_new = r2 + (h1 - r1)                                            # :2261-2277
+        s1 = np.einsum("bnd,bdk->bnk", x[0::2], np.linalg.inv(h1))         # svect(:,1)
+        ref_ljr2 = np.einsum("bnk,bkd->bnd", self._s_ref[1::2], h2_old)    # ref_ljr(:,2) as the volume moves left it
+        ref_s2 = np.einsum("bnd,bdk->bnk", ref_ljr2, np.linalg.inv(h2_new))   # ref_svect(:,2) in the NEW cell 2
+        s2 = ref_s2 + (s1 - self._s_ref[0::2])                             # :2339
+        x2 = np.einsum("bnk,bkd->bnd", s2, h2_new)                         # :2341
+        self._s_ref[1::2] = ref_s2                                         # ref_ljr(:,2) itself is unchanged: new fractional coords
+        x[1::2] = x2
+        em._chk(self.L.mw_upload_positions_range(1, nb, np.ascontiguousarray(x).ctypes.data_as(_dp)))
+        for w in range(self.nwalkers):
+            em.hmatrix[2 * w + 1] = h2_new[w]
+            em.volume[2 * w + 1] = abs(np.linalg.det(h2_new[w]))
+            em.compute_ivects(2 * w + 2)                                   # :2385-2390
+            em._stale[2 * w + 1] = False
+        em.ljr[:] = x
+        e = em.model_energy_batch(1, nb)                                   # :2395-2396
+        v = em.volume
+        for w in range(self.nwalkers):                                     # :2398-2400
+            mu = e[2 * w] + self.pressure * v[2 * w] - e[2 * w + 1] - self.pressure * v[2 * w + 1]
+            mu = mu * self.beta - n * math.log(v[2 * w] / v[2 * w + 1])
+            self.set_state(w + 1, self.state(w + 1)["ls"], mu)
+
     def tables(self, walker):
         """(weight, histogram, unbiased_hist) of one walker."""
         nb = self.grid.nbins

@@ -205,8 +205,8 @@ class SweepOracle:
         acc, sw = ctypes.c_longlong(0), ctypes.c_longlong(0)
         nvol = np.zeros(2, dtype=np.int64)
         log = np.zeros((nmoves, 8))
-        self.L.mwo_sweep_full(nmoves, ctypes.c_uint64(seed), ctypes.c_uint32(walker), ctypes.c_uint64(move0),
-                              ctypes.c_double(transP), ctypes.c_double(dv_max), st.nlat, st.n, _d(st.xyz), _d(st.h),
+        self.L.mwo_sweep_full_ref(nmoves, ctypes.c_uint64(seed), ctypes.c_uint32(walker), ctypes.c_uint64(move0),
+                              ctypes.c_double(transP), ctypes.c_double(dv_max), st.nlat, st.n, _d(st.xyz), _d(st.ref_xyz), _d(st.h),
                               _d(st.volume), _d(st.ivect), st.ivstride, _i(st.nivect), st.maxneigh, _i(nn), _i(jn), _i(vn),
                               ctypes.c_double(beta), ctypes.c_double(max_trans), ctypes.byref(eta), ctypes.byref(opt),
                               _d(histogram), _d(unbiased_hist), _d(weight), ctypes.byref(lsv), ctypes.byref(mu),
@@ -216,6 +216,18 @@ class SweepOracle:
         st.switches += sw.value
         st.nvol += nvol
         return log
+
+    def chain_sync(self, st, beta, pressure):
+        """mwo_chain_sync on a two-lattice FullSweepState (in place)."""
+        nn = np.ascontiguousarray(np.stack([t[0] for t in st.lists]))
+        jn = np.ascontiguousarray(np.stack([t[1] for t in st.lists]))
+        vn = np.ascontiguousarray(np.stack([t[2] for t in st.lists]))
+        mu = ctypes.c_double(st.ls_mu)
+        rc = self.L.mwo_chain_sync(st.n, _d(st.xyz), _d(st.ref_xyz), _d(st.h), _d(st.ref_h), _d(st.volume), _d(st.ivect),
+                                   st.ivstride, _i(st.nivect), st.maxneigh, _i(nn), _i(jn), _i(vn), ctypes.c_double(beta),
+                                   ctypes.c_double(pressure), ctypes.byref(mu), _d(st.model_energy))
+        assert rc == 0
+        st.ls_mu = mu.value
 
     def cycle(self, nmoves, seed, walker, move0, hs, xs, beta, max_trans, grid, weight, histogram, unbiased_hist,
               eta_interp=True, ls=1, ls_mu=0.0, model_energy=None, lists=None, record=True, samplerun=True,
@@ -278,6 +290,8 @@ class FullSweepState:
         self.ls, self.ls_mu = 1, 0.0
         self.accepted = self.switches = 0
         self.nvol = np.zeros(2, dtype=np.int64)
+        self.ref_xyz = self.xyz.copy()             # ref_ljr (init.f90:106), rescaled by volume moves
+        self.ref_h = self.h.copy()                 # ref_hmatrix (init.f90:90), never changes
 
     def iv(self, l):
         return np.ascontiguousarray(self.ivect[l, :self.nivect[l]])

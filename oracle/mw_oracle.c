@@ -618,6 +618,9 @@ static void rescale_positions(int n, double *xyz, const double *recip, const dou
     }
 }
 
+/* reference positions carried through volume moves (mc_moves.F90:1318-1349, 1461-1492); NULL = not carried */
+static double *g_ref_xyz = NULL;
+
 int mwo_volume_move(const double u[4], int nlat, int n, double *xyz, double *h, double *volume,
                     double *ivect, int ivstride, int *nivect, int maxneigh,
                     const int *nn, const int *jn, const int *vn,
@@ -639,6 +642,7 @@ int mwo_volume_move(const double u[4], int nlat, int n, double *xyz, double *h, 
     for (int l = 0; l < nlat; ++l) for (int t = 0; t < 9; ++t) h[9 * l + t] = h[9 * l + t] + delta[t];   /* :1281-1282 */
     for (int l = 0; l < nlat; ++l) {                                          /* :1285-1358 */
         rescale_positions(n, xyz + (size_t)3 * n * l, recip[l], h + 9 * l);
+        if (g_ref_xyz) rescale_positions(n, g_ref_xyz + (size_t)3 * n * l, recip[l], h + 9 * l);      /* :1318-1349 */
         volume[l] = fabs(det3(h + 9 * l));
         mwo_recipmatrix(h + 9 * l, recip[l]);
         const int niv = mwo_compute_ivects(h + 9 * l, ivect + (size_t)3 * ivstride * l, ivstride);
@@ -668,7 +672,10 @@ int mwo_volume_move(const double u[4], int nlat, int n, double *xyz, double *h, 
         volume[l] = old_vol[l];
         for (int t = 0; t < 9; ++t) h[9 * l + t] = old_h[l][t];
     }
-    for (int l = 0; l < nlat; ++l) rescale_positions(n, xyz + (size_t)3 * n * l, recip[l], h + 9 * l);   /* recip is the NEW one here */
+    for (int l = 0; l < nlat; ++l) {
+        rescale_positions(n, xyz + (size_t)3 * n * l, recip[l], h + 9 * l);   /* recip is the NEW one here */
+        if (g_ref_xyz) rescale_positions(n, g_ref_xyz + (size_t)3 * n * l, recip[l], h + 9 * l);      /* :1461-1492 */
+    }
     for (int l = 0; l < nlat; ++l) {
         const int niv = mwo_compute_ivects(h + 9 * l, ivect + (size_t)3 * ivstride * l, ivstride);       /* :1510-1512 */
         if (niv < 0) return -1;
@@ -721,4 +728,70 @@ void mwo_sweep_full(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0, 
             }
         }
     }
+}
+
+
+void mwo_sweep_full_ref(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0, double transP, double dv_max,
+                        int nlat, int n, double *xyz, double *ref_xyz, double *h, double *volume,
+                        double *ivect, int ivstride, int *nivect, int maxneigh,
+                        const int *nn, const int *jn, const int *vn,
+                        double beta, double max_trans, const mwo_eta *eta, mwo_cycle_opts *opt,
+                        double *histogram, double *unbiased_hist, double *weight,
+                        int *ls, double *ls_mu, double *model_energy,
+                        long long *accepted, long long *switches, long long *nvol, double *log)
+{
+    g_ref_xyz = ref_xyz;
+    mwo_sweep_full(nmoves, seed, walker, move0, transP, dv_max, nlat, n, xyz, h, volume, ivect, ivstride, nivect, maxneigh,
+                   nn, jn, vn, beta, max_trans, eta, opt, histogram, unbiased_hist, weight, ls, ls_mu, model_energy,
+                   accepted, switches, nvol, log);
+    g_ref_xyz = NULL;
+}
+
+/* mc_check_chain_synchronisation, mc_moves.F90:2217-2416 (leshift off) */
+int mwo_chain_sync(int n, double *xyz, const double *ref_xyz, double *h, const double *ref_h, double *volume,
+                   double *ivect, int ivstride, int *nivect, int maxneigh,
+                   const int *nn, const int *jn, const int *vn,
+                   double beta, double pressure, double *ls_mu, double *model_energy)
+{
+    const double invPi = 1.0 / 3.141592653589793238462643383279502884197;
+    double hmat_diff[2][9], recip[2][9];
+    /* :2248-2259: energies and ls_mu of the state as it is (ls_mu is overwritten again at the end) */
+    for (int l = 0; l < 2; ++l)
+        model_energy[l] = mwo_model_energy(n, xyz + (size_t)3 * n * l, ivect + (size_t)3 * ivstride * l, maxneigh,
+                                           nn + (size_t)n * l, jn + (size_t)n * maxneigh * l, vn + (size_t)n * maxneigh * l, NULL);
+    for (int l = 0; l < 2; ++l) for (int t = 0; t < 9; ++t) hmat_diff[l][t] = h[9 * l + t] - ref_h[9 * l + t];   /* :2261-2263 */
+    for (int t = 0; t < 9; ++t) h[9 + t] = ref_h[9 + t] + hmat_diff[0][t];                                        /* :2277 */
+    mwo_recipmatrix(h, recip[0]);                                                                                 /* :2279-2280 */
+    mwo_recipmatrix(h + 9, recip[1]);
+    for (int i = 0; i < n; ++i) {                                                                                 /* :2289-2343 */
+        double svect[2][3], ref_svect[2][3], spos_diff0[3];
+        for (int l = 0; l < 2; ++l) {
+            const double *p = xyz + (size_t)3 * n * l + 3 * i, *q = ref_xyz + (size_t)3 * n * l + 3 * i;
+            const double *rc = recip[l];
+            svect[l][0] = (HM(rc,1,1) * p[0] + HM(rc,2,1) * p[1] + HM(rc,3,1) * p[2]) * 0.5 * invPi;
+            svect[l][1] = (HM(rc,1,2) * p[0] + HM(rc,2,2) * p[1] + HM(rc,3,2) * p[2]) * 0.5 * invPi;
+            svect[l][2] = (HM(rc,1,3) * p[0] + HM(rc,2,3) * p[1] + HM(rc,3,3) * p[2]) * 0.5 * invPi;
+            ref_svect[l][0] = (HM(rc,1,1) * q[0] + HM(rc,2,1) * q[1] + HM(rc,3,1) * q[2]) * 0.5 * invPi;
+            ref_svect[l][1] = (HM(rc,1,2) * q[0] + HM(rc,2,2) * q[1] + HM(rc,3,2) * q[2]) * 0.5 * invPi;
+            ref_svect[l][2] = (HM(rc,1,3) * q[0] + HM(rc,2,3) * q[1] + HM(rc,3,3) * q[2]) * 0.5 * invPi;
+            if (l == 0) for (int d = 0; d < 3; ++d) spos_diff0[d] = svect[0][d] - ref_svect[0][d];
+        }
+        double s2[3];
+        for (int d = 0; d < 3; ++d) s2[d] = ref_svect[1][d] + spos_diff0[d];                                      /* :2339 */
+        double *p2 = xyz + (size_t)3 * n + 3 * i;
+        const double *h2 = h + 9;
+        for (int d = 1; d <= 3; ++d) p2[d - 1] = HM(h2,d,1) * s2[0] + HM(h2,d,2) * s2[1] + HM(h2,d,3) * s2[2];    /* :2341 matmul */
+    }
+    for (int l = 0; l < 2; ++l) {                                                                                 /* :2385-2390 */
+        volume[l] = fabs(det3(h + 9 * l));
+        const int niv = mwo_compute_ivects(h + 9 * l, ivect + (size_t)3 * ivstride * l, ivstride);
+        if (niv < 0) return -1;
+        nivect[l] = niv;
+    }
+    for (int l = 0; l < 2; ++l)                                                                                   /* :2395-2396 */
+        model_energy[l] = mwo_model_energy(n, xyz + (size_t)3 * n * l, ivect + (size_t)3 * ivstride * l, maxneigh,
+                                           nn + (size_t)n * l, jn + (size_t)n * maxneigh * l, vn + (size_t)n * maxneigh * l, NULL);
+    double mu = model_energy[0] + pressure * volume[0] - model_energy[1] - pressure * volume[1];                  /* :2398-2400 */
+    *ls_mu = mu * beta - (double)n * log(volume[0] / volume[1]);
+    return 0;
 }

@@ -183,3 +183,31 @@ void mwo_sweep_full(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0, 
 }
 #endif
 #endif
+
+/* ---- chain synchronisation (mc_check_chain_synchronisation, mc_moves.F90:2217-2416; leshift off) -------- */
+#ifndef MW_ORACLE_CHAIN_H
+#define MW_ORACLE_CHAIN_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Lattice 2 is re-imposed from lattice 1: its cell becomes ref_h(2) + (h(1) - ref_h(1)) and every molecule its
+ * reference fractional position plus lattice 1's fractional displacement; then volumes, image vectors, both full-box
+ * energies (existing lists) and ls_mu are recomputed.  ref_xyz[2][n][3] are the reference positions the volume moves
+ * keep rescaling (mc_moves.F90:1318-1349), ref_h[2][9] the cells the run started from (init.f90:90). */
+int mwo_chain_sync(int n, double *xyz, const double *ref_xyz, double *h, const double *ref_h, double *volume,
+                   double *ivect, int ivstride, int *nivect, int maxneigh,
+                   const int *nn, const int *jn, const int *vn,
+                   double beta, double pressure, double *ls_mu, double *model_energy);
+/* mwo_sweep_full that also carries ref_xyz through the volume moves (NULL: not carried). */
+void mwo_sweep_full_ref(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0, double transP, double dv_max,
+                        int nlat, int n, double *xyz, double *ref_xyz, double *h, double *volume,
+                        double *ivect, int ivstride, int *nivect, int maxneigh,
+                        const int *nn, const int *jn, const int *vn,
+                        double beta, double max_trans, const mwo_eta *eta, mwo_cycle_opts *opt,
+                        double *histogram, double *unbiased_hist, double *weight,
+                        int *ls, double *ls_mu, double *model_energy,
+                        long long *accepted, long long *switches, long long *nvol, double *log);
+#ifdef __cplusplus
+}
+#endif
+#endif

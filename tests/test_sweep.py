@@ -354,3 +354,52 @@ def test_npt_sweep_with_volume_moves_on_device_follows_the_oracle(so, c_oracle, 
                 assert np.allclose(t[0], wt, rtol=1e-10, atol=1e-11) and np.allclose(t[1], hi, rtol=1e-12)
     finally:
         em.energy_deinit()
+
+
+@pytest.mark.gpu
+def test_chain_synchronisation_follows_the_oracle(so, c_oracle):
+    """NPT sweeps with volume moves, then mc_check_chain_synchronisation: the farm (fractional reference positions kept
+    on the host, bulk transfers) against mwo_chain_sync (ref_ljr carried through every volume move), twice in a row."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.energy import load_boxes
+    from mc_water_ls_mw_amd.sweep import MuGrid, WalkerFarm
+    from oracle import FullSweepState
+    z1, z2 = load_golden("ic48"), load_golden("ih48")
+    grid = MuGrid(101, -400.0, 400.0)
+    nw, p_au = 3, 1.0 / 2.90363081e8
+    boxes = []
+    for w in range(nw):
+        boxes += [(z1["h"], lat.thermalise(z1["xyz"], 0.06, 460 + w)), (z2["h"], lat.thermalise(z2["xyz"], 0.06, 480 + w))]
+    em = load_boxes([b[0] for b in boxes], [b[1] for b in boxes])
+    farm = WalkerFarm(em, 2, 200.0, 1.1, grid=grid, weight=np.zeros(101), pressure_au=p_au)
+    try:
+        farm.options(record=True, samplerun=False, always_switch=True, npt=True, wl_factor=0.05)
+        farm.moves(trans_prob=0.5, vol_prob=0.1, dv_max_ang=0.924)
+        farm.set_reference()
+        mus = [farm.initial_mu(w) for w in range(1, nw + 1)]
+        for w in range(1, nw + 1):
+            farm.set_state(w, 1, mus[w - 1])
+        e0 = em.model_energy.copy()
+        sts = []
+        for w in range(nw):
+            st = FullSweepState(c_oracle, [boxes[2 * w][0], boxes[2 * w + 1][0]], [boxes[2 * w][1], boxes[2 * w + 1][1]])
+            st.model_energy[:] = e0[2 * w:2 * w + 2]
+            st.ls_mu = mus[w]
+            st.tabs = (np.zeros(101), np.zeros(101), np.zeros(101))
+            sts.append(st)
+        kw = dict(record=True, samplerun=False, always_switch=True, npt=True, wl_factor=0.05, pressure=p_au)
+        for rnd in range(2):
+            farm.sweep(96, seed=21, move0=96 * rnd)
+            farm.chain_synchronise()
+            hdev = farm.sync_cells()
+            for w, st in enumerate(sts):
+                so.full(st, 96, 21, w, 96 * rnd, farm.transP, farm.dv_max, farm.beta, farm.max_trans, grid, *st.tabs, **kw)
+                so.chain_sync(st, farm.beta, p_au)
+                s = farm.state(w + 1)
+                assert np.abs(hdev[2 * w + 1] - st.h[1]).max() < 1e-10 and np.abs(hdev[2 * w] - st.h[0]).max() < 1e-11
+                assert np.abs(farm.positions(2 * w + 2) - st.xyz[1]).max() < 1e-9
+                assert np.abs(farm.positions(2 * w + 1) - st.xyz[0]).max() < 1e-9
+                assert np.allclose(s["model_energy"], st.model_energy, rtol=0, atol=1e-9)
+                assert abs(s["ls_mu"] - st.ls_mu) < 1e-6 * (1 + abs(st.ls_mu)) and s["ls"] == st.ls
+    finally:
+        em.energy_deinit()

@@ -25,7 +25,7 @@ AUP_TO_ATM = 2.90363081e8
 pytestmark = pytest.mark.skipif(not os.path.exists(RNG), reason="oracle/_ref/mc_water_ref_rng not built")
 
 
-def namelist(num_lattices, temperature, cycles, samplerun, always_switch=False, npt=False, vol_prob=None):
+def namelist(num_lattices, temperature, cycles, samplerun, always_switch=False, npt=False, vol_prob=None, latt_sync=None):
     volume_lines = "allow_vol        = .false." if not npt else f"mc_vol_prob      = {vol_prob}"
     return f"""&potential
 model_type = "mW"
@@ -61,6 +61,7 @@ max_mc_cycles    = {cycles}
 eq_mc_cycles     = 1
 eq_adjust_mc     = .false.
 chkpt_dump_int   = {cycles}
+{'' if latt_sync is None else f'latt_sync_int    = {latt_sync}'}
 timer_qtime      = 172800
 timer_closetime  = 1800
 /
@@ -78,11 +79,11 @@ def read_records(path):
 
 
 def run_reference(d, num_lattices, temperature, cycles, weight=None, grid=None, samplerun=None, always_switch=False,
-                  tables=False, npt=False, vol_prob=None, transP=1.0):
+                  tables=False, npt=False, vol_prob=None, transP=1.0, latt_sync=None):
     from mc_water_ls_mw_amd import lattice as lat
     os.makedirs(d)
     samplerun = (weight is not None) if samplerun is None else samplerun
-    open(os.path.join(d, "ice.input"), "w").write(namelist(num_lattices, temperature, cycles, samplerun, always_switch, npt, vol_prob))
+    open(os.path.join(d, "ice.input"), "w").write(namelist(num_lattices, temperature, cycles, samplerun, always_switch, npt, vol_prob, latt_sync))
     z1 = load_golden("ic48_t015")
     h1, x1 = lat.read_xmol(_write(d, "input001.xmol", z1))
     boxes = [(h1, x1)]
@@ -103,6 +104,7 @@ def run_reference(d, num_lattices, temperature, cycles, weight=None, grid=None, 
     recs = read_records(os.path.join(d, sorted(chk)[-1]))
     ljr = np.frombuffer(recs[-2], dtype="<f8").reshape(num_lattices, 48, 3)      # ljr(3,1,N,L), column-major
     run_reference.hmatrix = np.frombuffer(recs[-4], dtype="<f8").reshape(num_lattices, 3, 3).copy()   # hmatrix(3,3,L)
+    run_reference.ref_ljr = np.frombuffer(recs[-3], dtype="<f8").reshape(num_lattices, 48, 3).copy()
     ls = struct.unpack("<i", recs[-1])[0]
     assert struct.unpack("<i", recs[1])[0] == cycles
     if tables:      # records: nwater, cycle, (max_trans, dv_max), wl_factor, histogram, weight, wl_invt_active, [uhist], ...
@@ -260,3 +262,36 @@ def test_npt_run_with_volume_moves_matches_the_reference_program(tmp_path, so, c
     assert np.abs(st.xyz - ljr).max() < 1e-9 and st.ls == ls                  # ... the same configuration
     assert np.allclose(np.array(energies), e_ref, rtol=2e-6, atol=2e-6)
     assert np.allclose(hi, hist, rtol=1e-12, atol=1e-12) and np.allclose(w, wgt, rtol=1e-10, atol=1e-11)
+
+
+def test_chain_synchronisation_matches_the_reference_program(tmp_path, so, c_oracle):
+    """NPT two-lattice run with latt_sync_int = 5: every fifth cycle the reference re-imposes lattice 2 from lattice 1
+    (mc_check_chain_synchronisation).  The oracle -- volume moves carrying ref_ljr, mwo_chain_sync -- must end at the
+    reference's checkpointed ljr, ref_ljr and cells."""
+    from mc_water_ls_mw_amd.lattice import ANG_TO_BOHR
+    from mc_water_ls_mw_amd.sweep import KB, MuGrid
+    from oracle import FullSweepState
+    grid = MuGrid(101, -400.0, 400.0)
+    vol_prob = 0.1
+    transP = 0.5 / (0.5 + vol_prob)
+    boxes, e_ref, ljr, ls, hist, wgt = run_reference(str(tmp_path / "run"), 2, 200, 30, samplerun=False, always_switch=True,
+                                                     tables=True, npt=True, vol_prob=vol_prob, transP=transP, latt_sync=5)
+    beta, p = 1.0 / (KB * 200.0), 1.0 / AUP_TO_ATM
+    st = FullSweepState(c_oracle, [b[0] for b in boxes], [b[1] for b in boxes])
+    mu = st.model_energy[0] + p * st.volume[0] - st.model_energy[1] - p * st.volume[1]
+    st.ls_mu = mu * beta - 48.0 * np.log(st.volume[0] / st.volume[1])
+    w, hi, uh = np.zeros(101), np.zeros(101), np.zeros(101)
+    energies = []
+    for cyc in range(1, 31):
+        if cyc % 10 == 0:
+            st.rebuild_lists(c_oracle)
+        so.full(st, 48, SEED, 0, (cyc - 1) * 48, transP, 0.924 * ANG_TO_BOHR, beta, 1.1 * ANG_TO_BOHR, grid, w, hi, uh,
+                record=True, samplerun=False, always_switch=True, npt=True, wl_factor=float(np.float32(0.05)), pressure=p)
+        if cyc % 5 == 0:                                       # mc_moves.F90:297-300 (after the moves of the cycle)
+            so.chain_sync(st, beta, p)
+        energies.append(st.model_energy[st.ls - 1] * HART_TO_EV)
+    assert np.abs(st.h - run_reference.hmatrix).max() < 1e-10
+    assert np.abs(st.ref_xyz - run_reference.ref_ljr).max() < 1e-9
+    assert np.abs(st.xyz - ljr).max() < 1e-9 and st.ls == ls
+    assert np.allclose(np.array(energies), e_ref, rtol=2e-6, atol=2e-6)
+    assert np.allclose(w, wgt, rtol=1e-10, atol=1e-11)
