@@ -93,6 +93,66 @@ class WalkerComms:
             a[:] = total[k * self.nbins:(k + 1) * self.nbins] + last
             last[:] = a
 
+    # ---- window domain decomposition ('dd', mc_moves.F90:660-709): every rank samples its own window of the
+    # overlap parameter; the windows are stitched on rank 0 and broadcast.  Collectives instead of the reference's
+    # serial Recv loop: one gather to rank 0 (gather_object of 808-byte arrays is latency, not bandwidth), the
+    # stitching in rank order exactly as the reference does it, one broadcast.
+    def _gather_to_root(self, arr):
+        if not dist.is_initialized() or self.world_size == 1:
+            return [np.array(arr, dtype=np.float64)]
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.device)
+        out = [torch.empty_like(t) for _ in range(self.world_size)]
+        dist.all_gather(out, t, group=self.group)
+        return [o.cpu().numpy() for o in out]
+
+    def _bcast(self, arr):
+        if not dist.is_initialized() or self.world_size == 1:
+            return arr
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.device)
+        dist.broadcast(t, src=0, group=self.group)
+        return t.cpu().numpy()
+
+    def join_eta(self, weight, overlap):
+        """comms_join_eta (comms_mpi.f90:381-459): rank r's window supplies the bins above r*bins_per_window,
+        shifted so that the mean over the 2*overlap+1 bins around the seam agrees; the middle bin is set to 0."""
+        parts = self._gather_to_root(weight)
+        length, size = len(weight), len(parts)
+        bpw = length // size                                           # :399
+        joined = parts[0].copy()                                       # :401
+        for irank in range(1, size):
+            recv = parts[irank]
+            end = irank * bpw                                          # my_end_bin (1-based), :419
+            seam = slice(end - overlap - 1, end + overlap)             # bins end-overlap .. end+overlap
+            shift = joined[seam].sum() / (2 * overlap + 1) - recv[seam].sum() / (2 * overlap + 1)   # :421-429
+            joined[end:] = recv[end:] + shift                          # bins end+1 .. length, :431-433
+        joined = joined - joined[length // 2]                          # :440-443
+        return self._bcast(joined)                                     # :446
+
+    def join_uhist(self, uhist, overlap):
+        """comms_join_uhist (comms_mpi.f90:299-379): the same stitching for the unbiased histogram, in log space."""
+        parts = self._gather_to_root(uhist)
+        length, size = len(uhist), len(parts)
+        bpw = length // size
+        joined = parts[0].copy()
+        for irank in range(1, size):
+            recv = parts[irank]
+            end = irank * bpw
+            seam = slice(end - overlap - 1, end + overlap)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                shift = np.log(joined[seam]).sum() / (2 * overlap + 1) - np.log(recv[seam]).sum() / (2 * overlap + 1)   # :334-346
+            if np.isnan(shift):                                        # :347
+                shift = 0.0
+            joined[end:] = recv[end:] * np.exp(shift)                  # :349-351
+        return self._bcast(joined)
+
+    def get_max(self, value):
+        """comms_get_max (comms_mpi.f90:279-297)."""
+        if not dist.is_initialized() or self.world_size == 1:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
     def barrier(self):                                # comms_barrier, comms_mpi.f90:601-618
         if dist.is_initialized() and self.world_size > 1:
             dist.barrier(group=self.group)

@@ -98,3 +98,42 @@ def test_single_process_is_identity():
     h = np.ones(NBINS)
     c.sync(w, h)
     assert np.array_equal(w, np.arange(NBINS) + 1.0) and np.array_equal(h, np.ones(NBINS))
+
+
+def _dd_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mc_water_ls_mw_amd.comms import WalkerComms
+    c = WalkerComms(NBINS)
+    rng = np.random.default_rng(7 + rank)
+    w = np.cumsum(rng.random(NBINS)) + 10.0 * rank          # each window has its own arbitrary offset
+    u = np.exp(rng.normal(0, 1, NBINS)) * (3.0 ** rank)
+    np.savez(os.path.join(tmp, f"dd{rank}.npz"), w=w, u=u, jw=c.join_eta(w, 2), ju=c.join_uhist(u, 2),
+             mx=c.get_max(float(rank) * 1.5 - 1.0))
+    dist.destroy_process_group()
+
+
+def test_window_join_three_ranks(tmp_path):
+    """'dd' strategy: comms_join_eta / comms_join_uhist / comms_get_max (comms_mpi.f90:279-459) over 3 ranks."""
+    world = 3
+    mp.spawn(_dd_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [dict(np.load(tmp_path / f"dd{k}.npz")) for k in range(world)]
+    bpw, ov = NBINS // world, 2
+    # plain restatement of the reference's serial loop
+    jw, ju = r[0]["w"].copy(), r[0]["u"].copy()
+    for k in range(1, world):
+        end = k * bpw
+        a, b = end - ov - 1, end + ov
+        jw[end:] = r[k]["w"][end:] + (jw[a:b].mean() - r[k]["w"][a:b].mean())
+        ju[end:] = r[k]["u"][end:] * np.exp(np.log(ju[a:b]).mean() - np.log(r[k]["u"][a:b]).mean())
+    jw -= jw[NBINS // 2]
+    for k in range(world):
+        assert np.allclose(r[k]["jw"], jw, rtol=1e-13, atol=1e-13)      # every rank holds the joined function
+        assert np.allclose(r[k]["ju"], ju, rtol=1e-12)
+        assert float(r[k]["mx"]) == 2.0
+    assert jw[NBINS // 2] == 0.0
+    # the seams are continuous in the mean
+    for k in range(1, world):
+        end = k * bpw
+        assert abs(np.diff(jw)[end - 1]) < 5.0
