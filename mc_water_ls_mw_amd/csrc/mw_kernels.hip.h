@@ -745,56 +745,62 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
                                                  int i, double xo, double yo, double zo,
                                                  double xn, double yn, double zn, int lane, MoveRes& res)
 {
-    // ---- pass 0: imol's own row, one slot per lane ----------------------------------------
+    // ---- pass 0: imol's own row; lanes 0..31 take slot l against the OLD position, lanes 32..63 the same
+    // slot against the TRIAL position, so that one rsqrt/reciprocal/exp sequence serves both evaluations.
+    // (Rows longer than 32 entries: the plain routine.)
     const int n_i = nnof(i);
-    const bool has = lane < n_i;
-    const uint32_t e = has ? row(i, lane) : 0u;
+    if (n_i > 32) return false;
+    const int half = lane >> 5, sl = lane & 31;
+    const bool has = sl < n_i;
+    const uint32_t e = has ? row(i, sl) : 0u;
     const int j = (int)(e & kJMask), kimg = (int)(e >> kJBits);
     double xj, yj, zj, jvx, jvy, jvz;
     getpos(j, xj, yj, zj);
     getiv(kimg, jvx, jvy, jvz);
     const int nnj = has ? nnof(j) : 0;
     const double qx = xj + jvx, qy = yj + jvy, qz = zj + jvz;                 // molint.F90:269
-    const double aox = qx - xo, aoy = qy - yo, aoz = qz - zo;                 // :272 (old position)
-    const double anx = qx - xn, any_ = qy - yn, anz = qz - zn;                //      (trial position)
-    const double r2o = aox * aox + aoy * aoy + aoz * aoz;
-    const double r2n = anx * anx + any_ * any_ + anz * anz;
-    const bool ino = has && (r2o < kRcSq), inn = has && (r2n < kRcSq);        // :276
-    const bool inu = ino || inn;
-    const unsigned long long U = __ballot(inu);
-    const int cntU = __popcll(U);
+    const double rix = half ? xn : xo, riy = half ? yn : yo, riz = half ? zn : zo;
+    const double ax = qx - rix, ay = qy - riy, az = qz - riz;                 // :272
+    const double r2 = ax * ax + ay * ay + az * az;
+    const bool in = has && (r2 < kRcSq);                                      // :276
+    const unsigned long long B = __ballot(in);
+    const unsigned int mo_ = (unsigned int)B, mn_ = (unsigned int)(B >> 32);  // in range of the old / trial position, by slot
+    const unsigned int U = mo_ | mn_;
+    const int cntU = __popc(U);
     if (cntU > kCap) return false;
 
-    double rinvo = 0.0, e1o = 0.0, go = 0.0, rinvn = 0.0, e1n = 0.0, gn = 0.0;
-    if (ino) pair_terms(r2o, rinvo, e1o, go);
-    if (inn) pair_terms(r2n, rinvn, e1n, gn);
-    const double qo = kSigSq * rinvo * rinvo, qn = kSigSq * rinvn * rinvn;
-    double acco = ino ? (kAeps * (kBigB * (qo * qo) - 1.0)) * e1o : 0.0;      // :294-297
-    double accn = inn ? (kAeps * (kBigB * (qn * qn) - 1.0)) * e1n : 0.0;
+    double rinv = 0.0, e1 = 0.0, g = 0.0;
+    if (in) pair_terms(r2, rinv, e1, g);
+    const double qq = kSigSq * rinv * rinv;
+    const double accp = in ? (kAeps * (kBigB * (qq * qq) - 1.0)) * e1 : 0.0;  // :294-297 (old in lanes 0..31, trial in 32..63)
     double t3o = 0.0, t3n = 0.0;
     unsigned int nto = 0, ntn = 0;
 
-    // ---- compact the in-range neighbours into the wave's scratch ----------------------------
-    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(U >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)U, 0u));
+    // ---- compact the in-range neighbours (of either position) into the wave's scratch ------------
+    const bool inu = (U >> sl) & 1u;
+    const int rank = __popc(U & ((1u << sl) - 1u));
     // first slot of every in-range j's row in the end-to-end numbering: a scalar walk over the set
     // bits (row lengths via v_readlane, sums on the scalar unit), plus the list slots each evaluation visits
-    const unsigned long long mo_ = __ballot(ino), mn_ = __ballot(inn);
     int start = 0, T = 0;
     unsigned int so = (unsigned int)n_i, sn = (unsigned int)n_i;
-    for (unsigned long long m = U; m;) {
-        const int jl = __ffsll((long long)m) - 1;
-        m &= m - 1ull;
+    for (unsigned int m = U; m;) {
+        const int jl = __ffs((int)m) - 1;
+        m &= m - 1u;
         const int nj = __builtin_amdgcn_readlane(nnj, jl);
-        if (lane == jl) start = T;
+        if (sl == jl) start = T;
         T += nj;
-        if ((mo_ >> jl) & 1ull) so += (unsigned int)nj;
-        if ((mn_ >> jl) & 1ull) sn += (unsigned int)nj;
+        if ((mo_ >> jl) & 1u) so += (unsigned int)nj;
+        if ((mn_ >> jl) & 1u) sn += (unsigned int)nj;
     }
     if (inu) {
-        ws->q[0][rank] = qx; ws->q[1][rank] = qy; ws->q[2][rank] = qz;
-        ws->rinvo[rank] = rinvo; ws->rinvn[rank] = rinvn; ws->go[rank] = go; ws->gn[rank] = gn;
-        ws->j[rank] = j; ws->kimg[rank] = kimg; ws->flag[rank] = (ino ? 1 : 0) | (inn ? 2 : 0);
-        ws->start[rank] = start;
+        if (half == 0) {
+            ws->q[0][rank] = qx; ws->q[1][rank] = qy; ws->q[2][rank] = qz;
+            ws->rinvo[rank] = rinv; ws->go[rank] = g;
+            ws->j[rank] = j; ws->kimg[rank] = kimg; ws->flag[rank] = (int)((mo_ >> sl) & 1u) | (int)(((mn_ >> sl) & 1u) << 1);
+            ws->start[rank] = start;
+        } else {
+            ws->rinvn[rank] = rinv; ws->gn[rank] = g;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -920,7 +926,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     if (nq > 0) flush();
     __builtin_amdgcn_wave_barrier();                          // scratch is reused by the wave's next request
 
-    double eo = acco + kLamEps * t3o, en = accn + kLamEps * t3n;                 // :397
+    double eo = (half == 0 ? accp : 0.0) + kLamEps * t3o, en = (half == 1 ? accp : 0.0) + kLamEps * t3n;   // :397
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         eo += __shfl_xor(eo, off, 64);
@@ -929,7 +935,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         ntn += (unsigned int)__shfl_xor((int)ntn, off, 64);
     }
     res.eo = eo; res.en = en;
-    res.io = (unsigned int)__popcll(mo_) + nto; res.in_ = (unsigned int)__popcll(mn_) + ntn;
+    res.io = (unsigned int)__popc(mo_) + nto; res.in_ = (unsigned int)__popc(mn_) + ntn;
     res.so = so; res.sn = sn;
     return true;
 }
