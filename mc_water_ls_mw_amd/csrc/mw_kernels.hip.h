@@ -81,23 +81,32 @@ __device__ __forceinline__ double fast_rcp(double x)
     return __builtin_fma(y, __builtin_fma(e, e, e), y);             // y (1 + e + e^2)
 }
 
+// d = a*b + c with c in a scalar register pair: the three-address v_fma_f64.  (Left to itself the
+// compiler keeps the Horner coefficients in VGPRs and emits v_mov_b64 + v_fmac_f64 per step.)
+__device__ __forceinline__ double fma_sc(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+
 // exp(x) for x <= 0 (any magnitude; underflows smoothly to 0).  n = round(x log2 e),
 // r = x - n ln2 in two pieces, degree-11 Taylor on |r| <= 0.347 (remainder < 7e-15), 2^n by ldexp.
 __device__ __forceinline__ double fast_exp_neg(double x)
 {
-    x = x < -800.0 ? -800.0 : x;                                    // exp(-800) == 0 in double anyway
+    x = __builtin_fmax(x, -800.0);                                  // exp(-800) == 0 in double anyway
     const double n = __builtin_rint(x * 1.4426950408889634);
     double r = __builtin_fma(n, -6.93147180369123816490e-01, x);    // ln2 high part (fdlibm split)
     r = __builtin_fma(n, -1.90821492927058770002e-10, r);           // ln2 low part
     double p = 2.50521083854417187751e-08;                           // 1/11!
-    p = __builtin_fma(p, r, 2.75573192239858906526e-07);             // 1/10!
-    p = __builtin_fma(p, r, 2.75573192239858906526e-06);             // 1/9!
-    p = __builtin_fma(p, r, 2.48015873015873015873e-05);             // 1/8!
-    p = __builtin_fma(p, r, 1.98412698412698412698e-04);             // 1/7!
-    p = __builtin_fma(p, r, 1.38888888888888888889e-03);             // 1/6!
-    p = __builtin_fma(p, r, 8.33333333333333333333e-03);             // 1/5!
-    p = __builtin_fma(p, r, 4.16666666666666666667e-02);             // 1/4!
-    p = __builtin_fma(p, r, 1.66666666666666666667e-01);             // 1/3!
+    p = fma_sc(p, r, 2.75573192239858906526e-07);                    // 1/10!
+    p = fma_sc(p, r, 2.75573192239858906526e-06);                    // 1/9!
+    p = fma_sc(p, r, 2.48015873015873015873e-05);                    // 1/8!
+    p = fma_sc(p, r, 1.98412698412698412698e-04);                    // 1/7!
+    p = fma_sc(p, r, 1.38888888888888888889e-03);                    // 1/6!
+    p = fma_sc(p, r, 8.33333333333333333333e-03);                    // 1/5!
+    p = fma_sc(p, r, 4.16666666666666666667e-02);                    // 1/4!
+    p = fma_sc(p, r, 1.66666666666666666667e-01);                    // 1/3!
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
@@ -459,10 +468,9 @@ __device__ __forceinline__ AtomSum atom_energy(int i, int n, const uint32_t* __r
         const double dx = (xj + ix) - xi, dy = (yj + iy) - yi, dz = (zj + iz) - zi;
         const double r2 = dx * dx + dy * dy + dz * dz;
         const double rinv = fast_rsqrt(r2);
-        const double r = r2 * rinv;
-        const double den = r - kSigA;               // < 0 inside the cutoff
+        const double den = fma_sc(r2, rinv, -kSigA);   // r - a sigma: < 0 inside the cutoff
         // r2 < rc^2 but r rounded onto rc: the pair's energy is exactly 0 in the limit
-        const double w = den < 0.0 ? fast_rcp(den) : -1.0e300;
+        const double w = fast_rcp(__builtin_fmin(den, -1.0e-300));
         const double t = fast_exp_neg(0.2 * kSigma * w);
         const double t2 = t * t, t4 = t2 * t2;
         const double e1 = t4 * t;                   // exp(sigma/(r - a sigma))       :459
@@ -514,10 +522,11 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
     const int* NN = nn + (size_t)b * N;
     const int niv = nivect[b];
 
-    // dynamic LDS: [in-range queue kQCap x BLOCK u32][image vectors][positions when LDSPOS]
-    uint32_t* queue = reinterpret_cast<uint32_t*>(smem) + tid;
-    double* siv = smem + ((size_t)kQCap * BLOCK * sizeof(uint32_t)) / sizeof(double);
-    double* spos = siv + (size_t)ivcap * 3;
+    // dynamic LDS: [positions when LDSPOS][image vectors][in-range queue kQCap x BLOCK u32]; the positions
+    // sit at offset 0 so that a gather's address is one multiply and the ds_read offsets are immediates.
+    double* spos = smem;
+    double* siv = smem + (LDSPOS ? 3 * (size_t)N : 0);
+    uint32_t* queue = reinterpret_cast<uint32_t*>(siv + (size_t)ivcap * 3) + tid;
     for (int t = tid; t < niv * 3; t += BLOCK) siv[t] = IV[t];
     if (LDSPOS) {
         for (int t = tid; t < 3 * N; t += BLOCK) spos[t] = P[t];   // flat, fully coalesced copy
@@ -612,10 +621,9 @@ __device__ __forceinline__ void load_pos(const double* __restrict__ P, int j, co
 __device__ __forceinline__ void pair_terms(double r2, double& rinv, double& e1, double& g)
 {
     rinv = fast_rsqrt(r2);                       // molint.F90:278
-    const double r = r2 * rinv;                  // :286
-    const double den = r - kSigA;
+    const double den = fma_sc(r2, rinv, -kSigA); // r - a sigma, r = r2 / sqrt(r2)        :286
     // r2 < rc^2 but r rounded onto rc: the term is exactly 0 in that limit          :288
-    const double w = den < 0.0 ? fast_rcp(den) : -1.0e300;
+    const double w = fast_rcp(__builtin_fmin(den, -1.0e-300));
     const double t = fast_exp_neg(0.2 * kSigma * w);
     const double t2 = t * t, t4 = t2 * t2;
     e1 = t4 * t;                                 // :291
@@ -965,10 +973,11 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
     const int* NN = nn + (size_t)b * N;
     const int niv = nivect[b];
 
-    // dynamic LDS: [16 wave scratches][image vectors][positions]
-    WaveScratch* ws = reinterpret_cast<WaveScratch*>(smem) + wave;
-    double* siv = smem + (16 * sizeof(WaveScratch)) / sizeof(double);
-    double* spos = siv + (size_t)ivcap * 3;
+    // dynamic LDS: [positions when LDSPOS][image vectors][16 wave scratches] (positions at offset 0: a gather's
+    // address is one multiply and the ds_read offsets are immediates)
+    double* spos = smem;
+    double* siv = smem + (LDSPOS ? 3 * (size_t)N : 0);
+    WaveScratch* ws = reinterpret_cast<WaveScratch*>(siv + (size_t)ivcap * 3) + wave;
     for (int t = tid; t < niv * 3; t += 1024) siv[t] = IV[t];
     if (LDSPOS) {
         for (int t = tid; t < 3 * N; t += 1024) spos[t] = P[t];
