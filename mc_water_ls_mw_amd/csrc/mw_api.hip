@@ -115,7 +115,7 @@ bool lds_fits(int N, int ivcap)
 constexpr size_t kMoveScratch = 16 * sizeof(mw::WaveScratch);
 bool lds_fits_move(int N, int ivcap)
 {
-    return kMoveScratch + (size_t)(3 * (size_t)N + 3 * (size_t)ivcap) * sizeof(double) <= (size_t)kLdsBudget;
+    return kMoveScratch + (size_t)(3 * (size_t)N + 3 * (size_t)ivcap) * sizeof(double) + (((size_t)N + 7) & ~(size_t)7) <= (size_t)kLdsBudget;
 }
 
 int check_live() { return g.live ? 0 : fail("mw: engine not initialised (call mw_init / energy_init first)"); }
@@ -729,7 +729,8 @@ static int launch_moves(int mode)
     if (g.mn == 0) return 0;
     const size_t iv_bytes = kMoveScratch + (size_t)3 * g.ivcap * sizeof(double);
     if (g.mlds)
-        hipLaunchKernelGGL(mw::k_move_energy<true>, dim3(g.mwork_n), dim3(1024), iv_bytes + (size_t)3 * g.N * sizeof(double), g.stream,
+        hipLaunchKernelGGL(mw::k_move_energy<true>, dim3(g.mwork_n), dim3(1024),
+                           iv_bytes + (size_t)3 * g.N * sizeof(double) + (((size_t)g.N + 7) & ~(size_t)7), g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
                            g.d_meold, g.d_menew, g.d_mcnt, g.N, g.ivcap, mode);
     else

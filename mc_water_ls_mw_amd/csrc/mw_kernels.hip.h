@@ -737,8 +737,8 @@ struct WaveScratch {
     double q[3][kCap];                         // position of j's image            (molint.F90:269)
     double rinvo[kCap], rinvn[kCap];           // 1/r_ij at the old / trial position
     double go[kCap], gn[kCap];                 // exp(gamma sigma/(r_ij - a sigma)) old / trial
-    int j[kCap], kimg[kCap], flag[kCap];       // molecule, image, bit0 = in range (old), bit1 = (trial)
-    int start[kCap + 2];                       // first slot of j's row in the end-to-end numbering
+    int j[kCap], kimg[kCap], flag[kCap];       // molecule, image | inverse image << 16, bit0 = in range (old), bit1 = (trial)
+    unsigned long long cm[kCap];               // bit p of the end-to-end slot numbering set: a row ends at slot p
     uint32_t qe[64];                           // queue of in-range third bodies: packed list entry ...
     int qown[64];                              // ... and the rank of the neighbour j whose row it came from
 };
@@ -749,19 +749,21 @@ static_assert(sizeof(WaveScratch) % 8 == 0, "scratch records must keep 8-byte al
 // list) or, for small systems in the sweep driver, LDS copies.
 template <typename PosFn, typename IvFn, typename RowFn, typename NnFn>
 __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn row, NnFn nnof,
-                                                 WaveScratch* __restrict__ ws,
-                                                 int i, double xo, double yo, double zo,
+                                                 WaveScratch* __restrict__ ws, int niv,
+                                                 int i, int n_i, uint32_t e,
+                                                 double xo, double yo, double zo,
                                                  double xn, double yn, double zn, int lane, MoveRes& res)
 {
     // ---- pass 0: imol's own row; lanes 0..31 take slot l against the OLD position, lanes 32..63 the same
     // slot against the TRIAL position, so that one rsqrt/reciprocal/exp sequence serves both evaluations.
-    // (Rows longer than 32 entries: the plain routine.)
-    const int n_i = nnof(i);
+    // `e` arrives as entry (lane & 31) of imol's row, fetched by the caller ahead of time (whatever the row
+    // length: rows are padded).  Rows longer than 32 entries take the plain routine, and so does a molecule
+    // that neighbours one of its own periodic images.
     if (n_i > 32) return false;
     const int half = lane >> 5, sl = lane & 31;
     const bool has = sl < n_i;
-    const uint32_t e = has ? row(i, sl) : 0u;
-    const int j = (int)(e & kJMask), kimg = (int)(e >> kJBits);
+    const int j = has ? (int)(e & kJMask) : 0, kimg = has ? (int)(e >> kJBits) : 0;
+    if (__ballot(has && j == i) != 0ull) return false;
     double xj, yj, zj, jvx, jvy, jvz;
     getpos(j, xj, yj, zj);
     getiv(kimg, jvx, jvy, jvz);
@@ -787,25 +789,42 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     // ---- compact the in-range neighbours (of either position) into the wave's scratch ------------
     const bool inu = (U >> sl) & 1u;
     const int rank = __popc(U & ((1u << sl) - 1u));
-    // first slot of every in-range j's row in the end-to-end numbering: a scalar walk over the set
-    // bits (row lengths via v_readlane, sums on the scalar unit), plus the list slots each evaluation visits
-    int start = 0, T = 0;
-    unsigned int so = (unsigned int)n_i, sn = (unsigned int)n_i;
-    for (unsigned int m = U; m;) {
-        const int jl = __ffs((int)m) - 1;
-        m &= m - 1u;
-        const int nj = __builtin_amdgcn_readlane(nnj, jl);
-        if (sl == jl) start = T;
-        T += nj;
-        if ((mo_ >> jl) & 1u) so += (unsigned int)nj;
-        if ((mn_ >> jl) & 1u) sn += (unsigned int)nj;
-    }
+    // The rows of the in-range j are laid end to end (slots 0..T-1).  An inclusive prefix sum over the 32
+    // slot lanes of each half gives every j its first slot, and in its upper 16 bits the list slots each
+    // evaluation visits (half 0: old position, half 1: trial position).
+    const int mine = (inu ? nnj : 0) | ((in ? nnj : 0) << 16);
+    int inc = mine;
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);        // row_shr:1
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);        // row_shr:2
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);        // row_shr:4
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);        // row_shr:8
+    const int r15 = __builtin_amdgcn_readlane(inc, 15), r47 = __builtin_amdgcn_readlane(inc, 47);
+    inc += (lane & 16) ? (half ? r47 : r15) : 0;
+    const int tot0 = __builtin_amdgcn_readlane(inc, 31), tot1 = __builtin_amdgcn_readlane(inc, 63);
+    const int T = tot0 & 0xffff;
+    const unsigned int so = (unsigned int)n_i + (unsigned int)(tot0 >> 16), sn = (unsigned int)n_i + (unsigned int)(tot1 >> 16);
+    const int start = (inc & 0xffff) - (inu ? nnj : 0);
+    // lane r of these two holds, for the in-range neighbour of rank r, its molecule and the first slot of
+    // its row: the scan below locates a slot's owner from registers alone (no LDS round trips in front of
+    // the row fetch).  Lanes that own no record aim at lane 63, which no rank reaches (cntU <= kCap).
+    const int dstl = (inu && half == 0) ? rank : 63;
+    const int jv  = __builtin_amdgcn_ds_permute(dstl << 2, j);
+    const int stv = __builtin_amdgcn_ds_permute(dstl << 2, start);
+    // the image that undoes `kimg`: cells are numbered centre first, then lexicographically without the
+    // centre (compute_ivects, molint.F90:174-217), so the opposite cell is the mirror position
+    const int cc = (niv - 1) >> 1;
+    const int lin = kimg <= cc ? kimg - 1 : kimg, linv = niv - 1 - lin;
+    const int kinv = kimg == 0 ? 0 : (linv < cc ? linv + 1 : linv);
+    // row-end marks: chunk c of the scan reads mask cm[c]; a slot's owner is the number of marks before it
+    if (lane < kCap) ws->cm[lane] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (inu && half == 0 && rank > 0 && start > 0)      // (rows are never empty: j lists i back)
+        __hip_atomic_fetch_or(&ws->cm[(start - 1) >> 6], 1ull << ((start - 1) & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     if (inu) {
         if (half == 0) {
             ws->q[0][rank] = qx; ws->q[1][rank] = qy; ws->q[2][rank] = qz;
             ws->rinvo[rank] = rinv; ws->go[rank] = g;
-            ws->j[rank] = j; ws->kimg[rank] = kimg; ws->flag[rank] = (int)((mo_ >> sl) & 1u) | (int)(((mn_ >> sl) & 1u) << 1);
-            ws->start[rank] = start;
+            ws->j[rank] = j; ws->kimg[rank] = kimg | (kinv << 16); ws->flag[rank] = (int)((mo_ >> sl) & 1u) | (int)(((mn_ >> sl) & 1u) << 1);
         } else {
             ws->rinvn[rank] = rinv; ws->gn[rank] = g;
         }
@@ -854,7 +873,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
             const uint32_t e2 = ws->qe[lane];
             const int own = ws->qown[lane];
             const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
-            const int kj = ws->kimg[own], fl = ws->flag[own];
+            const int kj = ws->kimg[own] & 0xffff, fl = ws->flag[own];
             double xk, yk, zk, kvx, kvy, kvz, sjx, sjy, sjz;
             getpos(kk, xk, yk, zk);
             getiv(k2, kvx, kvy, kvz);
@@ -878,17 +897,29 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         __builtin_amdgcn_wave_barrier();
         nq = 0;
     };
+    // The slot -> (owner, row entry) fetch runs ONE CHUNK AHEAD of the chunk being evaluated, so the row
+    // fetch (global memory for the big boxes) is in flight while the previous chunk is worked on.
+    int nbefore = 0;                                         // row ends in the chunks already fetched (wave-uniform)
+    auto fetch = [&](int t, int& own, uint32_t& ent) {
+        const unsigned long long M = ws->cm[t >> 6];         // one address for the whole wave
+        const unsigned int mlo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)M);
+        const unsigned int mhi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(M >> 32));
+        own = nbefore + (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        nbefore += __popc(mlo) + __popc(mhi);
+        const int jj = __builtin_amdgcn_ds_bpermute(own << 2, jv);
+        const int st = __builtin_amdgcn_ds_bpermute(own << 2, stv);
+        ent = t < T ? row(jj, t - st) : 0u;
+    };
+    int own_nx = 0; uint32_t ent_nx = 0u;
+    if (T > 0) fetch(lane, own_nx, ent_nx);
     for (int t0 = 0; t0 < T; t0 += 64) {
         const int t = t0 + lane;
         const bool valid = t < T;
-        int own = 0;                                         // largest r with start[r] <= t
-#pragma unroll
-        for (int step = 16; step > 0; step >>= 1) {
-            const int cand = own + step;
-            if (cand < cntU && ws->start[cand < kCap ? cand : kCap - 1] <= t) own = cand;
-        }
-        const int jj = ws->j[own], kj = ws->kimg[own];
-        const uint32_t e2 = valid ? row(jj, t - ws->start[own]) : 0u;
+        const int own = own_nx;
+        const uint32_t e2 = ent_nx;
+        if (t0 + 64 < T) fetch(t + 64, own_nx, ent_nx);
+        const int kjp = ws->kimg[own];
+        const int kj = kjp & 0xffff;
         const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
         double xk, yk, zk, kvx, kvy, kvz, sjx, sjy, sjz;
         getpos(kk, xk, yk, zk);
@@ -896,7 +927,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         getiv(kj, sjx, sjy, sjz);
         const double pjx = ws->q[0][own], pjy = ws->q[1][own], pjz = ws->q[2][own];
         const bool self = valid && (kk == i);
-        const bool selfimg = self && (kvx + sjx == 0.0) && (kvy + sjy == 0.0) && (kvz + sjz == 0.0);
+        const bool selfimg = self && (k2 == (kjp >> 16));   // the molecule itself, not an image: k's shift undoes j's
         const bool selfmove = self && !selfimg;
         const double box_ = ((xk + kvx) + sjx) - pjx;                            // :332,334
         const double boy_ = ((yk + kvy) + sjy) - pjy;
@@ -973,14 +1004,16 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
     const int* NN = nn + (size_t)b * N;
     const int niv = nivect[b];
 
-    // dynamic LDS: [positions when LDSPOS][image vectors][16 wave scratches] (positions at offset 0: a gather's
-    // address is one multiply and the ds_read offsets are immediates)
+    // dynamic LDS: [positions when LDSPOS][image vectors][16 wave scratches][row lengths, one byte each, when
+    // LDSPOS] (positions at offset 0: a gather's address is one multiply and the ds_read offsets are immediates)
     double* spos = smem;
     double* siv = smem + (LDSPOS ? 3 * (size_t)N : 0);
     WaveScratch* ws = reinterpret_cast<WaveScratch*>(siv + (size_t)ivcap * 3) + wave;
+    unsigned char* snn = reinterpret_cast<unsigned char*>(reinterpret_cast<WaveScratch*>(siv + (size_t)ivcap * 3) + 16);
     for (int t = tid; t < niv * 3; t += 1024) siv[t] = IV[t];
     if (LDSPOS) {
         for (int t = tid; t < 3 * N; t += 1024) spos[t] = P[t];
+        for (int t = tid; t < N; t += 1024) snn[t] = (unsigned char)NN[t];      // maxneigh <= 64
     }
     __syncthreads();
 
@@ -989,23 +1022,31 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
         const double* p = LDSPOS ? (spos + 3 * (size_t)jx) : (P + 3 * (size_t)jx);
         x = p[0]; y = p[1]; z = p[2];
     };
+    auto row = [&](int jx, int sl) { return LM[(size_t)jx * kRow + sl]; };
+    auto nnof = [&](int jx) { return LDSPOS ? (int)snn[jx] : NN[jx]; };
 
-    for (int m = w.y + wave; m < w.z; m += 16) {
-        const int i = req_imol[m];
+    // The wave's requests are m = w.y + wave + 16 k.  Lane k fetches request k's molecule (and trial position)
+    // up front; entry (lane & 31) of the molecule's own row is then fetched one request ahead of the one being
+    // evaluated, so no request starts by waiting on memory.
+    const int nmine = (w.z - w.y - wave + 15) / 16;                          // <= 64 (work items hold <= 1024 requests)
+    const int mk = w.y + wave + 16 * lane;
+    const int iall = lane < nmine ? req_imol[mk] : 0;
+    double tx = 0.0, ty = 0.0, tz = 0.0;
+    if ((mode & 2) && lane < nmine) { tx = req_trial[3 * (size_t)mk]; ty = req_trial[3 * (size_t)mk + 1]; tz = req_trial[3 * (size_t)mk + 2]; }
+    uint32_t e_nx = nmine > 0 ? row(__builtin_amdgcn_readfirstlane(iall), lane & 31) : 0u;
+
+    for (int k = 0; k < nmine; ++k) {
+        const int m = w.y + wave + 16 * k;
+        const int i = __builtin_amdgcn_readlane(iall, k);
+        const uint32_t e = e_nx;
+        if (k + 1 < nmine) e_nx = row(__builtin_amdgcn_readlane(iall, k + 1), lane & 31);
         double xo, yo, zo;
         getpos(i, xo, yo, zo);
         double xn = xo, yn = yo, zn = zo;
-        if (mode & 2) { xn = req_trial[3 * (size_t)m]; yn = req_trial[3 * (size_t)m + 1]; zn = req_trial[3 * (size_t)m + 2]; }
-
-        // does the molecule neighbour one of its own periodic images?  (wave-uniform)
-        const int n_i = NN[i];
-        const uint32_t e = lane < n_i ? LM[(size_t)i * kRow + lane] : 0xffffffffu;
-        const bool ownimage = __ballot((int)(e & kJMask) == i && lane < n_i) != 0ull;
+        if (mode & 2) { xn = readlane_f64(tx, k); yn = readlane_f64(ty, k); zn = readlane_f64(tz, k); }
 
         MoveRes r;
-        auto row = [&](int jx, int sl) { return LM[(size_t)jx * kRow + sl]; };
-        auto nnof = [&](int jx) { return NN[jx]; };
-        const bool fast = !ownimage && move_energy_wave(getpos, getiv, row, nnof, ws, i, xo, yo, zo, xn, yn, zn, lane, r);
+        const bool fast = move_energy_wave(getpos, getiv, row, nnof, ws, niv, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r);
         if (!fast) {
             Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
             Override tr; tr.idx = i; tr.x = xn; tr.y = yn; tr.z = zn;
@@ -1478,12 +1519,9 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
             const int* SN = snn + l * N;
             auto row = [&](int jx, int sl) { return LDSLIST ? SR[jx * 32 + sl] : LM[(size_t)jx * kRow + sl]; };
             auto nnof = [&](int jx) { return LDSLIST ? SN[jx] : NN[jx]; };
-            const int n_i = nnof(i);
-            const uint32_t e = lane < n_i ? row(i, lane) : 0xffffffffu;
-            const bool ownimage = __ballot((int)(e & kJMask) == i && lane < n_i) != 0ull;
             MoveRes res;
-            const bool fast = !ownimage && move_energy_wave(getpos, getiv, row, nnof, &ws, i, xo, yo, zo,
-                                                            pn[l][0], pn[l][1], pn[l][2], lane, res);
+            const bool fast = move_energy_wave(getpos, getiv, row, nnof, &ws, sniv[l], i, nnof(i), row(i, lane & 31), xo, yo, zo,
+                                               pn[l][0], pn[l][1], pn[l][2], lane, res);
             if (!fast) {
                 Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
                 Override tr; tr.idx = i; tr.x = pn[l][0]; tr.y = pn[l][1]; tr.z = pn[l][2];
