@@ -114,6 +114,36 @@ __device__ __forceinline__ double fast_exp_neg(double x)
 }
 
 // ---- wave / block reductions ---------------------------------------------------------
+// Inclusive prefix sums over the 64 lanes through the DPP network: four shifts inside each row of 16
+// lanes, then lane 15 of a row into the next row and lane 31 into the upper half.  Lane 63 ends up with
+// the wave's total (summation order: a fixed tree, the same for every call).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_wave_sum(double v)
+{
+    v += dpp_mov_f64<0x111, 0xf>(v);      // row_shr:1
+    v += dpp_mov_f64<0x112, 0xf>(v);      // row_shr:2
+    v += dpp_mov_f64<0x114, 0xf>(v);      // row_shr:4
+    v += dpp_mov_f64<0x118, 0xf>(v);      // row_shr:8
+    v += dpp_mov_f64<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v += dpp_mov_f64<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int dpp_wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+    return v;
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -965,14 +995,11 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     if (nq > 0) flush();
     __builtin_amdgcn_wave_barrier();                          // scratch is reused by the wave's next request
 
-    double eo = (half == 0 ? accp : 0.0) + kLamEps * t3o, en = (half == 1 ? accp : 0.0) + kLamEps * t3n;   // :397
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        eo += __shfl_xor(eo, off, 64);
-        en += __shfl_xor(en, off, 64);
-        nto += (unsigned int)__shfl_xor((int)nto, off, 64);
-        ntn += (unsigned int)__shfl_xor((int)ntn, off, 64);
-    }
+    // Wave sums on the DPP network (no LDS round trips): afterwards lane 63 holds the totals.
+    const double eo = readlane_f64(dpp_wave_sum(kLamEps * t3o + (half == 0 ? accp : 0.0)), 63);   // :397
+    const double en = readlane_f64(dpp_wave_sum(kLamEps * t3n + (half == 1 ? accp : 0.0)), 63);
+    const unsigned int cs = (unsigned int)__builtin_amdgcn_readlane(dpp_wave_sum_i32((int)(nto | (ntn << 16))), 63);
+    nto = cs & 0xffffu; ntn = cs >> 16;
     res.eo = eo; res.en = en;
     res.io = (unsigned int)__popc(mo_) + nto; res.in_ = (unsigned int)__popc(mn_) + ntn;
     res.so = so; res.sn = sn;
