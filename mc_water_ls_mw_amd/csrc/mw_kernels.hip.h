@@ -767,10 +767,10 @@ struct WaveScratch {
     double q[3][kCap];                         // position of j's image            (molint.F90:269)
     double rinvo[kCap], rinvn[kCap];           // 1/r_ij at the old / trial position
     double go[kCap], gn[kCap];                 // exp(gamma sigma/(r_ij - a sigma)) old / trial
-    int j[kCap], kimg[kCap], flag[kCap];       // molecule, image | inverse image << 16, bit0 = in range (old), bit1 = (trial)
+    int flag[kCap];                            // bit0 = in range of the old position, bit1 = of the trial position
     unsigned long long cm[kCap];               // bit p of the end-to-end slot numbering set: a row ends at slot p
     uint32_t qe[64];                           // queue of in-range third bodies: packed list entry ...
-    int qown[64];                              // ... and the rank of the neighbour j whose row it came from
+    int qown[64];                              // ... and rank | (image, inverse image, flags of that rank) << 5 of the j whose row it came from
 };
 static_assert(sizeof(WaveScratch) % 8 == 0, "scratch records must keep 8-byte alignment");
 
@@ -845,6 +845,9 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     const int cc = (niv - 1) >> 1;
     const int lin = kimg <= cc ? kimg - 1 : kimg, linv = niv - 1 - lin;
     const int kinv = kimg == 0 ? 0 : (linv < cc ? linv + 1 : linv);
+    // image (10 bits) | inverse image (10 bits) | in range of old, trial position (2 bits), by rank like jv
+    const int flg = (int)((mo_ >> sl) & 1u) | (int)(((mn_ >> sl) & 1u) << 1);
+    const int wv = __builtin_amdgcn_ds_permute(dstl << 2, kimg | (kinv << 10) | (flg << 20));
     // row-end marks: chunk c of the scan reads mask cm[c]; a slot's owner is the number of marks before it
     if (lane < kCap) ws->cm[lane] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -854,7 +857,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         if (half == 0) {
             ws->q[0][rank] = qx; ws->q[1][rank] = qy; ws->q[2][rank] = qz;
             ws->rinvo[rank] = rinv; ws->go[rank] = g;
-            ws->j[rank] = j; ws->kimg[rank] = kimg | (kinv << 16); ws->flag[rank] = (int)((mo_ >> sl) & 1u) | (int)(((mn_ >> sl) & 1u) << 1);
+            ws->flag[rank] = flg;
         } else {
             ws->rinvn[rank] = rinv; ws->gn[rank] = g;
         }
@@ -862,6 +865,27 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- rows of the in-range j: fetched ahead ----------------------------------------------------
+    // The i--j--k stage below walks the rows of all in-range j laid end to end, 64 slots per chunk.  A
+    // chunk's slot -> (owner rank, owner's packed word, row entry) fetch is issued TWO CHUNKS AHEAD of its
+    // evaluation -- the first two right here, before the j--i--k stage -- so the row fetch (global memory for
+    // the big boxes) is never waited for.
+    int nbefore = 0;                                         // row ends in the chunks already fetched (wave-uniform)
+    auto fetch = [&](int t, int& own, int& wj, uint32_t& ent) {
+        const unsigned long long M = ws->cm[t >> 6];         // one address for the whole wave
+        const unsigned int mlo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)M);
+        const unsigned int mhi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(M >> 32));
+        own = nbefore + (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        nbefore += __popc(mlo) + __popc(mhi);
+        const int jj = __builtin_amdgcn_ds_bpermute(own << 2, jv);
+        const int st = __builtin_amdgcn_ds_bpermute(own << 2, stv);
+        wj = __builtin_amdgcn_ds_bpermute(own << 2, wv);
+        ent = t < T ? row(jj, t - st) : 0u;
+    };
+    int own_a = 0, own_b = 0, w_a = 0, w_b = 0; uint32_t ent_a = 0u, ent_b = 0u;
+    if (T > 0) fetch(lane, own_a, w_a, ent_a);
+    if (T > 64) fetch(64 + lane, own_b, w_b, ent_b);
 
     // ---- j--i--k triplets: pairs (a < b) of in-range neighbours, one pair per lane ------------
     // (molint.F90:302-318; a is the earlier list slot, so cos is formed in the reference's order)
@@ -901,9 +925,9 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane < nq) {
             const uint32_t e2 = ws->qe[lane];
-            const int own = ws->qown[lane];
+            const int qw = ws->qown[lane];
+            const int own = qw & 31, kj = (qw >> 5) & 1023, fl = qw >> 25;
             const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
-            const int kj = ws->kimg[own] & 0xffff, fl = ws->flag[own];
             double xk, yk, zk, kvx, kvy, kvz, sjx, sjy, sjz;
             getpos(kk, xk, yk, zk);
             getiv(k2, kvx, kvy, kvz);
@@ -927,29 +951,14 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         __builtin_amdgcn_wave_barrier();
         nq = 0;
     };
-    // The slot -> (owner, row entry) fetch runs ONE CHUNK AHEAD of the chunk being evaluated, so the row
-    // fetch (global memory for the big boxes) is in flight while the previous chunk is worked on.
-    int nbefore = 0;                                         // row ends in the chunks already fetched (wave-uniform)
-    auto fetch = [&](int t, int& own, uint32_t& ent) {
-        const unsigned long long M = ws->cm[t >> 6];         // one address for the whole wave
-        const unsigned int mlo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)M);
-        const unsigned int mhi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(M >> 32));
-        own = nbefore + (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-        nbefore += __popc(mlo) + __popc(mhi);
-        const int jj = __builtin_amdgcn_ds_bpermute(own << 2, jv);
-        const int st = __builtin_amdgcn_ds_bpermute(own << 2, stv);
-        ent = t < T ? row(jj, t - st) : 0u;
-    };
-    int own_nx = 0; uint32_t ent_nx = 0u;
-    if (T > 0) fetch(lane, own_nx, ent_nx);
     for (int t0 = 0; t0 < T; t0 += 64) {
         const int t = t0 + lane;
         const bool valid = t < T;
-        const int own = own_nx;
-        const uint32_t e2 = ent_nx;
-        if (t0 + 64 < T) fetch(t + 64, own_nx, ent_nx);
-        const int kjp = ws->kimg[own];
-        const int kj = kjp & 0xffff;
+        const int own = own_a, wj = w_a;
+        const uint32_t e2 = ent_a;
+        own_a = own_b; w_a = w_b; ent_a = ent_b;
+        if (t0 + 128 < T) fetch(t + 128, own_b, w_b, ent_b);
+        const int kj = wj & 1023;
         const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
         double xk, yk, zk, kvx, kvy, kvz, sjx, sjy, sjz;
         getpos(kk, xk, yk, zk);
@@ -957,7 +966,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         getiv(kj, sjx, sjy, sjz);
         const double pjx = ws->q[0][own], pjy = ws->q[1][own], pjz = ws->q[2][own];
         const bool self = valid && (kk == i);
-        const bool selfimg = self && (k2 == (kjp >> 16));   // the molecule itself, not an image: k's shift undoes j's
+        const bool selfimg = self && (k2 == ((wj >> 10) & 1023));   // the molecule itself, not an image: k's shift undoes j's
         const bool selfmove = self && !selfimg;
         const double box_ = ((xk + kvx) + sjx) - pjx;                            // :332,334
         const double boy_ = ((yk + kvy) + sjy) - pjy;
@@ -966,7 +975,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         if (__ballot(selfmove) != 0ull) {
             // an image of the molecule itself as third body moves with it: both geometries, in line (rare)
             if (selfmove) {
-                const int fl = ws->flag[own];
+                const int fl = wj >> 20;
                 const double bnx = ((xn + kvx) + sjx) - pjx, bny = ((yn + kvy) + sjy) - pjy, bnz = ((zn + kvz) + sjz) - pjz;
                 const double s2n = bnx * bnx + bny * bny + bnz * bnz;
                 double rk, gk, e1k;
@@ -988,7 +997,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         if (nq + c > 64) flush();
         if (inq) {
             const int slot = nq + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mq, 0u));
-            ws->qe[slot] = e2; ws->qown[slot] = own;
+            ws->qe[slot] = e2; ws->qown[slot] = own | (wj << 5);
         }
         nq += c;
     }
