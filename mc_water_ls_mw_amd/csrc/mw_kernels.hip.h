@@ -897,18 +897,21 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         if ((b + 1) * b / 2 <= p) ++b;
         const int a = p - b * (b - 1) / 2;
         if (p < npairs) {
+            // every operand in one batch of LDS reads (one round trip), whichever positions are in range
             const int fa = ws->flag[a], fb = ws->flag[b];
             const double qax = ws->q[0][a], qay = ws->q[1][a], qaz = ws->q[2][a];
             const double qbx = ws->q[0][b], qby = ws->q[1][b], qbz = ws->q[2][b];
+            const double roa = ws->rinvo[a], rob = ws->rinvo[b], goa = ws->go[a], gob = ws->go[b];
+            const double rna = ws->rinvn[a], rnb = ws->rinvn[b], gna = ws->gn[a], gnb = ws->gn[b];
             if (fa & fb & 1) {
                 const double ct = (((qax - xo) * (qbx - xo) + (qay - yo) * (qby - yo) + (qaz - zo) * (qbz - zo))
-                                   * ws->rinvo[a]) * ws->rinvo[b];                              // :316,365
-                if (ct < 0.99) { const double d = ct - kCos0; t3o += ws->go[a] * (ws->go[b] * (d * d)); ++nto; }
+                                   * roa) * rob;                                                // :316,365
+                if (ct < 0.99) { const double d = ct - kCos0; t3o += goa * (gob * (d * d)); ++nto; }
             }
             if (fa & fb & 2) {
                 const double ct = (((qax - xn) * (qbx - xn) + (qay - yn) * (qby - yn) + (qaz - zn) * (qbz - zn))
-                                   * ws->rinvn[a]) * ws->rinvn[b];
-                if (ct < 0.99) { const double d = ct - kCos0; t3n += ws->gn[a] * (ws->gn[b] * (d * d)); ++ntn; }
+                                   * rna) * rnb;
+                if (ct < 0.99) { const double d = ct - kCos0; t3n += gna * (gnb * (d * d)); ++ntn; }
             }
         }
     }
@@ -933,6 +936,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
             getiv(k2, kvx, kvy, kvz);
             getiv(kj, sjx, sjy, sjz);
             const double pjx = ws->q[0][own], pjy = ws->q[1][own], pjz = ws->q[2][own];
+            const double ro = ws->rinvo[own], rn = ws->rinvn[own], go_ = ws->go[own], gn_ = ws->gn[own];
             const double bx = ((xk + kvx) + sjx) - pjx;                          // :332,334
             const double by = ((yk + kvy) + sjy) - pjy;
             const double bz = ((zk + kvz) + sjz) - pjz;
@@ -940,12 +944,12 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
             double rk, gk, e1k;
             pair_terms(s2, rk, e1k, gk);
             if (fl & 1) {
-                const double ct = (-((pjx - xo) * bx + (pjy - yo) * by + (pjz - zo) * bz) * ws->rinvo[own]) * rk;   // :320,341,365
-                if (ct < 0.99) { const double d = ct - kCos0; t3o += ws->go[own] * (gk * (d * d)); ++nto; }
+                const double ct = (-((pjx - xo) * bx + (pjy - yo) * by + (pjz - zo) * bz) * ro) * rk;   // :320,341,365
+                if (ct < 0.99) { const double d = ct - kCos0; t3o += go_ * (gk * (d * d)); ++nto; }
             }
             if (fl & 2) {
-                const double ct = (-((pjx - xn) * bx + (pjy - yn) * by + (pjz - zn) * bz) * ws->rinvn[own]) * rk;
-                if (ct < 0.99) { const double d = ct - kCos0; t3n += ws->gn[own] * (gk * (d * d)); ++ntn; }
+                const double ct = (-((pjx - xn) * bx + (pjy - yn) * by + (pjz - zn) * bz) * rn) * rk;
+                if (ct < 0.99) { const double d = ct - kCos0; t3n += gn_ * (gk * (d * d)); ++ntn; }
             }
         }
         __builtin_amdgcn_wave_barrier();
