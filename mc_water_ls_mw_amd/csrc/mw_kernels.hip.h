@@ -491,11 +491,13 @@ __device__ __forceinline__ AtomSum atom_energy(int i, int n, const uint32_t* __r
     // phase 2: pair term and moments over the in-range entries only
     double e2 = 0.0, S0 = 0.0, Q = 0.0, S1x = 0.0, S1y = 0.0, S1z = 0.0;
     double Sxx = 0.0, Syy = 0.0, Szz = 0.0, Sxy = 0.0, Sxz = 0.0, Syz = 0.0;
-    auto accumulate = [&](uint32_t e) {
-        double xj, yj, zj, ix, iy, iz;
-        getpos((int)(e & kJMask), xj, yj, zj);
-        getiv((int)(e >> kJBits), ix, iy, iz);
-        const double dx = (xj + ix) - xi, dy = (yj + iy) - yi, dz = (zj + iz) - zi;
+    // The gathers of entry q+1 are issued before entry q is evaluated (one LDS round trip hidden per entry).
+    auto gather = [&](uint32_t e, double (&v)[6]) {
+        getpos((int)(e & kJMask), v[0], v[1], v[2]);
+        getiv((int)(e >> kJBits), v[3], v[4], v[5]);
+    };
+    auto accumulate = [&](const double (&v)[6]) {
+        const double dx = (v[0] + v[3]) - xi, dy = (v[1] + v[4]) - yi, dz = (v[2] + v[5]) - zi;
         const double r2 = dx * dx + dy * dy + dz * dz;
         const double rinv = fast_rsqrt(r2);
         const double den = fma_sc(r2, rinv, -kSigA);   // r - a sigma: < 0 inside the cutoff
@@ -515,11 +517,23 @@ __device__ __forceinline__ AtomSum atom_energy(int i, int n, const uint32_t* __r
         Sxy += gx * uy; Sxz += gx * uz; Syz += gy * uz;
     };
     const int nq = cnt < kQCap ? cnt : kQCap;
-    for (int q = 0; q < nq; ++q) accumulate(queue[q * BLOCK]);
+    if (nq > 0) {
+        double va[6], vb[6];
+        gather(queue[0], va);
+        for (int q = 0; q < nq; ++q) {
+            const uint32_t en = queue[(q + 1 < nq ? q + 1 : q) * BLOCK];
+            gather(en, vb);
+            accumulate(va);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) va[c] = vb[c];
+        }
+    }
     while (over) {
         const int s = __ffsll((long long)over) - 1;
         over &= over - 1ull;
-        accumulate(L[(size_t)s * N + i]);
+        double v[6];
+        gather(L[(size_t)s * N + i], v);
+        accumulate(v);
     }
     const double F2 = Sxx * Sxx + Syy * Syy + Szz * Szz + 2.0 * (Sxy * Sxy + Sxz * Sxz + Syz * Syz);
     const double F1 = S1x * S1x + S1y * S1y + S1z * S1z;
