@@ -153,6 +153,14 @@ class WalkerComms:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
+    def bcast_flag(self, flag):
+        """comms_bcastlog (comms_mpi.f90): rank 0's logical for everybody."""
+        if not dist.is_initialized() or self.world_size == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
+        dist.broadcast(t, src=0, group=self.group)
+        return bool(int(t.item()))
+
     def barrier(self):                                # comms_barrier, comms_mpi.f90:601-618
         if dist.is_initialized() and self.world_size > 1:
             dist.barrier(group=self.group)

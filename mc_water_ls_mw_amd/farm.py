@@ -21,10 +21,17 @@ import numpy as np
 
 def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=400.0, wl_factor=0.05,
         list_update_int=10, mpi_sync_int=250, sigma_ang=0.05, seed=2025, device=0, comms=None, rank=0,
-        samplerun=False, weight=None, npt=False, pressure_atm=1.0):
-    """Run `cycles` MC cycles of `walkers` two-lattice walkers on this GPU.  Returns a dict of results."""
+        samplerun=False, weight=None, npt=False, pressure_atm=1.0,
+        flat_chk_int=10000, wl_schedule=0, wl_flattol=0.05, wl_minhist=20, wl_useinvt=False, file_wl_factor=None,
+        deltaG_int=100000, max_mc_cycles=None, eq_mc_cycles=0, outdir=None, thermalise=True):
+    """Run `cycles` MC cycles of `walkers` two-lattice walkers on this GPU.  Returns a dict of results.
+
+    ``flat_chk_int`` ... ``file_wl_factor``: the Wang-Landau schedule (mc_check_flatness, :291-294;
+    :mod:`mc_water_ls_mw_amd.schedule`); ``deltaG_int``: free-energy estimate of a sample run (:302-306);
+    ``outdir``: where wlf.dat and the tagged tables go (nothing is written when None)."""
     from . import lattice as lat
     from .energy import EnergyModule
+    from .schedule import WangLandauSchedule, delta_g_from_hist, log_unbiased_norm
     from .sweep import MuGrid, WalkerFarm
 
     n = len(x_pair[0])
@@ -32,7 +39,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
     for w in range(walkers):
         for l in range(2):
             em.hmatrix[2 * w + l] = h_pair[l]
-            em.ljr[2 * w + l] = lat.thermalise(x_pair[l], sigma_ang, 7919 * (rank * walkers + w) + l)
+            em.ljr[2 * w + l] = (lat.thermalise(x_pair[l], sigma_ang, 7919 * (rank * walkers + w) + l)
+                                 if thermalise else np.asarray(x_pair[l], dtype=np.float64))
     em._chk(em.L.mw_init(device, n, 2 * walkers, em.maxneigh))
     em._live = True
     try:
@@ -44,22 +52,50 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         em.model_energy_batch(1, 2 * walkers)
         grid = MuGrid(nbins, -mu_range, mu_range)
         farm = WalkerFarm(em, 2, temperature, 1.1, grid=grid, weight=weight, pressure_au=pressure_atm / 2.90363081e8)
-        farm.options(record=True, samplerun=samplerun, always_switch=True, npt=npt, wl_factor=wl_factor)
+        comms = farm.local_comms() if comms is None else comms             # one exchange object throughout
+        sched = WangLandauSchedule(grid.nbins, wl_factor, wl_schedule=wl_schedule, wl_flattol=wl_flattol,
+                                   wl_minhist=wl_minhist, wl_useinvt=wl_useinvt, samplerun=samplerun, outdir=outdir)
+        sched.adopt_file_factor(file_wl_factor)                            # mc_moves.F90:751-760,816-821
+        lun = 0.0
+        if samplerun:                                                      # :778-806
+            lun = log_unbiased_norm(np.zeros(grid.nbins) if weight is None else weight, grid.av_binwidth,
+                                    cycles if max_mc_cycles is None else max_mc_cycles, eq_mc_cycles,
+                                    comms.world_size * walkers, n)
+
+        def set_options(cyc):
+            farm.options(record=cyc >= eq_mc_cycles, samplerun=samplerun, always_switch=True, npt=npt,
+                         wl_factor=sched.move_factor(cyc, n), log_unbiased_norm=lun)        # :1615,1655-1657
+
         if npt:                                                    # io.f90:171-172: vol 1/N against trans 0.5
             farm.moves(trans_prob=0.5, vol_prob=1.0 / n, dv_max_ang=0.924)
         for w in range(1, walkers + 1):
             farm.set_state(w, 1, farm.initial_mu(w))
         t0 = time.perf_counter()
-        synced = None
+        synced, events, delta_g = None, [], None
         for cyc in range(1, cycles + 1):
             if cyc % list_update_int == 0:                         # mc_moves.F90:217-222
                 if npt:
                     farm.sync_cells()                              # device-side volume moves changed the cells
                 em.build_neighbours_batch(1, 2 * walkers)      # checked: fails loudly on list overflow
+            set_options(cyc)
             farm.sweep_launch(n, seed=seed + rank, move0=(cyc - 1) * n)
-            if comms is not None and cyc % mpi_sync_int == 0:      # mc_moves.F90:258-276
+            if cyc % mpi_sync_int == 0:                            # mc_moves.F90:258-276
                 em.sync()
                 synced = farm.synchronise(comms)
+            if cyc % flat_chk_int == 0:                            # :291-294
+                em.sync()
+                ev = sched.check_flatness(cyc, n, farm, comms)
+                if ev["action"] != "none":
+                    events.append(ev)
+            if samplerun and cyc % deltaG_int == 0:                # :302-306
+                em.sync()
+                synced = farm.synchronise(comms)                   # comms_allreduce_uhist (:2532) with the rest
+                dg, per, normp = delta_g_from_hist(synced[2], grid.binwidth, n, temperature)
+                delta_g = dict(cycle=cyc, kT=dg, **{"per_molecule_" + k: v for k, v in per.items()})
+                if outdir is not None and comms.rank == 0:         # :2590-2613
+                    with open(os.path.join(outdir, "unbiased_histogram_%010d.dat" % cyc), "w") as fh:
+                        for m_, p_ in zip(grid.mu_bin, normp):
+                            fh.write(f"  {float(m_)!r}        {float(p_)!r}\n")
         em.sync()
         wall = time.perf_counter() - t0
         states = [farm.state(w) for w in range(1, min(walkers, 32) + 1)]
@@ -71,8 +107,12 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                    drift_walker1_Ha=[states[0]["model_energy"][l] - fresh[l] for l in range(2)],
                    volume_moves_walker1=farm.volume_moves(1) if npt else None,
                    histogram_total=None if synced is None else float(synced[1].sum()),
-                   weight_max=None if synced is None else float(synced[0].max()))
+                   weight_max=None if synced is None else float(synced[0].max()),
+                   wl_factor=sched.wl_factor, wl_invt_active=sched.invt_active, flatness_events=events,
+                   delta_g=delta_g)
         out["tables"] = synced
+        out["walker1_tables"] = farm.tables(1)
+        out["walker1_positions"] = [farm.positions(1), farm.positions(2)]
         return out
     finally:
         em.energy_deinit()
@@ -86,6 +126,13 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--share-device", action="store_true")
     ap.add_argument("--npt", action="store_true", help="volume moves too (mc_ensemble = 'npt')")
+    ap.add_argument("--wl-factor", type=float, default=0.05)
+    ap.add_argument("--flat-chk", type=int, default=10000, help="flat_chk_int: cycles between flatness checks")
+    ap.add_argument("--wl-schedule", type=int, default=0, choices=[0, 1, 2])
+    ap.add_argument("--wl-flattol", type=float, default=0.05)
+    ap.add_argument("--wl-minhist", type=int, default=20)
+    ap.add_argument("--wl-useinvt", action="store_true")
+    ap.add_argument("--outdir", default=None, help="directory for wlf.dat / eta_weights.dat_* / histogram.dat_*")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -104,8 +151,11 @@ def main():
     z1, z2 = np.load(os.path.join(gold, "ic48.npz")), np.load(os.path.join(gold, "ih48.npz"))
     comms = WalkerComms(101, device=torch.device("cuda", local) if (world > 1 and args.backend == "nccl") else None)
     res = run([z1["h"], z2["h"]], [z1["xyz"], z2["xyz"]], args.walkers, args.cycles, mpi_sync_int=args.sync,
-              device=local, comms=comms, rank=rank, npt=args.npt)
+              device=local, comms=comms, rank=rank, npt=args.npt, wl_factor=args.wl_factor, flat_chk_int=args.flat_chk,
+              wl_schedule=args.wl_schedule, wl_flattol=args.wl_flattol, wl_minhist=args.wl_minhist,
+              wl_useinvt=args.wl_useinvt, outdir=args.outdir)
     tabs = res.pop("tables")
+    res.pop("walker1_tables"), res.pop("walker1_positions")
     if world > 1:
         t = torch.tensor(np.concatenate(tabs[:2]), dtype=torch.float64,
                          device=torch.device("cuda", local) if args.backend == "nccl" else "cpu")

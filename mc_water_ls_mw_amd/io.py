@@ -112,10 +112,44 @@ def read_table(path):
     return wl, np.array(mu), np.array(val)
 
 
+def fortran_e(x, width=20, digits=12):
+    """A real as Fortran's Ew.d edit descriptor prints it: 0.ddddE+xx, right-justified."""
+    x = float(x)
+    if x == 0.0:
+        body = "0." + "0" * digits + "E+00"
+    else:
+        mant, exp = f"{abs(x):.{digits - 1}E}".split("E")        # d.ddd E xx  ->  0.dddd E xx+1
+        body = ("-" if x < 0 else "") + "0." + mant.replace(".", "") + f"E{int(exp) + 1:+03d}"
+    return body.rjust(width)
+
+
 def write_table(path, wl_factor, mu_bin, values):
     """Same layout as mc_moves.F90:1826-1841: E20.12 header, list-directed pairs."""
     with open(path, "w") as fh:
-        mant = f"{wl_factor:.12E}"                     # Fortran E20.12 prints 0.dddE+xx; any float syntax is read back
-        fh.write(f"#Current energy increment = {mant:>20s}\n")
+        fh.write(f"#Current energy increment = {fortran_e(wl_factor)}\n")
         for m, v in zip(mu_bin, values):
             fh.write(f"  {float(m)!r}        {float(v)!r}\n")
+
+
+def append_wlf(directory, rows, replace=False):
+    """``wlf.dat``, the history of the Wang-Landau increment: one ``(I10,E20.12)`` line per (cycle, wl_factor)
+    (mc_moves.F90:2070-2082 when the histogram turns flat, :2152-2161 in 1/t mode)."""
+    with open(os.path.join(directory, "wlf.dat"), "w" if replace else "a") as fh:
+        for cycle, f in rows:
+            fh.write(f"{int(cycle):10d}{fortran_e(f)}\n")
+
+
+def read_wlf(directory):
+    rows = []
+    for ln in open(os.path.join(directory, "wlf.dat")):
+        f = ln.split()
+        if len(f) == 2:
+            rows.append((int(f[0]), float(f[1].replace("D", "E"))))
+    return rows
+
+
+def write_tagged_tables(directory, tag, wl_factor, mu_bin, weight, histogram):
+    """``eta_weights.dat_<tag>`` and ``histogram.dat_<tag>`` (mc_moves.F90:2084-2100 with tag = the increment as
+    F20.12; :2163-2177 with tag = the cycle as I20.20)."""
+    write_table(os.path.join(directory, "eta_weights.dat_" + tag), wl_factor, mu_bin, weight)
+    write_table(os.path.join(directory, "histogram.dat_" + tag), wl_factor, mu_bin, histogram)

@@ -201,6 +201,46 @@ class WalkerFarm:
         self.em._chk(self.L.mw_sweep_set_tables_range(1, nw, *[r.ctypes.data_as(_dp) for r in rep]))
         return summed
 
+    def local_comms(self):
+        """The exchange object of a single-process farm (no process group: the 'all-reduce' is the sum over this
+        GPU's walkers alone).  Holds the last-synchronised tables, so use either this or one WalkerComms throughout."""
+        if getattr(self, "_local_comms", None) is None:
+            from .comms import WalkerComms
+            self._local_comms = WalkerComms(self.grid.nbins, samplerun=True)
+        return self._local_comms
+
+    # -- the table operations of mc_check_flatness (mc_moves.F90:1936-2185) for a farm ---------------------------
+    def allreduce_hist(self, comms=None):
+        """comms_allreduce_hist (comms_mpi.f90:461-494) with every walker a 'rank': the increments of this GPU's
+        walkers since the last synchronisation are summed on the host, then over the GPUs; every walker receives
+        the global histogram, which is also returned."""
+        nb, nw = self.grid.nbins, self.nwalkers
+        h = np.zeros((nw, nb))
+        self.em._chk(self.L.mw_sweep_get_tables_range(1, nw, None, h.ctypes.data_as(_dp), None))
+        comms = self.local_comms() if comms is None else comms
+        last = comms.hist_last_sync
+        total = last + (h - last[None, :]).sum(axis=0)     # this GPU's contribution, as WalkerComms expects it
+        comms.allreduce_hist(total)
+        rep = np.ascontiguousarray(np.broadcast_to(total, (nw, nb)))
+        self.em._chk(self.L.mw_sweep_set_tables_range(1, nw, None, rep.ctypes.data_as(_dp), None))
+        return total
+
+    def reset_histogram(self, comms=None):
+        """histogram = 0 on every walker, and the synchronisation baseline with it (comms_set_histogram,
+        comms_mpi.f90:533-548; mc_moves.F90:1976-1977,2105-2106)."""
+        nb, nw = self.grid.nbins, self.nwalkers
+        z = np.zeros((nw, nb))
+        self.em._chk(self.L.mw_sweep_set_tables_range(1, nw, None, z.ctypes.data_as(_dp), None))
+        (self.local_comms() if comms is None else comms).set_histogram(np.zeros(nb))
+
+    def shift_weights(self):
+        """weight(:) -= weight(nbins/2 + 1) on every walker (mc_moves.F90:2062-2066)."""
+        nb, nw = self.grid.nbins, self.nwalkers
+        w = np.zeros((nw, nb))
+        self.em._chk(self.L.mw_sweep_get_tables_range(1, nw, w.ctypes.data_as(_dp), None, None))
+        w -= w[:, nb // 2][:, None]
+        self.em._chk(self.L.mw_sweep_set_tables_range(1, nw, np.ascontiguousarray(w).ctypes.data_as(_dp), None, None))
+
     def initial_mu(self, walker):
         """ls_mu as mc_init / mc_lattice_switch form it (mc_moves.F90:1581-1583), without leshift."""
         if self.nlat == 1:

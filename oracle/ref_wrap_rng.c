@@ -55,3 +55,16 @@ double __wrap__QMrandomPrandom_uniform_random(void)
     else ++mw_phase;
     return v;
 }
+
+/* G11: the serial comms flavour never sets comms::size (comms_serial.f90:21; BSS, so 0 -- mc.log reports
+ * "Number of MPI tasks : 0"), and mc_init's log_unbiased_norm multiplies by it (mc_moves.F90:781-782):
+ * log(0) makes the unbiased histogram and delta G of a serial sample run NaN.  The MPI flavour has
+ * size >= 1.  MW_WRAP_SIZE=n gives this build the value an n-rank MPI run would see (used with n = 1 by
+ * tests/test_schedule_pin.py to pin log_unbiased_norm and mc_compute_deltaG_from_hist); unset, the
+ * reference's own serial behaviour is left alone. */
+extern int _QMcommsEsize;
+__attribute__((constructor)) static void mw_wrap_comms_size(void)
+{
+    const char *e = getenv("MW_WRAP_SIZE");
+    if (e && atoi(e) > 0) _QMcommsEsize = atoi(e);
+}

@@ -25,7 +25,8 @@ AUP_TO_ATM = 2.90363081e8
 pytestmark = pytest.mark.skipif(not os.path.exists(RNG), reason="oracle/_ref/mc_water_ref_rng not built")
 
 
-def namelist(num_lattices, temperature, cycles, samplerun, always_switch=False, npt=False, vol_prob=None, latt_sync=None):
+def namelist(num_lattices, temperature, cycles, samplerun, always_switch=False, npt=False, vol_prob=None, latt_sync=None,
+             mc_extra="", book_extra=""):
     volume_lines = "allow_vol        = .false." if not npt else f"mc_vol_prob      = {vol_prob}"
     return f"""&potential
 model_type = "mW"
@@ -46,6 +47,7 @@ allow_switch     = .false.
 {volume_lines}
 eta_interp       = .true.
 samplerun        = .{'true' if samplerun else 'false'}.
+{mc_extra}
 /
 &config
 num_lattices = {num_lattices}
@@ -62,6 +64,7 @@ eq_mc_cycles     = 1
 eq_adjust_mc     = .false.
 chkpt_dump_int   = {cycles}
 {'' if latt_sync is None else f'latt_sync_int    = {latt_sync}'}
+{book_extra}
 timer_qtime      = 172800
 timer_closetime  = 1800
 /
@@ -79,11 +82,11 @@ def read_records(path):
 
 
 def run_reference(d, num_lattices, temperature, cycles, weight=None, grid=None, samplerun=None, always_switch=False,
-                  tables=False, npt=False, vol_prob=None, transP=1.0, latt_sync=None):
+                  tables=False, npt=False, vol_prob=None, transP=1.0, latt_sync=None, mc_extra="", book_extra="", run_env={}):
     from mc_water_ls_mw_amd import lattice as lat
     os.makedirs(d)
     samplerun = (weight is not None) if samplerun is None else samplerun
-    open(os.path.join(d, "ice.input"), "w").write(namelist(num_lattices, temperature, cycles, samplerun, always_switch, npt, vol_prob, latt_sync))
+    open(os.path.join(d, "ice.input"), "w").write(namelist(num_lattices, temperature, cycles, samplerun, always_switch, npt, vol_prob, latt_sync, mc_extra, book_extra))
     z1 = load_golden("ic48_t015")
     h1, x1 = lat.read_xmol(_write(d, "input001.xmol", z1))
     boxes = [(h1, x1)]
@@ -95,7 +98,7 @@ def run_reference(d, num_lattices, temperature, cycles, weight=None, grid=None, 
             fh.write("#Current energy increment =   0.500000007451E-01\n")
             for mu, w in zip(grid.mu_bin, weight):
                 fh.write(f"  {float(mu)!r}        {float(w)!r}\n")
-    env = dict(os.environ, MW_WRAP_SWITCH="1" if always_switch else "0", MW_WRAP_TRANSP=repr(float(transP)))
+    env = dict(os.environ, MW_WRAP_SWITCH="1" if always_switch else "0", MW_WRAP_TRANSP=repr(float(transP)), **run_env)
     out = subprocess.run([RNG, "ice.input"], cwd=d, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, (out.stdout[-800:], out.stderr[-800:])
     therm = [f for f in os.listdir(d) if f.endswith("_therm.dat")][0]
@@ -107,6 +110,7 @@ def run_reference(d, num_lattices, temperature, cycles, weight=None, grid=None, 
     run_reference.ref_ljr = np.frombuffer(recs[-3], dtype="<f8").reshape(num_lattices, 48, 3).copy()
     ls = struct.unpack("<i", recs[-1])[0]
     assert struct.unpack("<i", recs[1])[0] == cycles
+    run_reference.records = recs
     if tables:      # records: nwater, cycle, (max_trans, dv_max), wl_factor, histogram, weight, wl_invt_active, [uhist], ...
         hist = np.frombuffer(recs[4], dtype="<f8").copy()
         wgt = np.frombuffer(recs[5], dtype="<f8").copy()
