@@ -179,6 +179,11 @@ int mw_sweep_get_tables_range(int first_walker, int count, double *weight, doubl
 int mw_sweep_set_tables_range(int first_walker, int count, const double *weight, const double *histogram,
                               const double *unbiased_hist);
 int mw_sweep_get_switches(int walker, long long *switches);
+/* mc_update_wl_bins subtracts the window minimum from a walker's weights after every update
+ * (mc_moves.F90:1682-1685).  shifts[w] = the sum of those minima since the last call with reset != 0:
+ * weight + shift is the walker's table without that gauge change, which is what a many-walker farm has to
+ * sum (the reference's delta scheme, comms_mpi.f90:243-277, sums the gauge change of every rank as well). */
+int mw_sweep_get_shifts_range(int first_walker, int count, double *shifts, int reset);
 int mw_set_model_energy(int ils, double e);
 int mw_sweep_set_state(int walker, int ls, double ls_mu);
 int mw_sweep_get_state(int walker, int *ls, double *ls_mu, double *model_energy, long long *accepted);

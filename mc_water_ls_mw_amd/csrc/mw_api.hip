@@ -75,6 +75,7 @@ struct Ctx {
     double *d_sw_mubin = nullptr, *d_sw_binwidth = nullptr;
     double *d_wweight = nullptr, *d_whist = nullptr, *d_wuhist = nullptr;   // [walker][nbins]
     unsigned long long* d_wswitch = nullptr;
+    double* d_wshift = nullptr;      // per walker: sum of the minima mc_update_wl_bins subtracted since the last read-out
     unsigned long long* d_wvol = nullptr;        // [walker][2] volume moves attempted / accepted
     int* d_wflag = nullptr;                      // [walker] a volume move needed more image vectors than ivcap
     double* d_volume = nullptr;                  // [box] |det hmatrix|
@@ -436,7 +437,7 @@ int mw_finalize(void)
     hipStreamSynchronize(g.stream);
     hipFree(g.d_hmat);
     if (g.d_sw_mubin) { hipFree(g.d_sw_mubin); hipFree(g.d_sw_binwidth); hipFree(g.d_wweight); hipFree(g.d_whist); hipFree(g.d_wuhist); }
-    if (g.d_wls) { hipFree(g.d_wls); hipFree(g.d_wmu); hipFree(g.d_wacc); hipFree(g.d_wswitch); hipFree(g.d_wvol); hipFree(g.d_wflag); }
+    if (g.d_wls) { hipFree(g.d_wls); hipFree(g.d_wmu); hipFree(g.d_wacc); hipFree(g.d_wswitch); hipFree(g.d_wshift); hipFree(g.d_wvol); hipFree(g.d_wflag); }
     hipFree(g.d_volume);
     if (g.d_swlog) hipFree(g.d_swlog);
     hipFree(g.d_pos); hipFree(g.d_ivect); hipFree(g.d_nivect); hipFree(g.d_list); hipFree(g.d_listm); hipFree(g.d_nn); hipFree(g.d_stats);
@@ -843,12 +844,14 @@ int mw_sweep_configure(int nlat, double beta, double max_trans, int nbins, int e
         HIPCHK(hipMalloc(&g.d_wmu, sizeof(double) * g.nbox));
         HIPCHK(hipMalloc(&g.d_wacc, sizeof(unsigned long long) * g.nbox));
         HIPCHK(hipMalloc(&g.d_wswitch, sizeof(unsigned long long) * g.nbox));
+        HIPCHK(hipMalloc(&g.d_wshift, sizeof(double) * g.nbox));
         HIPCHK(hipMalloc(&g.d_wvol, sizeof(unsigned long long) * 2 * g.nbox));
         HIPCHK(hipMalloc(&g.d_wflag, sizeof(int) * g.nbox));
     }
     HIPCHK(hipMemset(g.d_wvol, 0, sizeof(unsigned long long) * 2 * g.nbox));
     HIPCHK(hipMemset(g.d_wflag, 0, sizeof(int) * g.nbox));
     HIPCHK(hipMemset(g.d_wswitch, 0, sizeof(unsigned long long) * g.nbox));
+    HIPCHK(hipMemset(g.d_wshift, 0, sizeof(double) * g.nbox));
     std::vector<int> one((size_t)g.nbox, 1);
     HIPCHK(hipMemcpy(g.d_wls, one.data(), sizeof(int) * g.nbox, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(g.d_wmu, 0, sizeof(double) * g.nbox));
@@ -1007,6 +1010,15 @@ int mw_sweep_set_tables_range(int first_walker, int count, const double* weight,
     return 0;
 }
 
+int mw_sweep_get_shifts_range(int first_walker, int count, double* shifts, int reset)
+{
+    if (check_live() || check_walker(first_walker, count)) return 1;
+    if (shifts) HIPCHK(hipMemcpyAsync(shifts, g.d_wshift + (first_walker - 1), sizeof(double) * count, hipMemcpyDeviceToHost, g.stream));
+    if (reset) HIPCHK(hipMemsetAsync(g.d_wshift + (first_walker - 1), 0, sizeof(double) * count, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
 int mw_sweep_get_switches(int walker, long long* switches)
 {
     if (check_live() || check_walker(walker, 1)) return 1;
@@ -1058,7 +1070,7 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
                         : (ldslist ? mw::k_sweep_translation<true, true, false>
                                    : (ldspos ? mw::k_sweep_translation<true, false, false> : mw::k_sweep_translation<false, false, false>));
     hipLaunchKernelGGL(kern, dim3(count), dim3(64), shmem, g.stream, g.d_pos, g.d_hmat, g.d_ivect, g.d_nivect,
-                       g.d_listm, g.d_list, g.d_nn, g.d_energy, g.d_wls, g.d_wmu, g.d_wacc, g.d_wswitch, g.sp, g.d_wweight, g.d_whist, g.d_wuhist,
+                       g.d_listm, g.d_list, g.d_nn, g.d_energy, g.d_wls, g.d_wmu, g.d_wacc, g.d_wswitch, g.d_wshift, g.sp, g.d_wweight, g.d_whist, g.d_wuhist,
                        g.d_sw_mubin, g.d_sw_binwidth, g.d_volume, g.d_wvol, g.d_wflag, g.N, g.S, g.ivcap, nmoves, seed, move0,
                        first_walker - 1, dlog);
     HIPCHK(hipGetLastError());

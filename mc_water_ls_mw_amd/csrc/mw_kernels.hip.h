@@ -1434,7 +1434,7 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
                          int* nivect, const uint32_t* __restrict__ listm, const uint32_t* __restrict__ list,
                          const int* __restrict__ nn, double* __restrict__ energy,
                          int* __restrict__ wls, double* __restrict__ wmu, unsigned long long* __restrict__ wacc,
-                         unsigned long long* __restrict__ wswitch,
+                         unsigned long long* __restrict__ wswitch, double* __restrict__ wshift,
                          SweepParams sp, double* wweight, double* whist, double* wuhist,
                          const double* __restrict__ mu_bin, const double* __restrict__ binwidth,
                          double* volume, unsigned long long* __restrict__ wvol, int* __restrict__ wflag,
@@ -1501,6 +1501,7 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
     double* hist = whist + (size_t)wlk * sp.nbins;
     double* uhist = wuhist + (size_t)wlk * sp.nbins;
     unsigned long long nsw = 0;
+    double gauge = 0.0;                      // total of the minima subtracted from this walker's weights (:1682-1685)
 
     int ls = wls[wlk];                       // active lattice, 1-based
     double ls_mu = wmu[wlk];
@@ -1644,6 +1645,7 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
                         if (b == k - 1) w = w + sp.av_binwidth * sp.wl_factor / bwk;
                         weight[b] = w - mn;
                     }
+                    gauge += mn;
                     if (lane == 0) hist[k - 1] = hist[k - 1] + sp.av_binwidth / bwk;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1680,7 +1682,7 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     if (lane == 0) {
-        wls[wlk] = ls; wmu[wlk] = ls_mu; wacc[wlk] += acc; wswitch[wlk] += nsw;
+        wls[wlk] = ls; wmu[wlk] = ls_mu; wacc[wlk] += acc; wswitch[wlk] += nsw; wshift[wlk] += gauge;
         wvol[2 * wlk] += nvol_try; wvol[2 * wlk + 1] += nvol_acc;
         if (flag) wflag[wlk] = 1;
         energy[box0] = men[0];

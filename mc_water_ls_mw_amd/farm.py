@@ -81,7 +81,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             farm.sweep_launch(n, seed=seed + rank, move0=(cyc - 1) * n)
             if cyc % mpi_sync_int == 0:                            # mc_moves.F90:258-276
                 em.sync()
-                synced = farm.synchronise(comms)
+                synced = farm.synchronise(comms, regauge=True)
             if cyc % flat_chk_int == 0:                            # :291-294
                 em.sync()
                 ev = sched.check_flatness(cyc, n, farm, comms)
@@ -89,7 +89,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                     events.append(ev)
             if samplerun and cyc % deltaG_int == 0:                # :302-306
                 em.sync()
-                synced = farm.synchronise(comms)                   # comms_allreduce_uhist (:2532) with the rest
+                synced = farm.synchronise(comms, regauge=True)     # comms_allreduce_uhist (:2532) with the rest
                 dg, per, normp = delta_g_from_hist(synced[2], grid.binwidth, n, temperature)
                 delta_g = dict(cycle=cyc, kT=dg, **{"per_molecule_" + k: v for k, v in per.items()})
                 if outdir is not None and comms.rank == 0:         # :2590-2613

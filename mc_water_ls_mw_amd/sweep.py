@@ -186,17 +186,36 @@ class WalkerFarm:
         self.em._chk(self.L.mw_sweep_get_switches(walker, ctypes.byref(v)))
         return v.value
 
-    def synchronise(self, comms):
+    def synchronise(self, comms=None, regauge=False):
         """The mpi_sync_int block of mc_cycle (mc_moves.F90:258-276) for a farm: every walker is a 'rank' of the
         reference; the increments of all walkers of this GPU are summed on the host, then over the GPUs by
-        ``comms`` (WalkerComms, one all-reduce), and every walker receives the synchronised tables."""
+        ``comms`` (WalkerComms, one all-reduce), and every walker receives the synchronised tables.
+
+        ``regauge=False`` is the reference's arithmetic to the letter: a rank's weight increment includes the window
+        minimum that mc_update_wl_bins subtracts after every update (:1682-1685), so R ranks subtract a minimum m
+        R times where one shared table would lose it once.  The synchronised table then sits at about -(R-1) m, every
+        rank adds that back on its next update, the sum comes out at +(R-1)^2 m, and so on: a uniform offset that
+        grows by the factor -(R-1) per synchronisation once no bin is left at weight 0 (the reference carries a
+        disabled "negative growth of eta" check for it, comms_mpi.f90:258-263).  Eight ranks live with that for a
+        while; eight thousand walkers per GPU lose all precision within a few synchronisations.
+        ``regauge=True`` (what farm.run uses): the device keeps each walker's accumulated minimum, the sum is taken
+        over weight + that (the increments proper), and the window minimum is subtracted once from the result --
+        one shared table in the reference's own gauge; identical to the reference for a single walker."""
+        comms = self.local_comms() if comms is None else comms
         nb, nw = self.grid.nbins, self.nwalkers
         tabs = [np.zeros((nw, nb)) for _ in range(3)]
         self.em._chk(self.L.mw_sweep_get_tables_range(1, nw, *[t.ctypes.data_as(_dp) for t in tabs]))
+        if regauge:
+            shifts = np.zeros(nw)
+            self.em._chk(self.L.mw_sweep_get_shifts_range(1, nw, shifts.ctypes.data_as(_dp), 1))
+            tabs[0] += shifts[:, None]
         last = (comms.eta_last_sync, comms.hist_last_sync, comms.uhist_last_sync)
         # a rank's contribution = sum over its walkers of (table - last): hand WalkerComms `last + that sum`
         summed = [last[t] + (tabs[t] - last[t][None, :]).sum(axis=0) for t in range(3)]
         comms.sync(summed[0], summed[1], summed[2])
+        if regauge:
+            summed[0] -= summed[0][self.grid.start_bin - 1:self.grid.end_bin].min()
+            comms.eta_last_sync[:] = summed[0]
         rep = [np.ascontiguousarray(np.broadcast_to(summed[t], (nw, nb))) for t in range(3)]
         self.em._chk(self.L.mw_sweep_set_tables_range(1, nw, *[r.ctypes.data_as(_dp) for r in rep]))
         return summed

@@ -403,3 +403,45 @@ def test_chain_synchronisation_follows_the_oracle(so, c_oracle):
                 assert abs(s["ls_mu"] - st.ls_mu) < 1e-6 * (1 + abs(st.ls_mu)) and s["ls"] == st.ls
     finally:
         em.energy_deinit()
+
+
+@pytest.mark.gpu
+def test_regauged_synchronisation_is_one_shared_table():
+    """Many walkers per GPU: WalkerFarm.synchronise(regauge=True) must give what ONE table updated by all walkers
+    would hold.  A Wang-Landau update adds wl_factor * av_binwidth / binwidth(k) to the weight and av_binwidth /
+    binwidth(k) to the histogram of the same bin, so over any interval  delta weight = wl_factor * delta histogram
+    up to the uniform gauge constant -- for the sum over walkers too.  The reference's own delta scheme (regauge=False)
+    multiplies that constant by the number of walkers at every synchronisation instead (see the docstring)."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.comms import WalkerComms
+    from mc_water_ls_mw_amd.energy import load_boxes
+    from mc_water_ls_mw_amd.sweep import MuGrid, WalkerFarm
+    z1, z2 = load_golden("ic48"), load_golden("ih48")
+    nw, f = 96, 0.05
+    hs, xs = [], []
+    for w in range(nw):
+        hs += [z1["h"], z2["h"]]
+        xs += [lat.thermalise(z1["xyz"], 0.05, 2 * w), lat.thermalise(z2["xyz"], 0.05, 2 * w + 1)]
+    em = load_boxes(hs, xs)
+    grid = MuGrid(101, -400.0, 400.0)
+    start = 2.0 + 0.01 * np.abs(grid.mu_bin)                   # no bin at weight 0: every walker subtracts a minimum
+    farm = WalkerFarm(em, 2, 200.0, 1.1, grid=grid, weight=start)
+    comms = WalkerComms(101)
+    comms.eta_last_sync[:] = start                             # the tables every walker starts from
+    try:
+        farm.options(record=True, samplerun=False, always_switch=True, wl_factor=f)
+        for w in range(1, nw + 1):
+            farm.set_state(w, 1, farm.initial_mu(w))
+        prev_w, prev_h = start.copy(), np.zeros(101)
+        for rnd in range(4):
+            farm.sweep(48 * 5, seed=99, move0=rnd * 48 * 5)
+            wt, hi, _ = farm.synchronise(comms, regauge=True)
+            d = (wt - prev_w) - f * (hi - prev_h)
+            assert hi.sum() > prev_h.sum()
+            assert np.abs(d - d[0]).max() < 1e-9 * max(1.0, np.abs(wt).max())     # uniform: one shared table
+            assert wt.min() == 0.0 and wt.max() < 1e4                               # in the reference's gauge, bounded
+            for w in (1, nw):
+                assert np.array_equal(farm.tables(w)[0], wt)
+            prev_w, prev_h = wt.copy(), hi.copy()
+    finally:
+        em.energy_deinit()
