@@ -17,8 +17,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmw_hip.so")
 SOURCES = [os.path.join(CSRC, "mw_api.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "mw_kernels.hip.h"),
-                  os.path.join(os.path.dirname(PKG), "include", "mw_energy.h")]
+DEPS = SOURCES + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip.h")) + \
+    [os.path.join(os.path.dirname(PKG), "include", "mw_energy.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 

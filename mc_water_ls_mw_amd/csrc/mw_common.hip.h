@@ -1,0 +1,164 @@
+// mw_common.hip.h -- gfx950 (MI355X, CDNA4) device code of the mW energy engine:
+// model constants, the packed list entry, double-precision primitives (rsqrt / reciprocal / exp sized
+// for the 1e-10 parity bar), wave and DPP reductions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mw {
+
+// ---- model constants (molint.F90:63-74, constants.f90:42-43) -----------------------
+constexpr double kAngToBohr = 1.0 / 0.5291772108;
+constexpr double kSigma     = 2.3925 * kAngToBohr;       // bohr
+constexpr double kEpsilon   = 6.189 / 627.509469;        // Hartree
+constexpr double kLambda    = 23.15;
+constexpr double kBigA      = 7.049556277;
+constexpr double kBigB      = 0.6022245584;
+constexpr double kGamma     = 1.2;
+constexpr double kSmallA    = 1.8;
+// molint.F90:74 has no _dp suffix: the reference holds float32(-0.33331324756) widened
+constexpr double kCos0      = (double)(-0.33331324756f);
+constexpr double kSigA      = kSigma * kSmallA;                       // rc = a*sigma
+constexpr double kRcSq      = kSigma * kSmallA * kSigma * kSmallA;    // molint.F90:255,432 order
+constexpr double kRn        = kSmallA * kSigma * 1.18;                // molint.F90:516
+constexpr double kRnSq      = kRn * kRn;                              // molint.F90:537
+constexpr double kAeps      = kBigA * kEpsilon;
+constexpr double kLamEps    = kLambda * kEpsilon;
+constexpr double kGamSig    = kGamma * kSigma;
+constexpr double kSigSq     = kSigma * kSigma;
+
+// ---- packed list entry: (jmol-1) in the low 22 bits, (image-1) in the next 10 -------
+constexpr int      kJBits = 22;
+constexpr uint32_t kJMask = (1u << kJBits) - 1u;
+
+__device__ __forceinline__ uint32_t pack_entry(int j0, int k0) { return (uint32_t)j0 | ((uint32_t)k0 << kJBits); }
+
+// The list is kept in two layouts, each coalesced for its consumer:
+//   list  [box][S][N]   slot-major     -- full-box kernel: thread = molecule, loop over slots
+//   listm [box][N][64]  molecule-major -- single-move kernels: lane = slot of one molecule's row
+// (a row is 256 B = two 128-B lines; S <= 64)
+constexpr int kRow = 64;
+
+// Wave-uniform broadcast of a double from lane `l` (l must be uniform: v_readlane, no LDS traffic).
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// ---- double-precision primitives sized for this tolerance ---------------------------------
+// The parity bar is 1e-10 relative on energies; these keep every factor below 1e-14 relative
+// while costing a fraction of the IEEE-exact sqrt / divide / libm exp sequences (which spend
+// most of their instructions on the last ulp and on special cases that cannot occur here:
+// the arguments are finite, positive (r^2), nonzero (r - a sigma < 0) or <= 0 (exponent)).
+
+// The gfx950 v_rsq_f64 / v_rcp_f64 estimates are good to ~5e-8 relative (measured, tools/hwprec.hip);
+// one third-order correction brings both to double rounding (1.4e-16 / <1e-16 measured).
+
+// 1/sqrt(x), x > 0 finite and normal.
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-x * y, y, 1.0);                 // 1 - x y^2
+    return __builtin_fma(y, e * __builtin_fma(e, 0.375, 0.5), y);   // y (1 + e/2 + 3e^2/8)
+}
+
+// 1/x, x finite, normal, nonzero.
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    const double y = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, y, 1.0);                     // 1 - x y
+    return __builtin_fma(y, __builtin_fma(e, e, e), y);             // y (1 + e + e^2)
+}
+
+// d = a*b + c with c in a scalar register pair: the three-address v_fma_f64.  (Left to itself the
+// compiler keeps the Horner coefficients in VGPRs and emits v_mov_b64 + v_fmac_f64 per step.)
+__device__ __forceinline__ double fma_sc(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+
+// exp(x) for x <= 0 (any magnitude; underflows smoothly to 0).  n = round(x log2 e),
+// r = x - n ln2 in two pieces, degree-11 Taylor on |r| <= 0.347 (remainder < 7e-15), 2^n by ldexp.
+__device__ __forceinline__ double fast_exp_neg(double x)
+{
+    x = __builtin_fmax(x, -800.0);                                  // exp(-800) == 0 in double anyway
+    const double n = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(n, -6.93147180369123816490e-01, x);    // ln2 high part (fdlibm split)
+    r = __builtin_fma(n, -1.90821492927058770002e-10, r);           // ln2 low part
+    double p = 2.50521083854417187751e-08;                           // 1/11!
+    p = fma_sc(p, r, 2.75573192239858906526e-07);                    // 1/10!
+    p = fma_sc(p, r, 2.75573192239858906526e-06);                    // 1/9!
+    p = fma_sc(p, r, 2.48015873015873015873e-05);                    // 1/8!
+    p = fma_sc(p, r, 1.98412698412698412698e-04);                    // 1/7!
+    p = fma_sc(p, r, 1.38888888888888888889e-03);                    // 1/6!
+    p = fma_sc(p, r, 8.33333333333333333333e-03);                    // 1/5!
+    p = fma_sc(p, r, 4.16666666666666666667e-02);                    // 1/4!
+    p = fma_sc(p, r, 1.66666666666666666667e-01);                    // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
+// ---- wave / block reductions ---------------------------------------------------------
+// Inclusive prefix sums over the 64 lanes through the DPP network: four shifts inside each row of 16
+// lanes, then lane 15 of a row into the next row and lane 31 into the upper half.  Lane 63 ends up with
+// the wave's total (summation order: a fixed tree, the same for every call).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_wave_sum(double v)
+{
+    v += dpp_mov_f64<0x111, 0xf>(v);      // row_shr:1
+    v += dpp_mov_f64<0x112, 0xf>(v);      // row_shr:2
+    v += dpp_mov_f64<0x114, 0xf>(v);      // row_shr:4
+    v += dpp_mov_f64<0x118, 0xf>(v);      // row_shr:8
+    v += dpp_mov_f64<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v += dpp_mov_f64<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int dpp_wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;   // valid in lane 0
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_down(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+}  // namespace mw

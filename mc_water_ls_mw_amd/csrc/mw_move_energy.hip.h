@@ -1,0 +1,516 @@
+// mw_move_energy.hip.h -- gfx950 (MI355X, CDNA4) device code of the mW energy engine:
+// compute_local_real_energy (molint.F90:220-404) and the fused old/new evaluation of a trial move:
+// local_energy_wave, move_energy_wave, k_move_energy, k_local_energy_single.
+#pragma once
+
+#include "mw_common.hip.h"
+
+namespace mw {
+
+// =====================================================================================
+// Local energy of one molecule = every pair and every triplet it takes part in
+// (as centre or as end), the building block of a single-move Delta E.
+// One 64-wide wavefront per request; lane l owns slot l of a neighbour list
+// (maxneigh <= 64).  Pass 0: the lanes hold imol's own list and evaluate the pair
+// term and g for the in-range lanes.  Then for every in-range j (a wave-uniform
+// loop over the ballot mask):
+//   * j--i--k triplets: lanes above j that are in range combine with j's
+//     broadcast vector (molint.F90:302-318: the remaining entries of imol's list);
+//   * i--j--k triplets: the lanes re-load jmol's list, shifted by j's image
+//     (molint.F90:324-343), and each evaluates its k.
+// A slot whose cos(theta) >= 0.99 contributes 0 (molint.F90:367-371; this is how
+// the k == i self term drops out) and so does an out-of-range slot (G2).
+//
+// A request may carry up to two position overrides {index, xyz}: the molecule
+// itself at a trial position, and (single-call drop-in path) the previously
+// queried molecule whose host copy may have been reverted.  Overrides are used
+// from registers wherever that index is gathered; with `commit` they are also
+// written to the mirrored positions for later launches.
+// =====================================================================================
+struct Override { int idx; double x, y, z; };   // idx < 0: none (0-based molecule index)
+
+__device__ __forceinline__ void load_pos(const double* __restrict__ P, int j, const Override& o1, const Override& o2,
+                                         double& x, double& y, double& z)
+{
+    const double* p = P + 3 * (size_t)j;
+    x = p[0]; y = p[1]; z = p[2];
+    if (j == o1.idx) { x = o1.x; y = o1.y; z = o1.z; }
+    if (j == o2.idx) { x = o2.x; y = o2.y; z = o2.z; }
+}
+
+__device__ __forceinline__ void pair_terms(double r2, double& rinv, double& e1, double& g)
+{
+    rinv = fast_rsqrt(r2);                       // molint.F90:278
+    const double den = fma_sc(r2, rinv, -kSigA); // r - a sigma, r = r2 / sqrt(r2)        :286
+    // r2 < rc^2 but r rounded onto rc: the term is exactly 0 in that limit          :288
+    const double w = fast_rcp(__builtin_fmin(den, -1.0e-300));
+    const double t = fast_exp_neg(0.2 * kSigma * w);
+    const double t2 = t * t, t4 = t2 * t2;
+    e1 = t4 * t;                                 // :291
+    g  = t4 * t2;                                // :292
+}
+
+// Returns the local energy in every lane.  `ninter` / `nslots` (wave-uniform) receive the number
+// of in-range interactions as the reference enumerates them (pairs + triplet slots with
+// cos(theta) < 0.99) and the number of list slots visited (n_i + sum of n_j over in-range j),
+// which prices the call's algorithmic bytes.
+__device__ __forceinline__ double local_energy_wave(const double* __restrict__ P, const double* __restrict__ IV,
+                                                    const uint32_t* __restrict__ LM, const int* __restrict__ NN,
+                                                    int i, const Override& o1, const Override& o2, int lane,
+                                                    unsigned int& ninter, unsigned int& nslots)
+{
+    double xi, yi, zi;
+    load_pos(P, i, o1, o2, xi, yi, zi);                                   // molint.F90:258
+    const int n_i = NN[i];
+
+    // pass 0: imol's own list, one slot per lane
+    const bool has = lane < n_i;
+    const uint32_t e = has ? LM[(size_t)i * kRow + lane] : 0u;
+    const int j = (int)(e & kJMask), kimg = (int)(e >> kJBits);
+    double xj, yj, zj;
+    load_pos(P, j, o1, o2, xj, yj, zj);
+    const double jvx = IV[3 * kimg], jvy = IV[3 * kimg + 1], jvz = IV[3 * kimg + 2];
+    const double qx = xj + jvx, qy = yj + jvy, qz = zj + jvz;             // :269 position of j's image
+    const double dx = qx - xi, dy = qy - yi, dz = qz - zi;                // :272
+    const double r2 = dx * dx + dy * dy + dz * dz;                        // :273
+    const bool inr = has && (r2 < kRcSq);                                 // :276
+    double rinv = 0.0, e1 = 0.0, g = 0.0;
+    if (inr) pair_terms(r2, rinv, e1, g);
+    const double q = kSigSq * rinv * rinv;
+    double acc2 = inr ? (kAeps * (kBigB * (q * q) - 1.0)) * e1 : 0.0;     // :294-297
+    double acc3 = 0.0;
+    unsigned int ntl = 0;            // per-lane count of triplet slots that contribute
+
+    unsigned long long mask = __ballot(inr);
+    ninter = (unsigned int)__popcll(mask);
+    nslots = (unsigned int)n_i;
+    while (mask) {                                                        // wave-uniform loop over in-range j
+        const int jl = __ffsll((long long)mask) - 1;
+        mask &= mask - 1ull;
+        const double ajx = __shfl(dx, jl, 64), ajy = __shfl(dy, jl, 64), ajz = __shfl(dz, jl, 64);
+        const double rinv_j = __shfl(rinv, jl, 64), g_j = __shfl(g, jl, 64);
+
+        // j--i--k: later in-range slots of imol's own list                 :302-318
+        if (inr && lane > jl) {
+            const double ct = ((ajx * dx + ajy * dy + ajz * dz) * rinv_j) * rinv;     // :316,365
+            if (ct < 0.99) { const double d = ct - kCos0; acc3 += g_j * (g * (d * d)); ++ntl; }   // :367-368,385-387
+        }
+
+        // i--j--k: jmol's list, translated by j's image                    :324-343
+        const int jj = __shfl(j, jl, 64);
+        const double sjx = __shfl(jvx, jl, 64), sjy = __shfl(jvy, jl, 64), sjz = __shfl(jvz, jl, 64);
+        const double pjx = __shfl(qx, jl, 64), pjy = __shfl(qy, jl, 64), pjz = __shfl(qz, jl, 64);
+        const int n_j = NN[jj];
+        nslots += (unsigned int)n_j;
+        if (lane < n_j) {
+            const uint32_t e2 = LM[(size_t)jj * kRow + lane];
+            const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
+            double xk, yk, zk;
+            load_pos(P, kk, o1, o2, xk, yk, zk);
+            const double bx = ((xk + IV[3 * k2]) + sjx) - pjx;            // :332,334
+            const double by = ((yk + IV[3 * k2 + 1]) + sjy) - pjy;
+            const double bz = ((zk + IV[3 * k2 + 2]) + sjz) - pjz;
+            const double s2 = bx * bx + by * by + bz * bz;                // :335
+            if (s2 < kRcSq) {                                             // :361
+                double rinv_k, e1_k, g_k;
+                pair_terms(s2, rinv_k, e1_k, g_k);
+                const double ct = (-(ajx * bx + ajy * by + ajz * bz) * rinv_j) * rinv_k;   // :320,341,365
+                if (ct < 0.99) { const double d = ct - kCos0; acc3 += g_j * (g_k * (d * d)); ++ntl; }
+            }
+        }
+    }
+    double tot = acc2 + kLamEps * acc3;                                    // :397
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        tot += __shfl_xor(tot, off, 64);
+        ntl += (unsigned int)__shfl_xor((int)ntl, off, 64);
+    }
+    ninter += ntl;
+    return tot;
+}
+
+// -------------------------------------------------------------------------------------
+// Batched single-move path: old AND new local energy of a trial move in one pass.
+//
+// What the two evaluations share is most of the work: the same list rows, the same
+// gathered positions and -- for the i--j--k triplets -- the same r_jk, g_jk (only the
+// molecule itself sits somewhere else), so each exp(.) of a third body is evaluated
+// once and used for both.  Lanes are packed across ALL in-range neighbours j at once:
+// the rows of the in-range j's are laid end to end (sum of nn(j) ~ 150 slots) and dealt
+// to the 64 lanes, so a pass is ~80 % full instead of one partly filled pass per j.
+// Each lane finds the j that owns its slot from the (wave-uniform) prefix sums and
+// pulls that j's vector/weights from the owning lane with cross-lane reads.
+//
+// Cases where a periodic image of the molecule itself takes part: as third body
+// (k == i through a non-identical image) both geometries are evaluated in line; a
+// molecule that neighbours its own image (cells narrower than the list radius) takes
+// the plain one-evaluation-at-a-time routine above.  The k == i self term is skipped
+// explicitly (the reference drops it through its cos(theta) >= 0.99 rule).
+// -------------------------------------------------------------------------------------
+struct MoveRes { double eo, en; unsigned int io, so, in_, sn; };
+
+// Per-wavefront LDS scratch: the in-range neighbours of the molecule, compacted by rank, so
+// that any lane can pull neighbour `r`'s record with plain LDS reads (a broadcast when lanes
+// of one group read the same record).
+constexpr int kCap = 24;                       // more in-range neighbours than this: plain routine
+struct WaveScratch {
+    double q[3][kCap];                         // position of j's image            (molint.F90:269)
+    double rinvo[kCap], rinvn[kCap];           // 1/r_ij at the old / trial position
+    double go[kCap], gn[kCap];                 // exp(gamma sigma/(r_ij - a sigma)) old / trial
+    int flag[kCap];                            // bit0 = in range of the old position, bit1 = of the trial position
+    unsigned long long cm[kCap];               // bit p of the end-to-end slot numbering set: a row ends at slot p
+    uint32_t qe[64];                           // queue of in-range third bodies: packed list entry ...
+    int qown[64];                              // ... and rank | (image, inverse image, flags of that rank) << 5 of the j whose row it came from
+};
+static_assert(sizeof(WaveScratch) % 8 == 0, "scratch records must keep 8-byte alignment");
+
+// Returns false (nothing written) when the request needs the plain routine.
+// `row(j, s)` returns list entry s of molecule j and `nnof(j)` its row length: global memory (molecule-major
+// list) or, for small systems in the sweep driver, LDS copies.
+template <typename PosFn, typename IvFn, typename RowFn, typename NnFn>
+__device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn row, NnFn nnof,
+                                                 WaveScratch* __restrict__ ws, int niv,
+                                                 int i, int n_i, uint32_t e,
+                                                 double xo, double yo, double zo,
+                                                 double xn, double yn, double zn, int lane, MoveRes& res)
+{
+    // ---- pass 0: imol's own row; lanes 0..31 take slot l against the OLD position, lanes 32..63 the same
+    // slot against the TRIAL position, so that one rsqrt/reciprocal/exp sequence serves both evaluations.
+    // `e` arrives as entry (lane & 31) of imol's row, fetched by the caller ahead of time (whatever the row
+    // length: rows are padded).  Rows longer than 32 entries take the plain routine, and so does a molecule
+    // that neighbours one of its own periodic images.
+    if (n_i > 32) return false;
+    const int half = lane >> 5, sl = lane & 31;
+    const bool has = sl < n_i;
+    const int j = has ? (int)(e & kJMask) : 0, kimg = has ? (int)(e >> kJBits) : 0;
+    if (__ballot(has && j == i) != 0ull) return false;
+    double xj, yj, zj, jvx, jvy, jvz;
+    getpos(j, xj, yj, zj);
+    getiv(kimg, jvx, jvy, jvz);
+    const int nnj = has ? nnof(j) : 0;
+    const double qx = xj + jvx, qy = yj + jvy, qz = zj + jvz;                 // molint.F90:269
+    const double rix = half ? xn : xo, riy = half ? yn : yo, riz = half ? zn : zo;
+    const double ax = qx - rix, ay = qy - riy, az = qz - riz;                 // :272
+    const double r2 = ax * ax + ay * ay + az * az;
+    const bool in = has && (r2 < kRcSq);                                      // :276
+    const unsigned long long B = __ballot(in);
+    const unsigned int mo_ = (unsigned int)B, mn_ = (unsigned int)(B >> 32);  // in range of the old / trial position, by slot
+    const unsigned int U = mo_ | mn_;
+    const int cntU = __popc(U);
+    if (cntU > kCap) return false;
+
+    double rinv = 0.0, e1 = 0.0, g = 0.0;
+    if (in) pair_terms(r2, rinv, e1, g);
+    const double qq = kSigSq * rinv * rinv;
+    const double accp = in ? (kAeps * (kBigB * (qq * qq) - 1.0)) * e1 : 0.0;  // :294-297 (old in lanes 0..31, trial in 32..63)
+    double t3o = 0.0, t3n = 0.0;
+    unsigned int nto = 0, ntn = 0;
+
+    // ---- compact the in-range neighbours (of either position) into the wave's scratch ------------
+    const bool inu = (U >> sl) & 1u;
+    const int rank = __popc(U & ((1u << sl) - 1u));
+    // The rows of the in-range j are laid end to end (slots 0..T-1).  An inclusive prefix sum over the 32
+    // slot lanes of each half gives every j its first slot, and in its upper 16 bits the list slots each
+    // evaluation visits (half 0: old position, half 1: trial position).
+    const int mine = (inu ? nnj : 0) | ((in ? nnj : 0) << 16);
+    int inc = mine;
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);        // row_shr:1
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);        // row_shr:2
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);        // row_shr:4
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);        // row_shr:8
+    const int r15 = __builtin_amdgcn_readlane(inc, 15), r47 = __builtin_amdgcn_readlane(inc, 47);
+    inc += (lane & 16) ? (half ? r47 : r15) : 0;
+    const int tot0 = __builtin_amdgcn_readlane(inc, 31), tot1 = __builtin_amdgcn_readlane(inc, 63);
+    const int T = tot0 & 0xffff;
+    const unsigned int so = (unsigned int)n_i + (unsigned int)(tot0 >> 16), sn = (unsigned int)n_i + (unsigned int)(tot1 >> 16);
+    const int start = (inc & 0xffff) - (inu ? nnj : 0);
+    // lane r of these two holds, for the in-range neighbour of rank r, its molecule and the first slot of
+    // its row: the scan below locates a slot's owner from registers alone (no LDS round trips in front of
+    // the row fetch).  Lanes that own no record aim at lane 63, which no rank reaches (cntU <= kCap).
+    const int dstl = (inu && half == 0) ? rank : 63;
+    const int jv  = __builtin_amdgcn_ds_permute(dstl << 2, j);
+    const int stv = __builtin_amdgcn_ds_permute(dstl << 2, start);
+    // the image that undoes `kimg`: cells are numbered centre first, then lexicographically without the
+    // centre (compute_ivects, molint.F90:174-217), so the opposite cell is the mirror position
+    const int cc = (niv - 1) >> 1;
+    const int lin = kimg <= cc ? kimg - 1 : kimg, linv = niv - 1 - lin;
+    const int kinv = kimg == 0 ? 0 : (linv < cc ? linv + 1 : linv);
+    // image (10 bits) | inverse image (10 bits) | in range of old, trial position (2 bits), by rank like jv
+    const int flg = (int)((mo_ >> sl) & 1u) | (int)(((mn_ >> sl) & 1u) << 1);
+    const int wv = __builtin_amdgcn_ds_permute(dstl << 2, kimg | (kinv << 10) | (flg << 20));
+    // row-end marks: chunk c of the scan reads mask cm[c]; a slot's owner is the number of marks before it
+    if (lane < kCap) ws->cm[lane] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (inu && half == 0 && rank > 0 && start > 0)      // (rows are never empty: j lists i back)
+        __hip_atomic_fetch_or(&ws->cm[(start - 1) >> 6], 1ull << ((start - 1) & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (inu) {
+        if (half == 0) {
+            ws->q[0][rank] = qx; ws->q[1][rank] = qy; ws->q[2][rank] = qz;
+            ws->rinvo[rank] = rinv; ws->go[rank] = g;
+            ws->flag[rank] = flg;
+        } else {
+            ws->rinvn[rank] = rinv; ws->gn[rank] = g;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- rows of the in-range j: fetched ahead ----------------------------------------------------
+    // The i--j--k stage below walks the rows of all in-range j laid end to end, 64 slots per chunk.  A
+    // chunk's slot -> (owner rank, owner's packed word, row entry) fetch is issued TWO CHUNKS AHEAD of its
+    // evaluation -- the first two right here, before the j--i--k stage -- so the row fetch (global memory for
+    // the big boxes) is never waited for.
+    int nbefore = 0;                                         // row ends in the chunks already fetched (wave-uniform)
+    auto fetch = [&](int t, int& own, int& wj, uint32_t& ent) {
+        const unsigned long long M = ws->cm[t >> 6];         // one address for the whole wave
+        const unsigned int mlo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)M);
+        const unsigned int mhi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(M >> 32));
+        own = nbefore + (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        nbefore += __popc(mlo) + __popc(mhi);
+        const int jj = __builtin_amdgcn_ds_bpermute(own << 2, jv);
+        const int st = __builtin_amdgcn_ds_bpermute(own << 2, stv);
+        wj = __builtin_amdgcn_ds_bpermute(own << 2, wv);
+        ent = t < T ? row(jj, t - st) : 0u;
+    };
+    int own_a = 0, own_b = 0, w_a = 0, w_b = 0; uint32_t ent_a = 0u, ent_b = 0u;
+    if (T > 0) fetch(lane, own_a, w_a, ent_a);
+    if (T > 64) fetch(64 + lane, own_b, w_b, ent_b);
+
+    // ---- j--i--k triplets: pairs (a < b) of in-range neighbours, one pair per lane ------------
+    // (molint.F90:302-318; a is the earlier list slot, so cos is formed in the reference's order)
+    const int npairs = cntU * (cntU - 1) / 2;
+    for (int p0 = 0; p0 < npairs; p0 += 64) {
+        const int p = p0 + lane;
+        int b = (int)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+        if (b * (b - 1) / 2 > p) --b;
+        if ((b + 1) * b / 2 <= p) ++b;
+        const int a = p - b * (b - 1) / 2;
+        if (p < npairs) {
+            // every operand in one batch of LDS reads (one round trip), whichever positions are in range
+            const int fa = ws->flag[a], fb = ws->flag[b];
+            const double qax = ws->q[0][a], qay = ws->q[1][a], qaz = ws->q[2][a];
+            const double qbx = ws->q[0][b], qby = ws->q[1][b], qbz = ws->q[2][b];
+            const double roa = ws->rinvo[a], rob = ws->rinvo[b], goa = ws->go[a], gob = ws->go[b];
+            const double rna = ws->rinvn[a], rnb = ws->rinvn[b], gna = ws->gn[a], gnb = ws->gn[b];
+            if (fa & fb & 1) {
+                const double ct = (((qax - xo) * (qbx - xo) + (qay - yo) * (qby - yo) + (qaz - zo) * (qbz - zo))
+                                   * roa) * rob;                                                // :316,365
+                if (ct < 0.99) { const double d = ct - kCos0; t3o += goa * (gob * (d * d)); ++nto; }
+            }
+            if (fa & fb & 2) {
+                const double ct = (((qax - xn) * (qbx - xn) + (qay - yn) * (qby - yn) + (qaz - zn) * (qbz - zn))
+                                   * rna) * rnb;
+                if (ct < 0.99) { const double d = ct - kCos0; t3n += gna * (gnb * (d * d)); ++ntn; }
+            }
+        }
+    }
+
+    // ---- i--j--k triplets (molint.F90:324-343): the rows of all in-range j, end to end --------
+    // Two stages.  SCAN: every slot gets the cheap part (gather, distance test); the ~1/3 that are in
+    // range are queued (entry + owner rank, 8 bytes) in the wave's scratch.  FLUSH: whenever 64 are
+    // queued (and at the end) one full pass does the expensive part -- rsqrt, reciprocal, exp and the two
+    // cosines -- with every lane busy, instead of three passes at one third occupancy.
+    int nq = 0;                                              // queued entries (wave-uniform)
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < nq) {
+            const uint32_t e2 = ws->qe[lane];
+            const int qw = ws->qown[lane];
+            const int own = qw & 31, kj = (qw >> 5) & 1023, fl = qw >> 25;
+            const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
+            double xk, yk, zk, kvx, kvy, kvz, sjx, sjy, sjz;
+            getpos(kk, xk, yk, zk);
+            getiv(k2, kvx, kvy, kvz);
+            getiv(kj, sjx, sjy, sjz);
+            const double pjx = ws->q[0][own], pjy = ws->q[1][own], pjz = ws->q[2][own];
+            const double ro = ws->rinvo[own], rn = ws->rinvn[own], go_ = ws->go[own], gn_ = ws->gn[own];
+            const double bx = ((xk + kvx) + sjx) - pjx;                          // :332,334
+            const double by = ((yk + kvy) + sjy) - pjy;
+            const double bz = ((zk + kvz) + sjz) - pjz;
+            const double s2 = bx * bx + by * by + bz * bz;                       // :335 (in range: tested at scan)
+            double rk, gk, e1k;
+            pair_terms(s2, rk, e1k, gk);
+            if (fl & 1) {
+                const double ct = (-((pjx - xo) * bx + (pjy - yo) * by + (pjz - zo) * bz) * ro) * rk;   // :320,341,365
+                if (ct < 0.99) { const double d = ct - kCos0; t3o += go_ * (gk * (d * d)); ++nto; }
+            }
+            if (fl & 2) {
+                const double ct = (-((pjx - xn) * bx + (pjy - yn) * by + (pjz - zn) * bz) * rn) * rk;
+                if (ct < 0.99) { const double d = ct - kCos0; t3n += gn_ * (gk * (d * d)); ++ntn; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        nq = 0;
+    };
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const bool valid = t < T;
+        const int own = own_a, wj = w_a;
+        const uint32_t e2 = ent_a;
+        own_a = own_b; w_a = w_b; ent_a = ent_b;
+        if (t0 + 128 < T) fetch(t + 128, own_b, w_b, ent_b);
+        const int kj = wj & 1023;
+        const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
+        double xk, yk, zk, kvx, kvy, kvz, sjx, sjy, sjz;
+        getpos(kk, xk, yk, zk);
+        getiv(k2, kvx, kvy, kvz);
+        getiv(kj, sjx, sjy, sjz);
+        const double pjx = ws->q[0][own], pjy = ws->q[1][own], pjz = ws->q[2][own];
+        const bool self = valid && (kk == i);
+        const bool selfimg = self && (k2 == ((wj >> 10) & 1023));   // the molecule itself, not an image: k's shift undoes j's
+        const bool selfmove = self && !selfimg;
+        const double box_ = ((xk + kvx) + sjx) - pjx;                            // :332,334
+        const double boy_ = ((yk + kvy) + sjy) - pjy;
+        const double boz_ = ((zk + kvz) + sjz) - pjz;
+        const double s2o = box_ * box_ + boy_ * boy_ + boz_ * boz_;              // :335
+        if (__ballot(selfmove) != 0ull) {
+            // an image of the molecule itself as third body moves with it: both geometries, in line (rare)
+            if (selfmove) {
+                const int fl = wj >> 20;
+                const double bnx = ((xn + kvx) + sjx) - pjx, bny = ((yn + kvy) + sjy) - pjy, bnz = ((zn + kvz) + sjz) - pjz;
+                const double s2n = bnx * bnx + bny * bny + bnz * bnz;
+                double rk, gk, e1k;
+                if ((s2o < kRcSq) && (fl & 1)) {
+                    pair_terms(s2o, rk, e1k, gk);
+                    const double ct = (-((pjx - xo) * box_ + (pjy - yo) * boy_ + (pjz - zo) * boz_) * ws->rinvo[own]) * rk;
+                    if (ct < 0.99) { const double d = ct - kCos0; t3o += ws->go[own] * (gk * (d * d)); ++nto; }
+                }
+                if ((s2n < kRcSq) && (fl & 2)) {
+                    pair_terms(s2n, rk, e1k, gk);
+                    const double ct = (-((pjx - xn) * bnx + (pjy - yn) * bny + (pjz - zn) * bnz) * ws->rinvn[own]) * rk;
+                    if (ct < 0.99) { const double d = ct - kCos0; t3n += ws->gn[own] * (gk * (d * d)); ++ntn; }
+                }
+            }
+        }
+        const bool inq = valid && !self && (s2o < kRcSq);                        // :361; the k == i self term is dropped
+        const unsigned long long mq = __ballot(inq);
+        const int c = __popcll(mq);
+        if (nq + c > 64) flush();
+        if (inq) {
+            const int slot = nq + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mq, 0u));
+            ws->qe[slot] = e2; ws->qown[slot] = own | (wj << 5);
+        }
+        nq += c;
+    }
+    if (nq > 0) flush();
+    __builtin_amdgcn_wave_barrier();                          // scratch is reused by the wave's next request
+
+    // Wave sums on the DPP network (no LDS round trips): afterwards lane 63 holds the totals.
+    const double eo = readlane_f64(dpp_wave_sum(kLamEps * t3o + (half == 0 ? accp : 0.0)), 63);   // :397
+    const double en = readlane_f64(dpp_wave_sum(kLamEps * t3n + (half == 1 ? accp : 0.0)), 63);
+    const unsigned int cs = (unsigned int)__builtin_amdgcn_readlane(dpp_wave_sum_i32((int)(nto | (ntn << 16))), 63);
+    nto = cs & 0xffffu; ntn = cs >> 16;
+    res.eo = eo; res.en = en;
+    res.io = (unsigned int)__popc(mo_) + nto; res.in_ = (unsigned int)__popc(mn_) + ntn;
+    res.so = so; res.sn = sn;
+    return true;
+}
+
+// One workgroup per work item {box, first request, last request+1}: the requests are
+// sorted by box on upload, so the workgroup stages that box's positions in LDS once
+// (LDSPOS) and its 16 wavefronts then serve the item's requests from LDS gathers.
+//   mode bit 0: write e_old (mirrored positions), bit 1: write e_new (trial position)
+template <bool LDSPOS>
+__global__ __launch_bounds__(1024)
+void k_move_energy(const double* __restrict__ pos, const double* __restrict__ ivect,
+                   const int* __restrict__ nivect, const uint32_t* __restrict__ listm,
+                   const int* __restrict__ nn, const int4* __restrict__ work,
+                   const int* __restrict__ req_imol, const double* __restrict__ req_trial,
+                   const int* __restrict__ perm,
+                   double* __restrict__ e_old, double* __restrict__ e_new,
+                   unsigned int* __restrict__ counts,   // [nreq][4]: inter_old, slots_old, inter_new, slots_new
+                   int N, int ivcap, int mode)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int4 w = work[blockIdx.x];
+    const int b = w.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* P  = pos + (size_t)b * N * 3;
+    const double* IV = ivect + (size_t)b * ivcap * 3;
+    const uint32_t* LM = listm + (size_t)b * N * kRow;
+    const int* NN = nn + (size_t)b * N;
+    const int niv = nivect[b];
+
+    // dynamic LDS: [positions when LDSPOS][image vectors][16 wave scratches][row lengths, one byte each, when
+    // LDSPOS] (positions at offset 0: a gather's address is one multiply and the ds_read offsets are immediates)
+    double* spos = smem;
+    double* siv = smem + (LDSPOS ? 3 * (size_t)N : 0);
+    WaveScratch* ws = reinterpret_cast<WaveScratch*>(siv + (size_t)ivcap * 3) + wave;
+    unsigned char* snn = reinterpret_cast<unsigned char*>(reinterpret_cast<WaveScratch*>(siv + (size_t)ivcap * 3) + 16);
+    for (int t = tid; t < niv * 3; t += 1024) siv[t] = IV[t];
+    if (LDSPOS) {
+        for (int t = tid; t < 3 * N; t += 1024) spos[t] = P[t];
+        for (int t = tid; t < N; t += 1024) snn[t] = (unsigned char)NN[t];      // maxneigh <= 64
+    }
+    __syncthreads();
+
+    auto getiv = [&](int k, double& x, double& y, double& z) { x = siv[3 * k]; y = siv[3 * k + 1]; z = siv[3 * k + 2]; };
+    auto getpos = [&](int jx, double& x, double& y, double& z) {
+        const double* p = LDSPOS ? (spos + 3 * (size_t)jx) : (P + 3 * (size_t)jx);
+        x = p[0]; y = p[1]; z = p[2];
+    };
+    auto row = [&](int jx, int sl) { return LM[(size_t)jx * kRow + sl]; };
+    auto nnof = [&](int jx) { return LDSPOS ? (int)snn[jx] : NN[jx]; };
+
+    // The wave's requests are m = w.y + wave + 16 k.  Lane k fetches request k's molecule (and trial position)
+    // up front; entry (lane & 31) of the molecule's own row is then fetched one request ahead of the one being
+    // evaluated, so no request starts by waiting on memory.
+    const int nmine = (w.z - w.y - wave + 15) / 16;                          // <= 64 (work items hold <= 1024 requests)
+    const int mk = w.y + wave + 16 * lane;
+    const int iall = lane < nmine ? req_imol[mk] : 0;
+    double tx = 0.0, ty = 0.0, tz = 0.0;
+    if ((mode & 2) && lane < nmine) { tx = req_trial[3 * (size_t)mk]; ty = req_trial[3 * (size_t)mk + 1]; tz = req_trial[3 * (size_t)mk + 2]; }
+    uint32_t e_nx = nmine > 0 ? row(__builtin_amdgcn_readfirstlane(iall), lane & 31) : 0u;
+
+    for (int k = 0; k < nmine; ++k) {
+        const int m = w.y + wave + 16 * k;
+        const int i = __builtin_amdgcn_readlane(iall, k);
+        const uint32_t e = e_nx;
+        if (k + 1 < nmine) e_nx = row(__builtin_amdgcn_readlane(iall, k + 1), lane & 31);
+        double xo, yo, zo;
+        getpos(i, xo, yo, zo);
+        double xn = xo, yn = yo, zn = zo;
+        if (mode & 2) { xn = readlane_f64(tx, k); yn = readlane_f64(ty, k); zn = readlane_f64(tz, k); }
+
+        MoveRes r;
+        const bool fast = move_energy_wave(getpos, getiv, row, nnof, ws, niv, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r);
+        if (!fast) {
+            Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
+            Override tr; tr.idx = i; tr.x = xn; tr.y = yn; tr.z = zn;
+            r.eo = local_energy_wave(P, IV, LM, NN, i, none, none, lane, r.io, r.so);
+            r.en = local_energy_wave(P, IV, LM, NN, i, tr, none, lane, r.in_, r.sn);
+        }
+        if (lane == 0) {
+            const size_t o = (size_t)perm[m];
+            if (mode & 1) { e_old[o] = r.eo; counts[4 * o] = r.io; counts[4 * o + 1] = r.so; }
+            if (mode & 2) { e_new[o] = r.en; counts[4 * o + 2] = r.in_; counts[4 * o + 3] = r.sn; }
+        }
+    }
+}
+
+// Single request with by-value overrides (the drop-in compute_local_real_energy call):
+// one wave, result written straight to host-visible memory.
+__global__ __launch_bounds__(64)
+void k_local_energy_single(double* __restrict__ pos, const double* __restrict__ ivect,
+                           const uint32_t* __restrict__ listm, const int* __restrict__ nn,
+                           int b, int i, Override o1, Override o2, int commit,
+                           double* __restrict__ e_out, int N, int ivcap)
+{
+    const int lane = threadIdx.x;
+    double* P = pos + (size_t)b * N * 3;
+    unsigned int ni, ns;
+    const double e = local_energy_wave(P, ivect + (size_t)b * ivcap * 3, listm + (size_t)b * N * kRow,
+                                       nn + (size_t)b * N, i, o1, o2, lane, ni, ns);
+    if (lane == 0) {
+        *e_out = e;
+        if (commit) {   // these two indices are never read from memory in this launch (overrides win)
+            if (o1.idx >= 0) { P[3 * o1.idx] = o1.x; P[3 * o1.idx + 1] = o1.y; P[3 * o1.idx + 2] = o1.z; }
+            if (o2.idx >= 0 && o2.idx != o1.idx) { P[3 * o2.idx] = o2.x; P[3 * o2.idx + 1] = o2.y; P[3 * o2.idx + 2] = o2.z; }
+        }
+    }
+}
+
+}  // namespace mw
