@@ -237,6 +237,21 @@ def main():
     e_walker0 = em.model_energy_fetch(1, 1)[0]
     name, cus, mem = em.device_info()
 
+    # the ceiling a plain device-to-device copy reaches on this box (report against nominal AND this)
+    copy_gbs = None
+    if rank == 0:
+        nbytes = 1 << 30
+        a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        b = torch.empty_like(a)
+        b.copy_(a); torch.cuda.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(10):
+            b.copy_(a)
+        t1.record(); torch.cuda.synchronize()
+        copy_gbs = 2.0 * nbytes * 10 / (t0.elapsed_time(t1) * 1e-3) / 1e9          # bytes read + bytes written
+        del a, b
+
     if rank == 0:
         sanity = None
         gold = os.path.join(ROOT, "tests", "golden", "ih4096_t015.npz")
@@ -277,6 +292,7 @@ def main():
                 "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+                "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
             },
             "kernels": {
                 "k_model_energy": {"avg_ms": ms_full, "interactions_per_launch": i_full,
