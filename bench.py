@@ -98,6 +98,49 @@ def cpu_baseline(h, xyz, moves_per_walker, budget_s=10.0):
     }
 
 
+def cpu_all_cores(args):
+    """The same bounded sample on every host core this process may use, one process per core (the Fortran modules
+    hold global state): the aggregate is what the reference's MPI build would deliver on this host's CPUs."""
+    import subprocess
+    ncores = _cpu_share()
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--moves", str(args.moves), "--sigma", str(args.sigma),
+           "--cpu-budget", str(min(args.cpu_budget, 8.0))]
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(ncores)]
+    vals = []
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        if p.returncode == 0:
+            try:
+                vals.append(json.loads(out.strip().splitlines()[-1]))
+            except (ValueError, IndexError):
+                pass
+    if not vals:
+        return None
+    return {"value": float(sum(v["value"] for v in vals)), "unit": "interactions/s", "cores": len(vals), "kind": vals[0]["kind"],
+            "sample": f"{len(vals)} concurrent processes, each the single-core sample", "cpu": vals[0]["cpu"]}
+
+
+def _cpu_share():
+    """Host cores this job may really use: the cgroup CPU quota if there is one, else the affinity mask, and never
+    more than 16 processes (a one-GPU box's share of the host)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            f = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if f[0] != "max":
+                    n = min(n, max(1, int(int(f[0]) / int(f[1]))))
+            else:
+                q = int(f[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 16))
+
+
 def _cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -118,11 +161,20 @@ def main():
     ap.add_argument("--sigma", type=float, default=0.15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)   # one process of the all-cores CPU leg
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank computes on device 0 (use with --backend gloo)")
     args = ap.parse_args()
+
+    if args.cpu_worker:                       # child of cpu_all_cores(): never touches the GPU
+        h, xs = make_walkers(0, 1, args.sigma)
+        print(json.dumps(cpu_baseline(h, xs[0], args.moves, args.cpu_budget)), flush=True)
+        return
+    all_cores = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        all_cores = cpu_all_cores(args)       # before this process initialises the GPU
 
     import torch
     import torch.distributed as dist
@@ -311,6 +363,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(h, xs[0], M, args.cpu_budget)
+            out["cpu_baseline"]["all_cores"] = all_cores
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
