@@ -708,6 +708,26 @@ int mw_moves_upload(int n, const int* ils, const int* imol, const double* trial_
             int4 w; w.x = b; w.y = s; w.z = std::min(s + chunk, start[(size_t)b + 1]); w.w = 0;
             work.push_back(w);
         }
+    // XCD-aware order.  Workgroups are dealt to the 8 XCDs round-robin (workgroup w runs on XCD w % 8) and every XCD
+    // has its own L2, so the work items of one box -- which all stage the same positions and walk the same list
+    // rows -- are placed on ONE XCD, one after the other: slot k*8 + x holds the k-th item of the boxes with
+    // (box index) % 8 == x.  (When the eight sequences differ in length the tail is dealt out as it comes.)
+    if (getenv("MW_NO_XCD_ORDER") == nullptr && work.size() >= 16) {
+        constexpr int kXcd = 8;
+        std::vector<std::vector<int4>> seq(kXcd);
+        int boxrank = -1, lastbox = -1;
+        for (const int4& w : work) {
+            if (w.x != lastbox) { ++boxrank; lastbox = w.x; }      // rank among the boxes that have requests
+            seq[(size_t)(boxrank % kXcd)].push_back(w);
+        }
+        std::vector<int4> ordered;
+        ordered.reserve(work.size());
+        std::vector<size_t> at(kXcd, 0);
+        while (ordered.size() < work.size())
+            for (int x = 0; x < kXcd; ++x)
+                if (at[x] < seq[x].size()) ordered.push_back(seq[x][at[x]++]);
+        work.swap(ordered);
+    }
     if (ensure_moves(n)) return 1;
     if ((int)work.size() > g.mwork_cap) {
         HIPCHK(hipStreamSynchronize(g.stream));
