@@ -114,9 +114,10 @@ bool lds_fits(int N, int ivcap)
     return kQueue1024 + (size_t)(3 * (size_t)N + 3 * (size_t)ivcap) * sizeof(double) <= (size_t)kLdsBudget;
 }
 constexpr size_t kMoveScratch = 16 * sizeof(mw::WaveScratch);
+constexpr size_t kMoveStage = (size_t)mw::kMoveChunk * (3 * sizeof(double) + sizeof(int));   // an item's requests in LDS
 bool lds_fits_move(int N, int ivcap)
 {
-    return kMoveScratch + (size_t)(3 * (size_t)N + 3 * (size_t)ivcap) * sizeof(double) + (((size_t)N + 7) & ~(size_t)7) <= (size_t)kLdsBudget;
+    return kMoveScratch + (size_t)(3 * (size_t)N + 3 * (size_t)ivcap) * sizeof(double) + (((size_t)N + 7) & ~(size_t)7) + kMoveStage <= (size_t)kLdsBudget;
 }
 
 int check_live() { return g.live ? 0 : fail("mw: engine not initialised (call mw_init / energy_init first)"); }
@@ -701,7 +702,7 @@ int mw_moves_upload(int n, const int* ils, const int* imol, const double* trial_
     }
     // LDS staging pays when a box's 24N bytes are shared by enough requests
     g.mlds = lds_fits_move(g.N, g.ivcap) && ((long long)n * 2048 >= (long long)used_boxes * 24 * g.N);
-    const int chunk = g.mlds ? 256 : 16;
+    const int chunk = g.mlds ? mw::kMoveChunk : 16;
     std::vector<int4> work;
     for (int b = 0; b < g.nbox; ++b)
         for (int s = start[b]; s < start[(size_t)b + 1]; s += chunk) {
@@ -751,7 +752,7 @@ static int launch_moves(int mode)
     const size_t iv_bytes = kMoveScratch + (size_t)3 * g.ivcap * sizeof(double);
     if (g.mlds)
         hipLaunchKernelGGL(mw::k_move_energy<true>, dim3(g.mwork_n), dim3(1024),
-                           iv_bytes + (size_t)3 * g.N * sizeof(double) + (((size_t)g.N + 7) & ~(size_t)7), g.stream,
+                           iv_bytes + (size_t)3 * g.N * sizeof(double) + (((size_t)g.N + 7) & ~(size_t)7) + kMoveStage, g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
                            g.d_meold, g.d_menew, g.d_mcnt, g.N, g.ivcap, mode);
     else

@@ -413,6 +413,8 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
 // sorted by box on upload, so the workgroup stages that box's positions in LDS once
 // (LDSPOS) and its 16 wavefronts then serve the item's requests from LDS gathers.
 //   mode bit 0: write e_old (mirrored positions), bit 1: write e_new (trial position)
+constexpr int kMoveChunk = 256;   // requests per work item when the box is staged in LDS
+
 template <bool LDSPOS>
 __global__ __launch_bounds__(1024)
 void k_move_energy(const double* __restrict__ pos, const double* __restrict__ ivect,
@@ -434,16 +436,24 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
     const int* NN = nn + (size_t)b * N;
     const int niv = nivect[b];
 
-    // dynamic LDS: [positions when LDSPOS][image vectors][16 wave scratches][row lengths, one byte each, when
-    // LDSPOS] (positions at offset 0: a gather's address is one multiply and the ds_read offsets are immediates)
+    // dynamic LDS: [positions when LDSPOS][image vectors][16 wave scratches] and, when LDSPOS, [row lengths, one
+    // byte per molecule][the item's requests: molecule, trial position] (positions at offset 0: a gather's
+    // address is one multiply and the ds_read offsets are immediates)
     double* spos = smem;
     double* siv = smem + (LDSPOS ? 3 * (size_t)N : 0);
     WaveScratch* ws = reinterpret_cast<WaveScratch*>(siv + (size_t)ivcap * 3) + wave;
     unsigned char* snn = reinterpret_cast<unsigned char*>(reinterpret_cast<WaveScratch*>(siv + (size_t)ivcap * 3) + 16);
+    double* strial = reinterpret_cast<double*>(snn + (((size_t)N + 7) & ~(size_t)7));
+    int* simol = reinterpret_cast<int*>(strial + 3 * kMoveChunk);
+    __shared__ int s_next;                                                   // next request nobody has taken yet
+    const int nreq = w.z - w.y;                                              // <= kMoveChunk when LDSPOS
     for (int t = tid; t < niv * 3; t += 1024) siv[t] = IV[t];
     if (LDSPOS) {
         for (int t = tid; t < 3 * N; t += 1024) spos[t] = P[t];
         for (int t = tid; t < N; t += 1024) snn[t] = (unsigned char)NN[t];      // maxneigh <= 64
+        for (int t = tid; t < nreq; t += 1024) simol[t] = req_imol[w.y + t];
+        if (mode & 2) for (int t = tid; t < 3 * nreq; t += 1024) strial[t] = req_trial[3 * (size_t)w.y + t];
+        if (tid == 0) s_next = 16;
     }
     __syncthreads();
 
@@ -454,26 +464,31 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
     };
     auto row = [&](int jx, int sl) { return LM[(size_t)jx * kRow + sl]; };
     auto nnof = [&](int jx) { return LDSPOS ? (int)snn[jx] : NN[jx]; };
+    auto imol_of = [&](int q) { return LDSPOS ? simol[q] : req_imol[w.y + q]; };
 
-    // The wave's requests are m = w.y + wave + 16 k.  Lane k fetches request k's molecule (and trial position)
-    // up front; entry (lane & 31) of the molecule's own row is then fetched one request ahead of the one being
-    // evaluated, so no request starts by waiting on memory.
-    const int nmine = (w.z - w.y - wave + 15) / 16;                          // <= 64 (work items hold <= 1024 requests)
-    const int mk = w.y + wave + 16 * lane;
-    const int iall = lane < nmine ? req_imol[mk] : 0;
-    double tx = 0.0, ty = 0.0, tz = 0.0;
-    if ((mode & 2) && lane < nmine) { tx = req_trial[3 * (size_t)mk]; ty = req_trial[3 * (size_t)mk + 1]; tz = req_trial[3 * (size_t)mk + 2]; }
-    uint32_t e_nx = nmine > 0 ? row(__builtin_amdgcn_readfirstlane(iall), lane & 31) : 0u;
+    // Requests are handed out dynamically: the first sixteen go to the sixteen wavefronts, after that a wavefront
+    // takes the next untaken one (an LDS counter) when it STARTS a request, and fetches entry (lane & 31) of that
+    // molecule's own row right away -- a request never begins by waiting on memory, and a wavefront that drew
+    // cheap requests simply serves more of them (static dealing left ~8 % of the wave-time idle at the item's end).
+    // (Without LDS staging an item holds at most 16 requests: one per wavefront.)
+    int cur = wave;
+    int i = cur < nreq ? imol_of(cur) : 0;
+    uint32_t e = cur < nreq ? row(i, lane & 31) : 0u;
+    while (cur < nreq) {
+        int nxt = 0;
+        if (lane == 0) nxt = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        nxt = LDSPOS ? __builtin_amdgcn_readfirstlane(nxt) : nreq;
+        int i_nx = 0; uint32_t e_nx = 0u;
+        if (nxt < nreq) { i_nx = imol_of(nxt); e_nx = row(i_nx, lane & 31); }
 
-    for (int k = 0; k < nmine; ++k) {
-        const int m = w.y + wave + 16 * k;
-        const int i = __builtin_amdgcn_readlane(iall, k);
-        const uint32_t e = e_nx;
-        if (k + 1 < nmine) e_nx = row(__builtin_amdgcn_readlane(iall, k + 1), lane & 31);
+        const int m = w.y + cur;
         double xo, yo, zo;
         getpos(i, xo, yo, zo);
         double xn = xo, yn = yo, zn = zo;
-        if (mode & 2) { xn = readlane_f64(tx, k); yn = readlane_f64(ty, k); zn = readlane_f64(tz, k); }
+        if (mode & 2) {
+            const double* t3 = LDSPOS ? (strial + 3 * cur) : (req_trial + 3 * (size_t)m);
+            xn = t3[0]; yn = t3[1]; zn = t3[2];
+        }
 
         MoveRes r;
         const bool fast = move_energy_wave(getpos, getiv, row, nnof, ws, niv, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r);
@@ -488,6 +503,7 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
             if (mode & 1) { e_old[o] = r.eo; counts[4 * o] = r.io; counts[4 * o + 1] = r.so; }
             if (mode & 2) { e_new[o] = r.en; counts[4 * o + 2] = r.in_; counts[4 * o + 3] = r.sn; }
         }
+        cur = nxt; i = i_nx; e = e_nx;
     }
 }
 
