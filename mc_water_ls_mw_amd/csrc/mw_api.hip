@@ -75,6 +75,7 @@ struct Ctx {
     double *d_sw_mubin = nullptr, *d_sw_binwidth = nullptr;
     double *d_wweight = nullptr, *d_whist = nullptr, *d_wuhist = nullptr;   // [walker][nbins]
     unsigned long long* d_wswitch = nullptr;
+    int mchunk = 16;                 // requests per work item of the uploaded batch
     double* d_wshift = nullptr;      // per walker: sum of the minima mc_update_wl_bins subtracted since the last read-out
     unsigned long long* d_wvol = nullptr;        // [walker][2] volume moves attempted / accepted
     int* d_wflag = nullptr;                      // [walker] a volume move needed more image vectors than ivcap
@@ -114,7 +115,7 @@ bool lds_fits(int N, int ivcap)
     return kQueue1024 + (size_t)(3 * (size_t)N + 3 * (size_t)ivcap) * sizeof(double) <= (size_t)kLdsBudget;
 }
 constexpr size_t kMoveScratch = 16 * sizeof(mw::WaveScratch);
-constexpr size_t kMoveStage = (size_t)mw::kMoveChunk * (3 * sizeof(double) + sizeof(int));   // an item's requests in LDS
+constexpr size_t kMoveStage = (size_t)mw::kMoveChunk * sizeof(int);   // the molecules of an item's requests in LDS (at most)
 bool lds_fits_move(int N, int ivcap)
 {
     return kMoveScratch + (size_t)(3 * (size_t)N + 3 * (size_t)ivcap) * sizeof(double) + (((size_t)N + 7) & ~(size_t)7) + kMoveStage <= (size_t)kLdsBudget;
@@ -702,13 +703,26 @@ int mw_moves_upload(int n, const int* ils, const int* imol, const double* trial_
     }
     // LDS staging pays when a box's 24N bytes are shared by enough requests
     g.mlds = lds_fits_move(g.N, g.ivcap) && ((long long)n * 2048 >= (long long)used_boxes * 24 * g.N);
-    const int chunk = g.mlds ? mw::kMoveChunk : 16;
+    // Requests per work item.  Inside an item the wavefronts draw requests dynamically, so large items waste little
+    // at their end and stage the box once for more work; but there must be enough items to fill the chip:
+    // aim at >= 4 items per CU, between 256 and the LDS capacity kMoveChunk.
+    int chunk = 16;
+    if (g.mlds) {
+        const long long want = (long long)n / (4LL * std::max(1, g.cu));
+        chunk = 256;
+        while (chunk < mw::kMoveChunk && chunk < want) chunk *= 2;
+    }
+    g.mchunk = chunk;
     std::vector<int4> work;
-    for (int b = 0; b < g.nbox; ++b)
-        for (int s = start[b]; s < start[(size_t)b + 1]; s += chunk) {
-            int4 w; w.x = b; w.y = s; w.z = std::min(s + chunk, start[(size_t)b + 1]); w.w = 0;
+    for (int b = 0; b < g.nbox; ++b) {
+        const int s0 = start[b], cntb = start[(size_t)b + 1] - s0;
+        if (cntb == 0) continue;
+        const int nitems = (cntb + chunk - 1) / chunk;           // equal shares: no short item at the end of a box
+        for (int k = 0; k < nitems; ++k) {
+            int4 w; w.x = b; w.y = s0 + (int)((long long)cntb * k / nitems); w.z = s0 + (int)((long long)cntb * (k + 1) / nitems); w.w = 0;
             work.push_back(w);
         }
+    }
     // XCD-aware order.  Workgroups are dealt to the 8 XCDs round-robin (workgroup w runs on XCD w % 8) and every XCD
     // has its own L2, so the work items of one box -- which all stage the same positions and walk the same list
     // rows -- are placed on ONE XCD, one after the other: slot k*8 + x holds the k-th item of the boxes with
@@ -752,7 +766,7 @@ static int launch_moves(int mode)
     const size_t iv_bytes = kMoveScratch + (size_t)3 * g.ivcap * sizeof(double);
     if (g.mlds)
         hipLaunchKernelGGL(mw::k_move_energy<true>, dim3(g.mwork_n), dim3(1024),
-                           iv_bytes + (size_t)3 * g.N * sizeof(double) + (((size_t)g.N + 7) & ~(size_t)7) + kMoveStage, g.stream,
+                           iv_bytes + (size_t)3 * g.N * sizeof(double) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
                            g.d_meold, g.d_menew, g.d_mcnt, g.N, g.ivcap, mode);
     else

@@ -413,7 +413,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
 // sorted by box on upload, so the workgroup stages that box's positions in LDS once
 // (LDSPOS) and its 16 wavefronts then serve the item's requests from LDS gathers.
 //   mode bit 0: write e_old (mirrored positions), bit 1: write e_new (trial position)
-constexpr int kMoveChunk = 256;   // requests per work item when the box is staged in LDS
+constexpr int kMoveChunk = 2048;   // requests per work item when the box is staged in LDS
 
 template <bool LDSPOS>
 __global__ __launch_bounds__(1024)
@@ -437,14 +437,13 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
     const int niv = nivect[b];
 
     // dynamic LDS: [positions when LDSPOS][image vectors][16 wave scratches] and, when LDSPOS, [row lengths, one
-    // byte per molecule][the item's requests: molecule, trial position] (positions at offset 0: a gather's
+    // byte per molecule][the molecules of the item's requests] (positions at offset 0: a gather's
     // address is one multiply and the ds_read offsets are immediates)
     double* spos = smem;
     double* siv = smem + (LDSPOS ? 3 * (size_t)N : 0);
     WaveScratch* ws = reinterpret_cast<WaveScratch*>(siv + (size_t)ivcap * 3) + wave;
     unsigned char* snn = reinterpret_cast<unsigned char*>(reinterpret_cast<WaveScratch*>(siv + (size_t)ivcap * 3) + 16);
-    double* strial = reinterpret_cast<double*>(snn + (((size_t)N + 7) & ~(size_t)7));
-    int* simol = reinterpret_cast<int*>(strial + 3 * kMoveChunk);
+    int* simol = reinterpret_cast<int*>(snn + (((size_t)N + 7) & ~(size_t)7));
     __shared__ int s_next;                                                   // next request nobody has taken yet
     const int nreq = w.z - w.y;                                              // <= kMoveChunk when LDSPOS
     for (int t = tid; t < niv * 3; t += 1024) siv[t] = IV[t];
@@ -452,7 +451,6 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
         for (int t = tid; t < 3 * N; t += 1024) spos[t] = P[t];
         for (int t = tid; t < N; t += 1024) snn[t] = (unsigned char)NN[t];      // maxneigh <= 64
         for (int t = tid; t < nreq; t += 1024) simol[t] = req_imol[w.y + t];
-        if (mode & 2) for (int t = tid; t < 3 * nreq; t += 1024) strial[t] = req_trial[3 * (size_t)w.y + t];
         if (tid == 0) s_next = 16;
     }
     __syncthreads();
@@ -474,21 +472,24 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
     int cur = wave;
     int i = cur < nreq ? imol_of(cur) : 0;
     uint32_t e = cur < nreq ? row(i, lane & 31) : 0u;
+    double tx = 0.0, ty = 0.0, tz = 0.0;                     // the request's trial position, fetched with its row entry
+    if ((mode & 2) && cur < nreq) { const double* t3 = req_trial + 3 * (size_t)(w.y + cur); tx = t3[0]; ty = t3[1]; tz = t3[2]; }
     while (cur < nreq) {
         int nxt = 0;
         if (lane == 0) nxt = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         nxt = LDSPOS ? __builtin_amdgcn_readfirstlane(nxt) : nreq;
         int i_nx = 0; uint32_t e_nx = 0u;
-        if (nxt < nreq) { i_nx = imol_of(nxt); e_nx = row(i_nx, lane & 31); }
+        double tx_nx = 0.0, ty_nx = 0.0, tz_nx = 0.0;
+        if (nxt < nreq) {
+            i_nx = imol_of(nxt); e_nx = row(i_nx, lane & 31);
+            if (mode & 2) { const double* t3 = req_trial + 3 * (size_t)(w.y + nxt); tx_nx = t3[0]; ty_nx = t3[1]; tz_nx = t3[2]; }
+        }
 
         const int m = w.y + cur;
         double xo, yo, zo;
         getpos(i, xo, yo, zo);
         double xn = xo, yn = yo, zn = zo;
-        if (mode & 2) {
-            const double* t3 = LDSPOS ? (strial + 3 * cur) : (req_trial + 3 * (size_t)m);
-            xn = t3[0]; yn = t3[1]; zn = t3[2];
-        }
+        if (mode & 2) { xn = tx; yn = ty; zn = tz; }
 
         MoveRes r;
         const bool fast = move_energy_wave(getpos, getiv, row, nnof, ws, niv, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r);
@@ -503,7 +504,7 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
             if (mode & 1) { e_old[o] = r.eo; counts[4 * o] = r.io; counts[4 * o + 1] = r.so; }
             if (mode & 2) { e_new[o] = r.en; counts[4 * o + 2] = r.in_; counts[4 * o + 3] = r.sn; }
         }
-        cur = nxt; i = i_nx; e = e_nx;
+        cur = nxt; i = i_nx; e = e_nx; tx = tx_nx; ty = ty_nx; tz = tz_nx;
     }
 }
 
