@@ -126,6 +126,25 @@ __device__ __forceinline__ double dpp_wave_sum(double v)
     v += dpp_mov_f64<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
     return v;
 }
+// Minimum over the 64 lanes, same network; lanes a step does not reach keep their own value.  Lane 63 ends up with it.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_keep_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_wave_min(double v)
+{
+    double o;
+    o = dpp_keep_f64<0x111, 0xf>(v); v = o < v ? o : v;
+    o = dpp_keep_f64<0x112, 0xf>(v); v = o < v ? o : v;
+    o = dpp_keep_f64<0x114, 0xf>(v); v = o < v ? o : v;
+    o = dpp_keep_f64<0x118, 0xf>(v); v = o < v ? o : v;
+    o = dpp_keep_f64<0x142, 0xa>(v); v = o < v ? o : v;
+    o = dpp_keep_f64<0x143, 0xc>(v); v = o < v ? o : v;
+    return v;
+}
 __device__ __forceinline__ int dpp_wave_sum_i32(int v)
 {
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);

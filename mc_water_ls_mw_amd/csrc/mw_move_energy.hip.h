@@ -87,8 +87,8 @@ __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P
     while (mask) {                                                        // wave-uniform loop over in-range j
         const int jl = __ffsll((long long)mask) - 1;
         mask &= mask - 1ull;
-        const double ajx = __shfl(dx, jl, 64), ajy = __shfl(dy, jl, 64), ajz = __shfl(dz, jl, 64);
-        const double rinv_j = __shfl(rinv, jl, 64), g_j = __shfl(g, jl, 64);
+        const double ajx = readlane_f64(dx, jl), ajy = readlane_f64(dy, jl), ajz = readlane_f64(dz, jl);   // jl is wave-uniform
+        const double rinv_j = readlane_f64(rinv, jl), g_j = readlane_f64(g, jl);
 
         // j--i--k: later in-range slots of imol's own list                 :302-318
         if (inr && lane > jl) {
@@ -97,9 +97,9 @@ __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P
         }
 
         // i--j--k: jmol's list, translated by j's image                    :324-343
-        const int jj = __shfl(j, jl, 64);
-        const double sjx = __shfl(jvx, jl, 64), sjy = __shfl(jvy, jl, 64), sjz = __shfl(jvz, jl, 64);
-        const double pjx = __shfl(qx, jl, 64), pjy = __shfl(qy, jl, 64), pjz = __shfl(qz, jl, 64);
+        const int jj = __builtin_amdgcn_readlane(j, jl);
+        const double sjx = readlane_f64(jvx, jl), sjy = readlane_f64(jvy, jl), sjz = readlane_f64(jvz, jl);
+        const double pjx = readlane_f64(qx, jl), pjy = readlane_f64(qy, jl), pjz = readlane_f64(qz, jl);
         const int n_j = NN[jj];
         nslots += (unsigned int)n_j;
         if (lane < n_j) {
@@ -119,13 +119,8 @@ __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P
             }
         }
     }
-    double tot = acc2 + kLamEps * acc3;                                    // :397
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        tot += __shfl_xor(tot, off, 64);
-        ntl += (unsigned int)__shfl_xor((int)ntl, off, 64);
-    }
-    ninter += ntl;
+    const double tot = readlane_f64(dpp_wave_sum(acc2 + kLamEps * acc3), 63);                       // :397
+    ninter += (unsigned int)__builtin_amdgcn_readlane(dpp_wave_sum_i32((int)ntl), 63);
     return tot;
 }
 

@@ -532,8 +532,7 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
                         if (b == k - 1) w = w + sp.av_binwidth * sp.wl_factor / bwk;
                         mn = w < mn ? w : mn;
                     }
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(mn, off, 64); mn = o < mn ? o : mn; }
+                    mn = readlane_f64(dpp_wave_min(mn), 63);
                     for (int b = sp.start_bin - 1 + lane; b < sp.end_bin; b += 64) {
                         double w = weight[b];
                         if (b == k - 1) w = w + sp.av_binwidth * sp.wl_factor / bwk;
