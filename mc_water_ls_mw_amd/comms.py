@@ -76,6 +76,11 @@ class WalkerComms:
     def allreduce_uhist(self, unbiased_hist):
         self._delta_sync(unbiased_hist, self.uhist_last_sync)
 
+    def set_weights(self, weight_in):
+        """Re-base the weights' delta scheme (no reference counterpart: used when a farm re-gauges the synchronised
+        table, see WalkerFarm.synchronise)."""
+        self.eta_last_sync[:] = weight_in
+
     def set_histogram(self, hist_in):                 # comms_mpi.f90:533-548
         self.hist_last_sync[:] = hist_in
 

@@ -215,7 +215,7 @@ class WalkerFarm:
         comms.sync(summed[0], summed[1], summed[2])
         if regauge:
             summed[0] -= summed[0][self.grid.start_bin - 1:self.grid.end_bin].min()
-            comms.eta_last_sync[:] = summed[0]
+            comms.set_weights(summed[0])
         rep = [np.ascontiguousarray(np.broadcast_to(summed[t], (nw, nb))) for t in range(3)]
         self.em._chk(self.L.mw_sweep_set_tables_range(1, nw, *[r.ctypes.data_as(_dp) for r in rep]))
         return summed
