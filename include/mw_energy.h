@@ -184,6 +184,15 @@ int mw_sweep_get_switches(int walker, long long *switches);
  * weight + shift is the walker's table without that gauge change, which is what a many-walker farm has to
  * sum (the reference's delta scheme, comms_mpi.f90:243-277, sums the gauge change of every rank as well). */
 int mw_sweep_get_shifts_range(int first_walker, int count, double *shifts, int reset);
+/* The sums of the exchange step for a farm, taken on the device (the tables never leave it): per table and bin,
+ * sum_x[b] = sum over the walkers of the range of (table[w][b] (+ shift[w] for the weights when use_shifts) - last_x[b]),
+ * in a fixed order.  A NULL last_x / sum_x skips that table.  reset_shifts zeroes the accumulated shifts afterwards.
+ * mw_sweep_broadcast_tables writes one row (nbins doubles; NULL skips) into every walker of the range.
+ * (comms_allreduce_eta/hist/uhist, comms_mpi.f90:243-277,461-530, with every walker a rank.) */
+int mw_sweep_reduce_tables(int first_walker, int count, const double *last_w, const double *last_h, const double *last_u,
+                           double *sum_w, double *sum_h, double *sum_u, int use_shifts, int reset_shifts);
+int mw_sweep_broadcast_tables(int first_walker, int count, const double *weight, const double *histogram,
+                              const double *unbiased_hist);
 int mw_set_model_energy(int ils, double e);
 int mw_sweep_set_state(int walker, int ls, double ls_mu);
 int mw_sweep_get_state(int walker, int *ls, double *ls_mu, double *model_energy, long long *accepted);

@@ -76,7 +76,9 @@ struct Ctx {
     double *d_wweight = nullptr, *d_whist = nullptr, *d_wuhist = nullptr;   // [walker][nbins]
     unsigned long long* d_wswitch = nullptr;
     int mchunk = 16;                 // requests per work item of the uploaded batch
-    double* d_wshift = nullptr;      // per walker: sum of the minima mc_update_wl_bins subtracted since the last read-out
+    double* d_wshift = nullptr;
+    double* d_tabscratch = nullptr;  // [3 nbins last | 3 nbins out | chunks x nbins partial] for mw_sweep_reduce_tables
+    size_t tabscratch_n = 0;      // per walker: sum of the minima mc_update_wl_bins subtracted since the last read-out
     unsigned long long* d_wvol = nullptr;        // [walker][2] volume moves attempted / accepted
     int* d_wflag = nullptr;                      // [walker] a volume move needed more image vectors than ivcap
     double* d_volume = nullptr;                  // [box] |det hmatrix|
@@ -442,6 +444,7 @@ int mw_finalize(void)
     if (g.d_wls) { hipFree(g.d_wls); hipFree(g.d_wmu); hipFree(g.d_wacc); hipFree(g.d_wswitch); hipFree(g.d_wshift); hipFree(g.d_wvol); hipFree(g.d_wflag); }
     hipFree(g.d_volume);
     if (g.d_swlog) hipFree(g.d_swlog);
+    if (g.d_tabscratch) hipFree(g.d_tabscratch);
     hipFree(g.d_pos); hipFree(g.d_ivect); hipFree(g.d_nivect); hipFree(g.d_list); hipFree(g.d_listm); hipFree(g.d_nn); hipFree(g.d_stats);
     hipFree(g.d_grid); hipFree(g.d_usegrid); hipFree(g.d_cellid); hipFree(g.d_shift); hipFree(g.d_sorted);
     hipFree(g.d_ccount); hipFree(g.d_cstart); hipFree(g.d_ccursor);
@@ -1050,6 +1053,62 @@ int mw_sweep_get_shifts_range(int first_walker, int count, double* shifts, int r
     if (check_live() || check_walker(first_walker, count)) return 1;
     if (shifts) HIPCHK(hipMemcpyAsync(shifts, g.d_wshift + (first_walker - 1), sizeof(double) * count, hipMemcpyDeviceToHost, g.stream));
     if (reset) HIPCHK(hipMemsetAsync(g.d_wshift + (first_walker - 1), 0, sizeof(double) * count, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+// sum over the walkers of (table + shift - last), per table and bin; NULL last_* / sum_* skips a table
+int mw_sweep_reduce_tables(int first_walker, int count, const double* last_w, const double* last_h, const double* last_u,
+                           double* sum_w, double* sum_h, double* sum_u, int use_shifts, int reset_shifts)
+{
+    if (check_live() || check_walker(first_walker, count)) return 1;
+    const int nb = g.sp.nbins, nchunks = (count + mw::kTableChunk - 1) / mw::kTableChunk;
+    const size_t need = (size_t)nb * (6 + (size_t)nchunks);
+    if (need > g.tabscratch_n) {
+        HIPCHK(hipStreamSynchronize(g.stream));
+        if (g.d_tabscratch) HIPCHK(hipFree(g.d_tabscratch));
+        HIPCHK(hipMalloc(&g.d_tabscratch, need * sizeof(double)));
+        g.tabscratch_n = need;
+    }
+    const double* last[3] = {last_w, last_h, last_u};
+    double* out[3] = {sum_w, sum_h, sum_u};
+    const double* tabs[3] = {g.d_wweight, g.d_whist, g.d_wuhist};
+    double* d_last = g.d_tabscratch, *d_out = g.d_tabscratch + 3 * (size_t)nb, *d_part = g.d_tabscratch + 6 * (size_t)nb;
+    for (int t = 0; t < 3; ++t) {
+        if (!last[t] || !out[t]) continue;
+        HIPCHK(hipMemcpyAsync(d_last + (size_t)t * nb, last[t], sizeof(double) * nb, hipMemcpyHostToDevice, g.stream));
+        hipLaunchKernelGGL(mw::k_tables_partial, dim3(nchunks), dim3(128), 0, g.stream, tabs[t],
+                           (t == 0 && use_shifts) ? (const double*)g.d_wshift : (const double*)nullptr,
+                           d_last + (size_t)t * nb, d_part, nb, first_walker - 1, count);
+        hipLaunchKernelGGL(mw::k_tables_final, dim3(1), dim3(128), 0, g.stream, d_part, d_out + (size_t)t * nb, nb, nchunks);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out[t], d_out + (size_t)t * nb, sizeof(double) * nb, hipMemcpyDeviceToHost, g.stream));
+    }
+    if (reset_shifts) HIPCHK(hipMemsetAsync(g.d_wshift + (first_walker - 1), 0, sizeof(double) * count, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+// the same row for every walker of the range; NULL skips a table
+int mw_sweep_broadcast_tables(int first_walker, int count, const double* weight, const double* histogram, const double* unbiased_hist)
+{
+    if (check_live() || check_walker(first_walker, count)) return 1;
+    const int nb = g.sp.nbins;
+    if ((size_t)nb * 6 > g.tabscratch_n) {
+        HIPCHK(hipStreamSynchronize(g.stream));
+        if (g.d_tabscratch) HIPCHK(hipFree(g.d_tabscratch));
+        g.tabscratch_n = (size_t)nb * 8;
+        HIPCHK(hipMalloc(&g.d_tabscratch, g.tabscratch_n * sizeof(double)));
+    }
+    const double* rows[3] = {weight, histogram, unbiased_hist};
+    double* tabs[3] = {g.d_wweight, g.d_whist, g.d_wuhist};
+    for (int t = 0; t < 3; ++t) {
+        if (!rows[t]) continue;
+        double* d_row = g.d_tabscratch + (size_t)t * nb;
+        HIPCHK(hipMemcpyAsync(d_row, rows[t], sizeof(double) * nb, hipMemcpyHostToDevice, g.stream));
+        hipLaunchKernelGGL(mw::k_tables_broadcast, dim3(count), dim3(128), 0, g.stream, tabs[t], (const double*)d_row, nb, first_walker - 1);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipStreamSynchronize(g.stream));
     return 0;
 }

@@ -583,4 +583,44 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
     }
 }
 
+// =====================================================================================
+// The exchange step's host-side sums, on the device: a farm holds one table per walker, and the synchronisation
+// needs  sum over walkers of (table + gauge shift - last synchronised table)  per bin -- 3 x nbins numbers -- and
+// afterwards the same synchronised row in every walker.  Fixed summation order (chunks of walkers, then the
+// chunks in order), so the result does not depend on scheduling.
+//   k_tables_partial: grid = chunks of kTableChunk walkers, thread = bin;  k_tables_final: thread = bin
+// =====================================================================================
+constexpr int kTableChunk = 64;
+
+__global__ __launch_bounds__(128)
+void k_tables_partial(const double* __restrict__ tab, const double* __restrict__ shift, const double* __restrict__ last,
+                      double* __restrict__ partial, int nbins, int w0, int count)
+{
+    const int c = blockIdx.x;
+    const int wa = w0 + c * kTableChunk, wb = min(w0 + count, wa + kTableChunk);
+    for (int b = threadIdx.x; b < nbins; b += blockDim.x) {
+        const double l = last[b];
+        double s = 0.0;
+        for (int w = wa; w < wb; ++w) s += (tab[(size_t)w * nbins + b] + (shift ? shift[w] : 0.0)) - l;
+        partial[(size_t)c * nbins + b] = s;
+    }
+}
+
+__global__ __launch_bounds__(128)
+void k_tables_final(const double* __restrict__ partial, double* __restrict__ out, int nbins, int nchunks)
+{
+    for (int b = threadIdx.x; b < nbins; b += blockDim.x) {
+        double s = 0.0;
+        for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * nbins + b];
+        out[b] = s;
+    }
+}
+
+__global__ __launch_bounds__(128)
+void k_tables_broadcast(double* __restrict__ tab, const double* __restrict__ row, int nbins, int w0)
+{
+    double* t = tab + (size_t)(w0 + blockIdx.x) * nbins;
+    for (int b = threadIdx.x; b < nbins; b += blockDim.x) t[b] = row[b];
+}
+
 }  // namespace mw

@@ -72,13 +72,26 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             farm.set_state(w, 1, farm.initial_mu(w))
         t0 = time.perf_counter()
         synced, events, delta_g = None, [], None
-        for cyc in range(1, cycles + 1):
-            if cyc % list_update_int == 0:                         # mc_moves.F90:217-222
+        def ends_a_stretch(c):
+            """Does the host have something to do after cycle c (or before cycle c + 1)?"""
+            return (c == cycles or (c + 1) % list_update_int == 0 or c % mpi_sync_int == 0 or c % flat_chk_int == 0
+                    or (samplerun and c % deltaG_int == 0) or c + 1 == eq_mc_cycles or sched.invt_active)
+
+        cyc = 0
+        while cyc < cycles:
+            first = cyc + 1
+            if first % list_update_int == 0:                       # mc_moves.F90:217-222
                 if npt:
                     farm.sync_cells()                              # device-side volume moves changed the cells
                 em.build_neighbours_batch(1, 2 * walkers)      # checked: fails loudly on list overflow
-            set_options(cyc)
-            farm.sweep_launch(n, seed=seed + rank, move0=(cyc - 1) * n)
+            # Cycles between two host actions go out as ONE launch (the move counter simply runs on): a launch
+            # stages a walker's positions and list rows in LDS, which is amortised over n moves per cycle only.
+            # (In 1/t mode the increment changes every cycle, so cycles stay single.)
+            cyc = first
+            while not ends_a_stretch(cyc):
+                cyc += 1
+            set_options(first)
+            farm.sweep_launch(n * (cyc - first + 1), seed=seed + rank, move0=(first - 1) * n)
             if cyc % mpi_sync_int == 0:                            # mc_moves.F90:258-276
                 em.sync()
                 synced = farm.synchronise(comms, regauge=True)

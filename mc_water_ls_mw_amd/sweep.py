@@ -203,21 +203,18 @@ class WalkerFarm:
         one shared table in the reference's own gauge; identical to the reference for a single walker."""
         comms = self.local_comms() if comms is None else comms
         nb, nw = self.grid.nbins, self.nwalkers
-        tabs = [np.zeros((nw, nb)) for _ in range(3)]
-        self.em._chk(self.L.mw_sweep_get_tables_range(1, nw, *[t.ctypes.data_as(_dp) for t in tabs]))
-        if regauge:
-            shifts = np.zeros(nw)
-            self.em._chk(self.L.mw_sweep_get_shifts_range(1, nw, shifts.ctypes.data_as(_dp), 1))
-            tabs[0] += shifts[:, None]
-        last = (comms.eta_last_sync, comms.hist_last_sync, comms.uhist_last_sync)
-        # a rank's contribution = sum over its walkers of (table - last): hand WalkerComms `last + that sum`
-        summed = [last[t] + (tabs[t] - last[t][None, :]).sum(axis=0) for t in range(3)]
+        # a rank's contribution = sum over its walkers of (table - last), taken on the device (the tables stay there:
+        # 3 x nbins numbers cross PCIe instead of 3 x nwalkers x nbins); WalkerComms is handed `last + that sum`
+        last = [np.ascontiguousarray(a, dtype=np.float64) for a in (comms.eta_last_sync, comms.hist_last_sync, comms.uhist_last_sync)]
+        sums = [np.zeros(nb) for _ in range(3)]
+        self.em._chk(self.L.mw_sweep_reduce_tables(1, nw, *[a.ctypes.data_as(_dp) for a in last],
+                                                    *[a.ctypes.data_as(_dp) for a in sums], int(bool(regauge)), int(bool(regauge))))
+        summed = [last[t] + sums[t] for t in range(3)]
         comms.sync(summed[0], summed[1], summed[2])
         if regauge:
             summed[0] -= summed[0][self.grid.start_bin - 1:self.grid.end_bin].min()
             comms.set_weights(summed[0])
-        rep = [np.ascontiguousarray(np.broadcast_to(summed[t], (nw, nb))) for t in range(3)]
-        self.em._chk(self.L.mw_sweep_set_tables_range(1, nw, *[r.ctypes.data_as(_dp) for r in rep]))
+        self.em._chk(self.L.mw_sweep_broadcast_tables(1, nw, *[np.ascontiguousarray(a).ctypes.data_as(_dp) for a in summed]))
         return summed
 
     def local_comms(self):
@@ -234,22 +231,21 @@ class WalkerFarm:
         walkers since the last synchronisation are summed on the host, then over the GPUs; every walker receives
         the global histogram, which is also returned."""
         nb, nw = self.grid.nbins, self.nwalkers
-        h = np.zeros((nw, nb))
-        self.em._chk(self.L.mw_sweep_get_tables_range(1, nw, None, h.ctypes.data_as(_dp), None))
         comms = self.local_comms() if comms is None else comms
-        last = comms.hist_last_sync
-        total = last + (h - last[None, :]).sum(axis=0)     # this GPU's contribution, as WalkerComms expects it
+        last = np.ascontiguousarray(comms.hist_last_sync, dtype=np.float64)
+        inc = np.zeros(nb)
+        self.em._chk(self.L.mw_sweep_reduce_tables(1, nw, None, last.ctypes.data_as(_dp), None,
+                                                    None, inc.ctypes.data_as(_dp), None, 0, 0))
+        total = last + inc                                 # this GPU's contribution, as WalkerComms expects it
         comms.allreduce_hist(total)
-        rep = np.ascontiguousarray(np.broadcast_to(total, (nw, nb)))
-        self.em._chk(self.L.mw_sweep_set_tables_range(1, nw, None, rep.ctypes.data_as(_dp), None))
+        self.em._chk(self.L.mw_sweep_broadcast_tables(1, nw, None, np.ascontiguousarray(total).ctypes.data_as(_dp), None))
         return total
 
     def reset_histogram(self, comms=None):
         """histogram = 0 on every walker, and the synchronisation baseline with it (comms_set_histogram,
         comms_mpi.f90:533-548; mc_moves.F90:1976-1977,2105-2106)."""
         nb, nw = self.grid.nbins, self.nwalkers
-        z = np.zeros((nw, nb))
-        self.em._chk(self.L.mw_sweep_set_tables_range(1, nw, None, z.ctypes.data_as(_dp), None))
+        self.em._chk(self.L.mw_sweep_broadcast_tables(1, nw, None, np.zeros(nb).ctypes.data_as(_dp), None))
         (self.local_comms() if comms is None else comms).set_histogram(np.zeros(nb))
 
     def shift_weights(self):
