@@ -121,9 +121,8 @@ class WalkerFarm:
         h = np.zeros((nb, 3, 3))
         self.em._chk(self.L.mw_sweep_sync_cells(1, nb, h.ctypes.data_as(_dp)))
         self.em.hmatrix[:] = h
-        for b in range(nb):
-            self.em.volume[b] = abs(np.linalg.det(h[b]))
-            self.em._stale[b] = False       # positions on the device are the authoritative ones here
+        self.em.volume[:] = np.abs(np.linalg.det(h))    # one stacked call: thousands of boxes per farm
+        self.em._stale[:] = [False] * nb                # positions on the device are the authoritative ones here
         return h
 
     # -- chain synchronisation (mc_check_chain_synchronisation, mc_moves.F90:2217-2416) -------------------------
