@@ -1144,7 +1144,8 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
     const bool ldspos = pos_bytes <= 16 * 1024;        // small systems: the walker's positions stay in LDS (8 walkers per CU)
     // the reference's own system sizes: list rows (<= 32 entries) and row lengths in LDS as well
     bool ldslist = false;
-    const size_t list_bytes = (size_t)g.sp.nlat * g.N * (32 * sizeof(uint32_t) + sizeof(int));
+    int rstride = 32;
+    size_t list_bytes = (size_t)g.sp.nlat * g.N * (32 * sizeof(uint32_t) + sizeof(int));
     if (ldspos && iv_bytes + pos_bytes + list_bytes <= 17 * 1024) {
         if (g.nnmax_version != g.list_version) {     // once per list rebuild: the longest row of ANY box
             std::vector<int> st((size_t)g.nbox * 2);
@@ -1156,8 +1157,14 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
             g.nnmax_version = g.list_version;
         }
         ldslist = g.nnmax_cached <= 32;
+        if (ldslist) {                               // rows as short as the lists allow: LDS per walker sets the occupancy
+            rstride = std::max(4, (g.nnmax_cached + 3) & ~3);
+            list_bytes = (size_t)g.sp.nlat * g.N * (rstride * sizeof(uint32_t) + sizeof(int));
+            list_bytes = (list_bytes + 7) & ~(size_t)7;
+        }
     }
-    const size_t shmem = iv_bytes + (ldspos ? pos_bytes : 0) + (ldslist ? list_bytes : 0);
+    const size_t shmem = iv_bytes + (ldspos ? pos_bytes : 0) + (ldslist ? list_bytes : 0)
+                         + (g.sp.nlat == 2 ? (size_t)3 * g.sp.nbins * sizeof(double) : 0);   // weight, mu_bin, binwidth
     const bool withvol = g.sp.transP < 1.0;          // volume moves: the build that carries the out-of-line mc_volume
     auto kern = withvol ? (ldslist ? mw::k_sweep_translation<true, true, true>
                                    : (ldspos ? mw::k_sweep_translation<true, false, true> : mw::k_sweep_translation<false, false, true>))
@@ -1166,7 +1173,7 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
     hipLaunchKernelGGL(kern, dim3(count), dim3(64), shmem, g.stream, g.d_pos, g.d_hmat, g.d_ivect, g.d_nivect,
                        g.d_listm, g.d_list, g.d_nn, g.d_energy, g.d_wls, g.d_wmu, g.d_wacc, g.d_wswitch, g.d_wshift, g.sp, g.d_wweight, g.d_whist, g.d_wuhist,
                        g.d_sw_mubin, g.d_sw_binwidth, g.d_volume, g.d_wvol, g.d_wflag, g.N, g.S, g.ivcap, nmoves, seed, move0,
-                       first_walker - 1, dlog);
+                       first_walker - 1, dlog, rstride);
     HIPCHK(hipGetLastError());
     return 0;
 }

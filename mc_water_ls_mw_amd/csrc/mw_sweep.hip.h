@@ -330,14 +330,14 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
                          int* __restrict__ wls, double* __restrict__ wmu, unsigned long long* __restrict__ wacc,
                          unsigned long long* __restrict__ wswitch, double* __restrict__ wshift,
                          SweepParams sp, double* wweight, double* whist, double* wuhist,
-                         const double* __restrict__ mu_bin, const double* __restrict__ binwidth,
+                         const double* __restrict__ mu_bin_g, const double* __restrict__ binwidth_g,
                          double* volume, unsigned long long* __restrict__ wvol, int* __restrict__ wflag,
                          int N, int S, int ivcap, int nmoves, unsigned long long seed, unsigned long long move0,
-                         int walker0, double* __restrict__ mvlog)
+                         int walker0, double* __restrict__ mvlog, int rstride)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ WaveScratch ws;
-    __shared__ uint32_t squeue[kQCap * 64];      // in-range queue of the volume move's full-box energy
+    __shared__ uint32_t squeue[WITHVOL ? kQCap * 64 : 1];   // in-range queue of the volume move's full-box energy
     __shared__ double shmat[2][9], svol[2];      // the walker's cells: volume moves change them in place
     __shared__ int sniv[2];
     const int lane = threadIdx.x;
@@ -358,17 +358,32 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
             for (int t = lane; t < 3 * N; t += 64) spos[(size_t)l * N * 3 + t] = Pg[t];
         }
     }
-    // LDSLIST (the reference's own system sizes, ~48 molecules): list rows (32 entries each) and row lengths too,
-    // so that nothing in the move loop waits on global memory.  Rows longer than 32 keep the global list.
+    // LDSLIST (the reference's own system sizes, ~48 molecules): list rows (`rstride` entries each: the longest row of
+    // any box, rounded up to 4, at most 32) and row lengths too, so that nothing in the move loop waits on global
+    // memory.  (A read of slots rstride..31 of a row lands in the next row or the row lengths: masked by the caller.)
     uint32_t* srow = reinterpret_cast<uint32_t*>(spos + (LDSPOS ? (size_t)L * N * 3 : 0));
-    int* snn = reinterpret_cast<int*>(srow + (LDSLIST ? (size_t)L * N * 32 : 0));
+    int* snn = reinterpret_cast<int*>(srow + (LDSLIST ? (size_t)L * N * rstride : 0));
     if (LDSLIST) {
         for (int l = 0; l < L; ++l) {
             const uint32_t* LMg = listm + (size_t)(box0 + l) * N * kRow;
-            for (int t = lane; t < N * 32; t += 64) srow[(size_t)l * N * 32 + t] = LMg[(size_t)(t >> 5) * kRow + (t & 31)];
+            for (int t = lane; t < N * rstride; t += 64) srow[(size_t)l * N * rstride + t] = LMg[(size_t)(t / rstride) * kRow + (t % rstride)];
             for (int t = lane; t < N; t += 64) snn[l * N + t] = nn[(size_t)(box0 + l) * N + t];
         }
     }
+    // two lattices: this walker's weight table and the (shared) bin centres / widths, so that eta_weight and the
+    // Wang-Landau update after every move are LDS arithmetic; the weights go back to the walker's table at the end
+    double* sweight = reinterpret_cast<double*>(snn + (LDSLIST ? (size_t)L * N : 0));
+    double* smub = sweight + sp.nbins;
+    double* sbw = smub + sp.nbins;
+    if (L == 2) {
+        for (int t = lane; t < sp.nbins; t += 64) {
+            sweight[t] = wweight[(size_t)wlk * sp.nbins + t];
+            smub[t] = mu_bin_g[t];
+            sbw[t] = binwidth_g[t];
+        }
+    }
+    const double* mu_bin = smub;
+    const double* binwidth = sbw;
     __shared__ double srecip[2][9];          // recip_matrix(:,:,ils) of the walker's lattices
     if (lane == 0) {
         for (int l = 0; l < L; ++l) {
@@ -391,7 +406,7 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
     int flag = 0;
 
     // this walker's weight table (read by eta_weight, updated by mc_update_wl_bins) and histograms
-    double* weight = wweight + (size_t)wlk * sp.nbins;
+    double* weight = sweight;                // (LDS copy; only two-lattice runs read or update it)
     double* hist = whist + (size_t)wlk * sp.nbins;
     double* uhist = wuhist + (size_t)wlk * sp.nbins;
     unsigned long long nsw = 0;
@@ -464,9 +479,9 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
             double xo, yo, zo;
             getpos(i, xo, yo, zo);
             pn[l][0] = xo + tv[l][0]; pn[l][1] = yo + tv[l][1]; pn[l][2] = zo + tv[l][2];   // :1079
-            const uint32_t* SR = srow + (size_t)l * N * 32;
+            const uint32_t* SR = srow + (size_t)l * N * rstride;
             const int* SN = snn + l * N;
-            auto row = [&](int jx, int sl) { return LDSLIST ? SR[jx * 32 + sl] : LM[(size_t)jx * kRow + sl]; };
+            auto row = [&](int jx, int sl) { return LDSLIST ? SR[jx * rstride + sl] : LM[(size_t)jx * kRow + sl]; };
             auto nnof = [&](int jx) { return LDSLIST ? SN[jx] : NN[jx]; };
             MoveRes res;
             const bool fast = move_energy_wave(getpos, getiv, row, nnof, &ws, sniv[l], i, nnof(i), row(i, lane & 31), xo, yo, zo,
@@ -574,6 +589,8 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    if (L == 2 && sp.record && !sp.samplerun)
+        for (int t = lane; t < sp.nbins; t += 64) wweight[(size_t)wlk * sp.nbins + t] = sweight[t];
     if (lane == 0) {
         wls[wlk] = ls; wmu[wlk] = ls_mu; wacc[wlk] += acc; wswitch[wlk] += nsw; wshift[wlk] += gauge;
         wvol[2 * wlk] += nvol_try; wvol[2 * wlk + 1] += nvol_acc;
