@@ -445,3 +445,35 @@ def test_regauged_synchronisation_is_one_shared_table():
             prev_w, prev_h = wt.copy(), hi.copy()
     finally:
         em.energy_deinit()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_random_single_box_walkers_follow_the_oracle(seed, so):
+    """Seeded random systems through every build of the driver: thin cells (a molecule neighbours its own image: the
+    plain routine inside the sweep), compressed lattices (rows beyond 32 entries: the global list instead of LDS rows),
+    dilute and sheared ones, sizes that do and do not fit the LDS-resident variants."""
+    import test_gpu_fuzz as fz
+    rng = np.random.default_rng(9100 + seed)
+    for _ in range(50):
+        kind, h, x = fz.random_system(rng)
+        if kind != "gas" and len(x) >= 8:
+            break
+    temperature, max_trans = float(rng.uniform(150.0, 400.0)), float(rng.uniform(0.2, 1.1))
+    nw = 3
+    from mc_water_ls_mw_amd import lattice as lat
+    boxes = [(h, lat.thermalise(x, 0.02, 500 + seed * 10 + w)) for w in range(nw)]
+    from mc_water_ls_mw_amd.energy import load_boxes
+    from mc_water_ls_mw_amd.sweep import WalkerFarm
+    em = load_boxes([b[0] for b in boxes], [b[1] for b in boxes], maxneigh=64)
+    farm = WalkerFarm(em, 1, temperature, max_trans)
+    try:
+        for w in range(1, nw + 1):
+            farm.set_state(w, 1, 0.0)
+        nmoves = 90
+        log = farm.sweep(nmoves, seed=77 + seed, move0=3, log=True)
+        for w in range(nw):
+            ref = so.sweep(nmoves, 77 + seed, w, 3, [h], [boxes[w][1]], farm.beta, farm.max_trans, maxneigh=64)
+            _compare(log[w], ref, farm.state(w + 1), [farm.positions(w + 1)])
+    finally:
+        em.energy_deinit()
