@@ -509,7 +509,8 @@ __global__ __launch_bounds__(64)
 void k_local_energy_single(double* __restrict__ pos, const double* __restrict__ ivect,
                            const uint32_t* __restrict__ listm, const int* __restrict__ nn,
                            int b, int i, Override o1, Override o2, int commit,
-                           double* __restrict__ e_out, int N, int ivcap)
+                           double* __restrict__ e_out, int N, int ivcap,
+                           unsigned long long* __restrict__ done, unsigned long long seq)
 {
     const int lane = threadIdx.x;
     double* P = pos + (size_t)b * N * 3;
@@ -522,6 +523,9 @@ void k_local_energy_single(double* __restrict__ pos, const double* __restrict__ 
             if (o1.idx >= 0) { P[3 * o1.idx] = o1.x; P[3 * o1.idx + 1] = o1.y; P[3 * o1.idx + 2] = o1.z; }
             if (o2.idx >= 0 && o2.idx != o1.idx) { P[3 * o2.idx] = o2.x; P[3 * o2.idx + 1] = o2.y; P[3 * o2.idx + 2] = o2.z; }
         }
+        // the host spins on `done` (host-visible memory) instead of going through a stream synchronisation
+        __threadfence_system();
+        __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
