@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -20,6 +21,10 @@
 namespace {
 
 thread_local std::string g_err;
+// Every entry point takes this lock: the engine is one context per process, calls from several host threads (the
+// reference's dormant OpenMP would evaluate both lattices concurrently, mc_moves.F90:1006-1018) are serialised.
+std::recursive_mutex g_mu;
+#define MW_LOCK std::lock_guard<std::recursive_mutex> mw_lock_(g_mu)
 
 int fail(const char* fmt, ...)
 {
@@ -342,6 +347,7 @@ int mw_is_initialised(void) { return g.live ? 1 : 0; }
 
 int mw_constants(double out[8])
 {
+    MW_LOCK;
     out[0] = mw::kSigma; out[1] = mw::kEpsilon; out[2] = mw::kLambda; out[3] = mw::kBigA;
     out[4] = mw::kBigB;  out[5] = mw::kGamma;   out[6] = mw::kSmallA; out[7] = mw::kCos0;
     return 0;
@@ -349,6 +355,7 @@ int mw_constants(double out[8])
 
 int mw_init(int device, int nwater, int nboxes, int maxneigh)
 {
+    MW_LOCK;
     if (g.live) return fail("mw_init: already initialised (call mw_finalize first)");
     if (nwater < 1 || nboxes < 1) return fail("mw_init: nwater = %d, nboxes = %d must be positive", nwater, nboxes);
     if (nwater > (1 << mw::kJBits)) return fail("mw_init: nwater = %d exceeds the %d-bit packed index", nwater, mw::kJBits);
@@ -438,6 +445,7 @@ int mw_init(int device, int nwater, int nboxes, int maxneigh)
 
 int mw_finalize(void)
 {
+    MW_LOCK;
     if (!g.live) return 0;
     hipSetDevice(g.device);
     hipStreamSynchronize(g.stream);
@@ -465,6 +473,7 @@ int mw_finalize(void)
 
 int mw_device_info(char* name, int name_len, int* compute_units, long long* global_mem)
 {
+    MW_LOCK;
     if (check_live()) return 1;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, g.device));
@@ -476,6 +485,7 @@ int mw_device_info(char* name, int name_len, int* compute_units, long long* glob
 
 int mw_set_cell(int ils, const double h[9], int* nivect_out)
 {
+    MW_LOCK;
     if (check_live() || check_box(ils)) return 1;
     std::vector<double> iv;
     int imv[3] = {1, 1, 1};
@@ -509,6 +519,7 @@ int mw_set_cell(int ils, const double h[9], int* nivect_out)
 
 int mw_get_ivects(int ils, double* out, int max_vectors, int* nivect_out)
 {
+    MW_LOCK;
     if (check_live() || check_box(ils)) return 1;
     const int n = g.h_nivect[ils - 1];
     if (nivect_out) *nivect_out = n;
@@ -521,6 +532,7 @@ int mw_get_ivects(int ils, double* out, int max_vectors, int* nivect_out)
 
 int mw_upload_positions(int ils, const double* xyz)
 {
+    MW_LOCK;
     if (check_live() || check_box(ils)) return 1;
     if (!xyz) return fail("mw_upload_positions: null pointer");
     const size_t bytes = (size_t)g.N * 3 * sizeof(double);
@@ -531,6 +543,7 @@ int mw_upload_positions(int ils, const double* xyz)
 
 int mw_download_positions(int ils, double* xyz)
 {
+    MW_LOCK;
     if (check_live() || check_box(ils)) return 1;
     const size_t bytes = (size_t)g.N * 3 * sizeof(double);
     HIPCHK(hipMemcpyAsync(xyz, g.d_pos + (size_t)(ils - 1) * g.N * 3, bytes, hipMemcpyDeviceToHost, g.stream));
@@ -540,6 +553,7 @@ int mw_download_positions(int ils, double* xyz)
 
 int mw_upload_positions_range(int first_ils, int count, const double* xyz)
 {
+    MW_LOCK;
     if (check_live() || check_range(first_ils, count)) return 1;
     if (!xyz) return fail("mw_upload_positions_range: null pointer");
     const size_t per = (size_t)g.N * 3;
@@ -550,6 +564,7 @@ int mw_upload_positions_range(int first_ils, int count, const double* xyz)
 
 int mw_download_positions_range(int first_ils, int count, double* xyz)
 {
+    MW_LOCK;
     if (check_live() || check_range(first_ils, count)) return 1;
     const size_t per = (size_t)g.N * 3;
     HIPCHK(hipMemcpyAsync(xyz, g.d_pos + (size_t)(first_ils - 1) * per, per * count * sizeof(double), hipMemcpyDeviceToHost, g.stream));
@@ -559,6 +574,7 @@ int mw_download_positions_range(int first_ils, int count, double* xyz)
 
 int mw_patch_position(int ils, int imol, const double r[3])
 {
+    MW_LOCK;
     if (check_live() || check_box(ils) || check_mol(imol)) return 1;
     HIPCHK(hipMemcpyAsync(g.d_pos + ((size_t)(ils - 1) * g.N + (imol - 1)) * 3, r, 3 * sizeof(double), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -567,6 +583,7 @@ int mw_patch_position(int ils, int imol, const double r[3])
 
 int mw_build_neighbours_launch(int first_ils, int count)
 {
+    MW_LOCK;
     if (check_live() || check_range(first_ils, count)) return 1;
     for (int b = first_ils; b < first_ils + count; ++b)
         if (g.h_nivect[b - 1] < 1) return fail("mw_build_neighbours: box %d has no cell yet (call mw_set_cell / compute_ivects)", b);
@@ -575,6 +592,7 @@ int mw_build_neighbours_launch(int first_ils, int count)
 
 int mw_build_neighbours_batch(int first_ils, int count, int* min_nn, int* max_nn)
 {
+    MW_LOCK;
     if (mw_build_neighbours_launch(first_ils, count)) return 1;
     return finish_build(first_ils, count, min_nn, max_nn);
 }
@@ -583,6 +601,7 @@ int mw_build_neighbours(int ils, int* min_nn, int* max_nn) { return mw_build_nei
 
 int mw_get_neighbours(int ils, int* nn, int* jn, int* vn)
 {
+    MW_LOCK;
     if (check_live() || check_box(ils)) return 1;
     const size_t N = (size_t)g.N, S = (size_t)g.S;
     std::vector<int> hnn(N);
@@ -604,6 +623,7 @@ int mw_get_neighbours(int ils, int* nn, int* jn, int* vn)
 
 int mw_neighbour_total(int first_ils, int count, long long* total_entries)
 {
+    MW_LOCK;
     if (check_live() || check_range(first_ils, count)) return 1;
     std::vector<int> hnn((size_t)count * g.N);
     HIPCHK(hipMemcpyAsync(hnn.data(), g.d_nn + (size_t)(first_ils - 1) * g.N, hnn.size() * sizeof(int), hipMemcpyDeviceToHost, g.stream));
@@ -616,6 +636,7 @@ int mw_neighbour_total(int first_ils, int count, long long* total_entries)
 
 int mw_model_energy_counts_total(int first_ils, int count, long long* npairs, long long* ntriplets)
 {
+    MW_LOCK;
     if (check_live() || check_range(first_ils, count)) return 1;
     std::vector<unsigned long long> c((size_t)count * 2);
     HIPCHK(hipMemcpyAsync(c.data(), g.d_counts + 2 * (size_t)(first_ils - 1), c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, g.stream));
@@ -629,12 +650,14 @@ int mw_model_energy_counts_total(int first_ils, int count, long long* npairs, lo
 
 int mw_model_energy_launch(int first_ils, int count)
 {
+    MW_LOCK;
     if (check_live() || check_range(first_ils, count)) return 1;
     return launch_model_energy(first_ils, count);
 }
 
 int mw_model_energy_fetch(int first_ils, int count, double* e_out)
 {
+    MW_LOCK;
     if (check_live() || check_range(first_ils, count)) return 1;
     HIPCHK(hipMemcpyAsync(e_out, g.d_energy + (first_ils - 1), sizeof(double) * count, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -643,6 +666,7 @@ int mw_model_energy_fetch(int first_ils, int count, double* e_out)
 
 int mw_model_energy_batch(int first_ils, int count, double* e_out)
 {
+    MW_LOCK;
     if (mw_model_energy_launch(first_ils, count)) return 1;
     return mw_model_energy_fetch(first_ils, count, e_out);
 }
@@ -651,6 +675,7 @@ int mw_model_energy(int ils, double* e) { return mw_model_energy_batch(ils, 1, e
 
 int mw_model_energy_counts(int ils, long long* npairs, long long* ntriplets)
 {
+    MW_LOCK;
     if (check_live() || check_box(ils)) return 1;
     unsigned long long c[2];
     HIPCHK(hipMemcpyAsync(c, g.d_counts + 2 * (size_t)(ils - 1), sizeof c, hipMemcpyDeviceToHost, g.stream));
@@ -662,6 +687,7 @@ int mw_model_energy_counts(int ils, long long* npairs, long long* ntriplets)
 
 int mw_local_energy_patched(int ils, int imol, const double r_imol[3], int imol_prev, const double r_prev[3], double* e)
 {
+    MW_LOCK;
     if (check_live() || check_box(ils) || check_mol(imol)) return 1;
     mw::Override o1, o2;
     o1.idx = -1; o1.x = o1.y = o1.z = 0.0;
@@ -694,6 +720,7 @@ int mw_local_energy(int ils, int imol, double* e) { return mw_local_energy_patch
 
 int mw_moves_upload(int n, const int* ils, const int* imol, const double* trial_xyz)
 {
+    MW_LOCK;
     if (check_live()) return 1;
     if (n < 0) return fail("mw_moves_upload: n = %d", n);
     g.mn = 0;
@@ -796,12 +823,14 @@ static int launch_moves(int mode)
 
 int mw_moves_launch(void)
 {
+    MW_LOCK;
     if (check_live()) return 1;
     return launch_moves(3);
 }
 
 int mw_moves_fetch(double* e_old, double* e_new)
 {
+    MW_LOCK;
     if (check_live()) return 1;
     if (g.mn > 0) {
         if (e_old) HIPCHK(hipMemcpyAsync(e_old, g.d_meold, sizeof(double) * g.mn, hipMemcpyDeviceToHost, g.stream));
@@ -813,6 +842,7 @@ int mw_moves_fetch(double* e_old, double* e_new)
 
 int mw_moves_counts(long long out[4])
 {
+    MW_LOCK;
     if (check_live()) return 1;
     out[0] = out[1] = out[2] = out[3] = 0;
     if (g.mn == 0) return 0;
@@ -828,6 +858,7 @@ int mw_moves_counts(long long out[4])
 
 int mw_local_energy_batch(int n, const int* ils, const int* imol, const double* trial_xyz, double* e_out)
 {
+    MW_LOCK;
     if (mw_moves_upload(n, ils, imol, trial_xyz)) return 1;
     if (launch_moves(trial_xyz ? 2 : 1)) return 1;
     return trial_xyz ? mw_moves_fetch(nullptr, e_out) : mw_moves_fetch(e_out, nullptr);
@@ -835,6 +866,7 @@ int mw_local_energy_batch(int n, const int* ils, const int* imol, const double* 
 
 int mw_delta_energy_batch(int n, const int* ils, const int* imol, const double* trial_xyz, double* e_old, double* e_new)
 {
+    MW_LOCK;
     if (!trial_xyz) return fail("mw_delta_energy_batch: trial positions are required");
     if (mw_moves_upload(n, ils, imol, trial_xyz)) return 1;
     if (launch_moves(3)) return 1;
@@ -843,6 +875,7 @@ int mw_delta_energy_batch(int n, const int* ils, const int* imol, const double* 
 
 int mw_set_model_energy(int ils, double e)
 {
+    MW_LOCK;
     if (check_live() || check_box(ils)) return 1;
     HIPCHK(hipMemcpyAsync(g.d_energy + (ils - 1), &e, sizeof(double), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -853,6 +886,7 @@ int mw_sweep_configure(int nlat, double beta, double max_trans, int nbins, int e
                        double r_pos, double a_pos, double r_neg, double a_neg, double mu_lo, double mu_hi,
                        const double* weight, const double* mu_bin, const double* binwidth)
 {
+    MW_LOCK;
     if (check_live()) return 1;
     if (nlat != 1 && nlat != 2) return fail("mw_sweep_configure: num_lattices = %d (1 or 2)", nlat);
     if (g.nbox % nlat) return fail("mw_sweep_configure: %d boxes do not split into walkers of %d lattices", g.nbox, nlat);
@@ -921,6 +955,7 @@ static int check_walker(int first, int count)
 
 int mw_sweep_set_state(int walker, int ls, double ls_mu)
 {
+    MW_LOCK;
     if (check_live() || check_walker(walker, 1)) return 1;
     if (ls < 1 || ls > g.sp.nlat) return fail("mw_sweep_set_state: active lattice %d outside 1..%d", ls, g.sp.nlat);
     HIPCHK(hipMemcpyAsync(g.d_wls + (walker - 1), &ls, sizeof(int), hipMemcpyHostToDevice, g.stream));
@@ -931,6 +966,7 @@ int mw_sweep_set_state(int walker, int ls, double ls_mu)
 
 int mw_sweep_get_state(int walker, int* ls, double* ls_mu, double* model_energy, long long* accepted)
 {
+    MW_LOCK;
     if (check_live() || check_walker(walker, 1)) return 1;
     int l = 0; double mu = 0.0; unsigned long long a = 0; double e[2] = {0.0, 0.0};
     HIPCHK(hipMemcpyAsync(&l, g.d_wls + (walker - 1), sizeof(int), hipMemcpyDeviceToHost, g.stream));
@@ -948,6 +984,7 @@ int mw_sweep_get_state(int walker, int* ls, double* ls_mu, double* model_energy,
 int mw_sweep_options(int record, int samplerun, int always_switch, int npt,
                      double av_binwidth, double wl_factor, double log_unbiased_norm, double pressure)
 {
+    MW_LOCK;
     if (check_live()) return 1;
     if (!g.sweep_ready) return fail("mw_sweep_options: call mw_sweep_configure first");
     if ((record || always_switch) && g.sp.nlat != 2) return fail("mw_sweep_options: histograms and lattice switches need two lattices");
@@ -958,6 +995,7 @@ int mw_sweep_options(int record, int samplerun, int always_switch, int npt,
 
 int mw_sweep_moves(double transP, double dv_max_bohr)
 {
+    MW_LOCK;
     if (check_live()) return 1;
     if (!g.sweep_ready) return fail("mw_sweep_moves: call mw_sweep_configure first");
     if (!(transP > 0.0)) return fail("mw_sweep_moves: transP = %g must be positive", transP);
@@ -967,6 +1005,7 @@ int mw_sweep_moves(double transP, double dv_max_bohr)
 
 int mw_sweep_get_volume_moves(int walker, long long* attempted, long long* accepted)
 {
+    MW_LOCK;
     if (check_live() || check_walker(walker, 1)) return 1;
     unsigned long long v[2];
     int flag = 0;
@@ -983,6 +1022,7 @@ int mw_sweep_get_volume_moves(int walker, long long* attempted, long long* accep
 // are stale: read the cells back and rebuild them exactly as mw_set_cell does.  Call before rebuilding lists.
 int mw_sweep_sync_cells(int first_ils, int count, double* h_out)
 {
+    MW_LOCK;
     if (check_live() || check_range(first_ils, count)) return 1;
     std::vector<double> h((size_t)count * 9);
     std::vector<int> flags((size_t)g.nbox, 0);
@@ -1031,16 +1071,19 @@ static int tables_io(int walker, double* weight, double* hist, double* uhist, bo
 
 int mw_sweep_get_tables(int walker, double* weight, double* histogram, double* unbiased_hist)
 {
+    MW_LOCK;
     return tables_io(walker, weight, histogram, unbiased_hist, false);
 }
 
 int mw_sweep_set_tables(int walker, const double* weight, const double* histogram, const double* unbiased_hist)
 {
+    MW_LOCK;
     return tables_io(walker, const_cast<double*>(weight), const_cast<double*>(histogram), const_cast<double*>(unbiased_hist), true);
 }
 
 int mw_sweep_get_tables_range(int first_walker, int count, double* weight, double* histogram, double* unbiased_hist)
 {
+    MW_LOCK;
     if (check_live() || check_walker(first_walker, count)) return 1;
     const size_t nb = (size_t)g.sp.nbins, off = (size_t)(first_walker - 1) * nb, bytes = (size_t)count * nb * sizeof(double);
     if (weight) HIPCHK(hipMemcpyAsync(weight, g.d_wweight + off, bytes, hipMemcpyDeviceToHost, g.stream));
@@ -1052,6 +1095,7 @@ int mw_sweep_get_tables_range(int first_walker, int count, double* weight, doubl
 
 int mw_sweep_set_tables_range(int first_walker, int count, const double* weight, const double* histogram, const double* unbiased_hist)
 {
+    MW_LOCK;
     if (check_live() || check_walker(first_walker, count)) return 1;
     const size_t nb = (size_t)g.sp.nbins, off = (size_t)(first_walker - 1) * nb, bytes = (size_t)count * nb * sizeof(double);
     if (weight) HIPCHK(hipMemcpyAsync(g.d_wweight + off, weight, bytes, hipMemcpyHostToDevice, g.stream));
@@ -1063,6 +1107,7 @@ int mw_sweep_set_tables_range(int first_walker, int count, const double* weight,
 
 int mw_sweep_get_shifts_range(int first_walker, int count, double* shifts, int reset)
 {
+    MW_LOCK;
     if (check_live() || check_walker(first_walker, count)) return 1;
     if (shifts) HIPCHK(hipMemcpyAsync(shifts, g.d_wshift + (first_walker - 1), sizeof(double) * count, hipMemcpyDeviceToHost, g.stream));
     if (reset) HIPCHK(hipMemsetAsync(g.d_wshift + (first_walker - 1), 0, sizeof(double) * count, g.stream));
@@ -1074,6 +1119,7 @@ int mw_sweep_get_shifts_range(int first_walker, int count, double* shifts, int r
 int mw_sweep_reduce_tables(int first_walker, int count, const double* last_w, const double* last_h, const double* last_u,
                            double* sum_w, double* sum_h, double* sum_u, int use_shifts, int reset_shifts)
 {
+    MW_LOCK;
     if (check_live() || check_walker(first_walker, count)) return 1;
     const int nb = g.sp.nbins, nchunks = (count + mw::kTableChunk - 1) / mw::kTableChunk;
     const size_t need = (size_t)nb * (6 + (size_t)nchunks);
@@ -1105,6 +1151,7 @@ int mw_sweep_reduce_tables(int first_walker, int count, const double* last_w, co
 // the same row for every walker of the range; NULL skips a table
 int mw_sweep_broadcast_tables(int first_walker, int count, const double* weight, const double* histogram, const double* unbiased_hist)
 {
+    MW_LOCK;
     if (check_live() || check_walker(first_walker, count)) return 1;
     const int nb = g.sp.nbins;
     if ((size_t)nb * 6 > g.tabscratch_n) {
@@ -1128,6 +1175,7 @@ int mw_sweep_broadcast_tables(int first_walker, int count, const double* weight,
 
 int mw_sweep_get_switches(int walker, long long* switches)
 {
+    MW_LOCK;
     if (check_live() || check_walker(walker, 1)) return 1;
     unsigned long long v = 0;
     HIPCHK(hipMemcpyAsync(&v, g.d_wswitch + (walker - 1), sizeof v, hipMemcpyDeviceToHost, g.stream));
@@ -1138,6 +1186,7 @@ int mw_sweep_get_switches(int walker, long long* switches)
 
 int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigned long long seed, unsigned long long move0, int want_log)
 {
+    MW_LOCK;
     if (check_live() || check_walker(first_walker, count)) return 1;
     if (nmoves < 0) return fail("mw_sweep_translation: nmoves = %d", nmoves);
     if (nmoves == 0) return 0;
@@ -1193,6 +1242,7 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
 
 int mw_sweep_translation(int first_walker, int count, int nmoves, unsigned long long seed, unsigned long long move0, double* log)
 {
+    MW_LOCK;
     if (mw_sweep_translation_launch(first_walker, count, nmoves, seed, move0, log != nullptr)) return 1;
     if (log && nmoves > 0)
         HIPCHK(hipMemcpyAsync(log, g.d_swlog, sizeof(double) * (size_t)count * nmoves * 8, hipMemcpyDeviceToHost, g.stream));
@@ -1202,6 +1252,7 @@ int mw_sweep_translation(int first_walker, int count, int nmoves, unsigned long 
 
 int mw_sync(void)
 {
+    MW_LOCK;
     if (check_live()) return 1;
     HIPCHK(hipStreamSynchronize(g.stream));
     return 0;
@@ -1209,6 +1260,7 @@ int mw_sync(void)
 
 int mw_timer_start(int slot)
 {
+    MW_LOCK;
     if (check_live()) return 1;
     if (slot < 0 || slot >= kTimerSlots) return fail("mw_timer: slot %d outside 0..%d", slot, kTimerSlots - 1);
     if (!g.ev[slot][0]) { HIPCHK(hipEventCreate(&g.ev[slot][0])); HIPCHK(hipEventCreate(&g.ev[slot][1])); }
@@ -1218,6 +1270,7 @@ int mw_timer_start(int slot)
 
 int mw_timer_stop(int slot)
 {
+    MW_LOCK;
     if (check_live()) return 1;
     if (slot < 0 || slot >= kTimerSlots) return fail("mw_timer: slot %d outside 0..%d", slot, kTimerSlots - 1);
     if (!g.ev[slot][1]) return fail("mw_timer_stop: slot %d was never started", slot);
@@ -1227,6 +1280,7 @@ int mw_timer_stop(int slot)
 
 int mw_timer_elapsed_ms(int slot, float* ms)
 {
+    MW_LOCK;
     if (check_live()) return 1;
     if (slot < 0 || slot >= kTimerSlots) return fail("mw_timer: slot %d outside 0..%d", slot, kTimerSlots - 1);
     if (!g.ev[slot][1]) return fail("mw_timer_elapsed_ms: slot %d was never started", slot);

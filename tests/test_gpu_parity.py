@@ -311,3 +311,36 @@ def test_dense_boxes_take_the_plain_routines(d_oo, c_oracle):
         assert abs(em.compute_local_real_energy(17, 1) - ref[16]) <= RTOL * abs(ref[16])
     finally:
         em.energy_deinit()
+
+
+def test_concurrent_host_threads_are_serialised(c_oracle):
+    """SURVEY.md 8(b), threading: the reference's dormant OpenMP sections would call compute_local_real_energy for
+    both lattices at once (mc_moves.F90:1006-1018).  Two host threads hammer the two boxes of an Ic/Ih pair through
+    the single-call entry (ctypes releases the GIL during a call): every value must be the serial one."""
+    import threading
+    from mc_water_ls_mw_amd.energy import load_boxes
+    z1, z2 = load_golden("ic48_t015"), load_golden("ih48_t020")
+    em = load_boxes([z1["h"], z2["h"]], [z1["xyz"], z2["xyz"]])
+    try:
+        want = [np.array([em.compute_local_real_energy(i, ils) for i in range(1, 49)]) for ils in (1, 2)]
+        got = [np.zeros((6, 48)), np.zeros((6, 48))]
+        errors = []
+
+        def worker(ils):
+            try:
+                for rep in range(6):
+                    for i in range(1, 49):
+                        got[ils - 1][rep, i - 1] = em.compute_local_real_energy(i, ils)
+            except Exception as exc:          # noqa: BLE001
+                errors.append(exc)
+
+        threads = [threading.Thread(target=worker, args=(ils,)) for ils in (1, 2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors
+        for ils in (0, 1):
+            assert np.array_equal(got[ils], np.broadcast_to(want[ils], (6, 48)))
+    finally:
+        em.energy_deinit()
