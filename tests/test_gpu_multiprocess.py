@@ -1,0 +1,49 @@
+"""GPU, two processes: the N > 1 paths end to end on a one-GPU box -- two ranks (gloo) sharing device 0, each with
+its own engine context and walkers, exchanging through WalkerComms.  (The 8-GPU RCCL run is the driver's; this is
+the same code with the backend swapped.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(args, timeout=600):
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:]                     # rank 0 prints ONE json line
+    return json.loads(lines[0])
+
+
+def test_two_rank_farm_agrees_on_the_synchronised_tables():
+    res = _launch(["-m", "mc_water_ls_mw_amd.farm", "--walkers", "16", "--cycles", "30", "--sync", "10",
+                   "--backend", "gloo", "--share-device"])
+    assert res["world"] == 2 and res["ranks_agree"] is True
+    assert res["histogram_total"] > 0 and res["weight_max"] > 0
+    assert 0.02 < res["acceptance"] < 0.9
+    assert res["moves_per_s_all_ranks"] > res["moves_per_s"]
+
+
+def test_two_rank_bench_line():
+    res = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--walkers", "32",
+                   "--moves", "256", "--backend", "gloo", "--share-device", "--no-cpu-baseline"])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak" and res["unit"] == "interactions/s"
+    assert res["value"] > res["per_gpu"] > 0
+    assert res["roofline"]["kernel"] in ("k_move_energy", "k_model_energy") and res["cpu_baseline"] is None
+    assert "gloo all-reduce" in res["config"]["exchange"]
