@@ -24,7 +24,8 @@ thread_local std::string g_err;
 // Every entry point takes this lock: the engine is one context per process, calls from several host threads (the
 // reference's dormant OpenMP would evaluate both lattices concurrently, mc_moves.F90:1006-1018) are serialised.
 std::recursive_mutex g_mu;
-#define MW_LOCK std::lock_guard<std::recursive_mutex> mw_lock_(g_mu)
+struct DeviceGuard;
+#define MW_LOCK std::lock_guard<std::recursive_mutex> mw_lock_(g_mu); DeviceGuard mw_dev_
 
 int fail(const char* fmt, ...)
 {
@@ -59,6 +60,12 @@ struct Ctx {
     uint32_t* d_listm = nullptr;   // molecule-major [box][N][64]
     int* d_nn = nullptr;
     int* d_stats = nullptr;
+    // sorted slot-major layout (k_list_order): column t of d_list belongs to molecule d_order[t]
+    int* d_order = nullptr;        // [box][N]
+    int* d_nns = nullptr;          // [box][N]   row length of column t
+    int* d_cmax = nullptr;         // [box][ceil(N/64)] longest row of each group of 64 columns
+    unsigned char* d_cin = nullptr;   // [box][N]   neighbours inside the energy cutoff when the list was built
+    int order_kbits = -1;
     // cell-grid neighbour builder
     mw::GridDesc* d_grid = nullptr;
     int* d_usegrid = nullptr;
@@ -115,6 +122,20 @@ struct Ctx {
 };
 
 Ctx g;
+
+// The current HIP device is per host thread: an entry point called from a thread other than the one that ran
+// mw_init (the reference's OpenMP sections, a Python worker thread) would otherwise allocate and launch on
+// device 0.  Every entry point makes the engine's device current and restores the caller's on return.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    DeviceGuard()
+    {
+        if (g.live && hipGetDevice(&prev) == hipSuccess && prev != g.device)
+            switched = hipSetDevice(g.device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
 
 constexpr size_t kQueue1024 = (size_t)mw::kQCap * 1024 * sizeof(uint32_t);
 constexpr size_t kQueue256 = (size_t)mw::kQCap * 256 * sizeof(uint32_t);
@@ -261,7 +282,7 @@ Geo model_geo(int count)
         ge.shmem = kQueue256 + (size_t)(3 * (size_t)g.ivcap) * sizeof(double);
     }
     if (ge.nsplit > g.nsplit_max) ge.nsplit = g.nsplit_max;
-    ge.chunk = (g.N + ge.nsplit - 1) / ge.nsplit;
+    ge.chunk = (((g.N + ge.nsplit - 1) / ge.nsplit) + 63) & ~63;   // whole groups of 64 list columns (cmax is per group)
     return ge;
 }
 
@@ -272,10 +293,10 @@ int launch_model_energy(int first, int count)
     const int box0 = first - 1;
     if (ge.lds)
         hipLaunchKernelGGL((mw::k_model_energy<true, 1024>), grid, dim3(1024), ge.shmem, g.stream, g.d_pos, g.d_ivect,
-                           g.d_nivect, g.d_list, g.d_nn, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
+                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
     else
         hipLaunchKernelGGL((mw::k_model_energy<false, 256>), grid, dim3(256), ge.shmem, g.stream, g.d_pos, g.d_ivect,
-                           g.d_nivect, g.d_list, g.d_nn, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
+                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
     HIPCHK(hipGetLastError());
     // the partials of box b live at [b*nsplit .. b*nsplit+nsplit): same nsplit in both kernels
     hipLaunchKernelGGL(mw::k_sum_partials, dim3((count + 255) / 256), dim3(256), 0, g.stream, g.d_partial, g.d_cpartial,
@@ -308,13 +329,21 @@ int launch_build(int first, int count)
                            g.N, g.cstride, box0);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(mw::k_cell_search, grid, dim3(256), (size_t)g.S * 256 * sizeof(uint32_t), g.stream, g.d_pos, g.d_ivect,
-                           g.d_grid, g.d_cellid, g.d_shift, g.d_cstart, g.d_sorted, g.d_list, g.d_listm, g.d_nn, g.d_stats,
+                           g.d_grid, g.d_cellid, g.d_shift, g.d_cstart, g.d_sorted, g.d_listm, g.d_nn, g.d_cin, g.d_stats,
                            g.N, g.S, g.ivcap, g.cstride, box0);
         HIPCHK(hipGetLastError());
     }
     if (ngrid < count) {
-        hipLaunchKernelGGL(mw::k_build_neighbours, grid, dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_nivect, g.d_list,
-                           g.d_listm, g.d_nn, g.d_stats, g.d_usegrid, g.N, g.S, g.ivcap, box0);
+        hipLaunchKernelGGL(mw::k_build_neighbours, grid, dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_nivect,
+                           g.d_listm, g.d_nn, g.d_cin, g.d_stats, g.d_usegrid, g.N, g.S, g.ivcap, box0);
+        HIPCHK(hipGetLastError());
+    }
+    // the slot-major layout of the full-box kernel, columns sorted by work (mw_neighbours.hip.h, k_list_order)
+    {
+        const int ngroups = (g.N + 63) / 64;
+        const size_t shmem = g.order_kbits < 0 ? 0 : sizeof(int) * ((size_t)ngroups << g.order_kbits);
+        hipLaunchKernelGGL(mw::k_list_order, dim3(count), dim3(1024), shmem, g.stream, g.d_listm, g.d_nn, g.d_cin, g.d_stats,
+                           g.d_list, g.d_order, g.d_nns, g.d_cmax, g.N, g.S, box0, g.order_kbits);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -400,6 +429,24 @@ int mw_init(int device, int nwater, int nboxes, int maxneigh)
     HIPCHK(hipMalloc(&g.d_listm, nb * N * (size_t)mw::kRow * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.d_nn, nb * N * sizeof(int)));
     HIPCHK(hipMalloc(&g.d_stats, nb * 2 * sizeof(int)));
+    {
+        const size_t ngroups = (N + 63) / 64;
+        HIPCHK(hipMalloc(&g.d_order, nb * N * sizeof(int)));
+        HIPCHK(hipMalloc(&g.d_nns, nb * N * sizeof(int)));
+        HIPCHK(hipMalloc(&g.d_cmax, nb * ngroups * sizeof(int)));
+        HIPCHK(hipMalloc(&g.d_cin, nb * N));
+        HIPCHK(hipMemset(g.d_nns, 0, nb * N * sizeof(int)));
+        HIPCHK(hipMemset(g.d_cmax, 0, nb * ngroups * sizeof(int)));
+        HIPCHK(hipMemset(g.d_cin, 0, nb * N));
+        // identity order until the first list build (an energy call before any build sees empty rows anyway)
+        std::vector<int> ident(nb * N);
+        for (size_t b = 0; b < nb; ++b) for (size_t i = 0; i < N; ++i) ident[b * N + i] = (int)i;
+        HIPCHK(hipMemcpy(g.d_order, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
+        // sort key bits: (key, group) table of k_list_order within kOrderSlots ints of LDS
+        g.order_kbits = -1;
+        for (int kb = 8; kb >= 0; --kb)
+            if ((ngroups << kb) <= (size_t)mw::kOrderSlots) { g.order_kbits = kb; break; }
+    }
     g.cstride = nwater + 64;
     HIPCHK(hipMalloc(&g.d_grid, nb * sizeof(mw::GridDesc)));
     HIPCHK(hipMalloc(&g.d_usegrid, nb * sizeof(int)));
@@ -435,6 +482,8 @@ int mw_init(int device, int nwater, int nboxes, int maxneigh)
     // the LDS-staged kernel asks for more than the default 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_model_energy<true, 1024>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_list_order),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, mw::kOrderSlots * (int)sizeof(int)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_cell_search),
                                hipFuncAttributeMaxDynamicSharedMemorySize, MW_MAXNEIGH_LIMIT * 256 * (int)sizeof(uint32_t)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_move_energy<true>),
@@ -456,6 +505,7 @@ int mw_finalize(void)
     if (g.d_swlog) hipFree(g.d_swlog);
     if (g.d_tabscratch) hipFree(g.d_tabscratch);
     hipFree(g.d_pos); hipFree(g.d_ivect); hipFree(g.d_nivect); hipFree(g.d_list); hipFree(g.d_listm); hipFree(g.d_nn); hipFree(g.d_stats);
+    hipFree(g.d_order); hipFree(g.d_nns); hipFree(g.d_cmax); hipFree(g.d_cin);
     hipFree(g.d_grid); hipFree(g.d_usegrid); hipFree(g.d_cellid); hipFree(g.d_shift); hipFree(g.d_sorted);
     hipFree(g.d_ccount); hipFree(g.d_cstart); hipFree(g.d_ccursor);
     hipFree(g.d_partial); hipFree(g.d_cpartial); hipFree(g.d_energy); hipFree(g.d_counts);
@@ -603,17 +653,17 @@ int mw_get_neighbours(int ils, int* nn, int* jn, int* vn)
 {
     MW_LOCK;
     if (check_live() || check_box(ils)) return 1;
-    const size_t N = (size_t)g.N, S = (size_t)g.S;
+    const size_t N = (size_t)g.N, S = (size_t)g.S, R = (size_t)mw::kRow;
     std::vector<int> hnn(N);
-    std::vector<uint32_t> hl(N * S);
+    std::vector<uint32_t> hl(N * R);
     HIPCHK(hipMemcpyAsync(hnn.data(), g.d_nn + (size_t)(ils - 1) * N, N * sizeof(int), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipMemcpyAsync(hl.data(), g.d_list + (size_t)(ils - 1) * N * S, N * S * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(hl.data(), g.d_listm + (size_t)(ils - 1) * N * R, N * R * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     for (size_t i = 0; i < N; ++i) {
         if (nn) nn[i] = hnn[i];
         for (size_t s = 0; s < S; ++s) {
             const bool used = (int)s < hnn[i];
-            const uint32_t e = hl[s * N + i];                      // device layout is slot-major
+            const uint32_t e = used ? hl[i * R + s] : 0u;           // molecule-major rows
             if (jn) jn[i * S + s] = used ? (int)(e & mw::kJMask) + 1 : 0;   // reference layout jn(slot, imol)
             if (vn) vn[i * S + s] = used ? (int)(e >> mw::kJBits) + 1 : 0;
         }
@@ -1233,7 +1283,7 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
                         : (ldslist ? mw::k_sweep_translation<true, true, false>
                                    : (ldspos ? mw::k_sweep_translation<true, false, false> : mw::k_sweep_translation<false, false, false>));
     hipLaunchKernelGGL(kern, dim3(count), dim3(64), shmem, g.stream, g.d_pos, g.d_hmat, g.d_ivect, g.d_nivect,
-                       g.d_listm, g.d_list, g.d_nn, g.d_energy, g.d_wls, g.d_wmu, g.d_wacc, g.d_wswitch, g.d_wshift, g.sp, g.d_wweight, g.d_whist, g.d_wuhist,
+                       g.d_listm, g.d_list, g.d_nn, g.d_order, g.d_nns, g.d_cmax, g.d_energy, g.d_wls, g.d_wmu, g.d_wacc, g.d_wswitch, g.d_wshift, g.sp, g.d_wweight, g.d_whist, g.d_wuhist,
                        g.d_sw_mubin, g.d_sw_binwidth, g.d_volume, g.d_wvol, g.d_wflag, g.N, g.S, g.ivcap, nmoves, seed, move0,
                        first_walker - 1, dlog, rstride);
     HIPCHK(hipGetLastError());

@@ -82,27 +82,47 @@ __device__ __forceinline__ double fma_sc(double a, double b, double c)
     return d;
 }
 
-// exp(x) for x <= 0 (any magnitude; underflows smoothly to 0).  n = round(x log2 e),
-// r = x - n ln2 in two pieces, degree-11 Taylor on |r| <= 0.347 (remainder < 7e-15), 2^n by ldexp.
-__device__ __forceinline__ double fast_exp_neg(double x)
+// exp(x) for -800 <= x <= 0.  n = round(x log2 e), r = x - n ln2 in two pieces, degree-10 minimax polynomial
+// on |r| <= ln2/2 (relative error 4.5e-16 over the interval, evaluated in double: tighter than the degree-11
+// Taylor sum, one multiply-add fewer), 2^n by ldexp.
+__device__ __forceinline__ double fast_exp_neg_bounded(double x)
 {
-    x = __builtin_fmax(x, -800.0);                                  // exp(-800) == 0 in double anyway
     const double n = __builtin_rint(x * 1.4426950408889634);
     double r = __builtin_fma(n, -6.93147180369123816490e-01, x);    // ln2 high part (fdlibm split)
     r = __builtin_fma(n, -1.90821492927058770002e-10, r);           // ln2 low part
-    double p = 2.50521083854417187751e-08;                           // 1/11!
-    p = fma_sc(p, r, 2.75573192239858906526e-07);                    // 1/10!
-    p = fma_sc(p, r, 2.75573192239858906526e-06);                    // 1/9!
-    p = fma_sc(p, r, 2.48015873015873015873e-05);                    // 1/8!
-    p = fma_sc(p, r, 1.98412698412698412698e-04);                    // 1/7!
-    p = fma_sc(p, r, 1.38888888888888888889e-03);                    // 1/6!
-    p = fma_sc(p, r, 8.33333333333333333333e-03);                    // 1/5!
-    p = fma_sc(p, r, 4.16666666666666666667e-02);                    // 1/4!
-    p = fma_sc(p, r, 1.66666666666666666667e-01);                    // 1/3!
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
+    double p = 2.76263932715658755431e-07;
+    p = fma_sc(p, r, 2.76401815000467573734e-06);
+    p = fma_sc(p, r, 2.48015042451010998305e-05);
+    p = fma_sc(p, r, 1.98411702687116374552e-04);
+    p = fma_sc(p, r, 1.38888889325820222981e-03);
+    p = fma_sc(p, r, 8.33333338566921363877e-03);
+    p = fma_sc(p, r, 4.16666666665728713248e-02);
+    p = fma_sc(p, r, 1.66666666665543999892e-01);
+    p = fma_sc(p, r, 5.00000000000000555112e-01);
+    p = fma_sc(p, r, 1.00000000000000666134e+00);
     p = __builtin_fma(p, r, 1.0);
     return __builtin_amdgcn_ldexp(p, (int)n);
+}
+// exp(x) for x <= 0 (any magnitude; underflows smoothly to 0)
+__device__ __forceinline__ double fast_exp_neg(double x)
+{
+    return fast_exp_neg_bounded(__builtin_fmax(x, -800.0));         // exp(-800) == 0 in double anyway
+}
+
+// The two exponentials of an in-range pair from one: with t = exp(0.2 sigma/(r - a sigma)),
+// exp(sigma/(r - a sigma)) = t^5 (molint.F90:291,459) and g = exp(gamma sigma/(r - a sigma)) = t^6 (:292,462).
+// r2 < rc^2 but r rounded onto (or within 1.2e-3 bohr of) rc: both are exactly 0 in double (t < 1e-300), which
+// the clamp reproduces while keeping the exponent inside fast_exp_neg_bounded's range.
+constexpr double kDenClamp = -1.2e-3;
+__device__ __forceinline__ void pair_terms(double r2, double& rinv, double& e1, double& g)
+{
+    rinv = fast_rsqrt(r2);                       // molint.F90:278
+    const double den = fma_sc(r2, rinv, -kSigA); // r - a sigma, r = r2 / sqrt(r2)        :286
+    const double w = fast_rcp(__builtin_fmin(den, kDenClamp));
+    const double t = fast_exp_neg_bounded(0.2 * kSigma * w);
+    const double t2 = t * t, t4 = t2 * t2;
+    e1 = t4 * t;
+    g  = t4 * t2;
 }
 
 // ---- wave / block reductions ---------------------------------------------------------

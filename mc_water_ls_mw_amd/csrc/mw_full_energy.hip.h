@@ -21,58 +21,69 @@ namespace mw {
 // tolerance: the terms are O(S0^2) ~ 0.4 while the parity bar is 1e-10 relative
 // on E_i ~ 2e-2 -- fourteen digits are left over.
 //
-// Both exponentials of a pair come from one: with t = exp(0.2*sigma/(r - a*sigma)),
-// exp(sigma/(r-a sigma)) = t^5 and g = exp(1.2 sigma/(r - a sigma)) = t^6.
+// Both exponentials of a pair come from one (pair_terms, mw_common.hip.h).
 //
-// Divergence control: phase 1 runs the cheap distance test over all list slots
-// (list read eight slots at a time, so eight coalesced loads are in flight) and
-// parks the in-range entries in a per-thread LDS queue; phase 2 runs the expensive
-// part only over that queue, so a wave's trip count is its largest in-range count
-// (4-12) rather than its largest list length (16-25).
+// One molecule per lane, and the lanes of a wavefront hold molecules that do the SAME amount of work:
+// the list builder sorts the molecules of a box by (in-range neighbours, row length) at build time
+// (k_list_order) and stores the slot-major list in that order -- column t of the list belongs to
+// molecule order[t], nns[t] is its row length, cmax[t / 64] the longest row of its group of 64.  The order
+// is a layout hint only: every in-range decision is taken here, on the current positions.
+//
+// Divergence control inside a wavefront: phase 1 runs the cheap distance test over all list slots
+// (list read eight slots at a time, so eight coalesced loads are in flight) and parks the in-range
+// entries in a per-thread LDS queue; phase 2 runs the expensive part only over that queue, so a
+// wavefront's trip count is its largest in-range count -- which the sorted order keeps within one of
+// the mean (7 instead of 10 passes on the thermal 4096-molecule boxes) -- rather than its longest row.
 //
 // LDSPOS = true : one workgroup stages the whole box's positions in LDS
 //                 (N*24 B: 96 KiB at N = 4096) and gathers r_j from there.
 // LDSPOS = false: r_j gathered from global memory (L2-resident for the sizes
 //                 that do not fit LDS, e.g. 786 KiB at N = 32768).
-//   grid = (nsplit, nboxes_in_launch); each block takes atoms [split*chunk, ...)
+//   grid = (nsplit, nboxes_in_launch); each block takes list columns [split*chunk, ...), chunk % 64 == 0
 // =====================================================================================
 struct AtomSum { double e; unsigned long long np, nt; };
 
 constexpr int kQCap = 12;   // in-range entries per molecule parked in LDS between the two phases
 
+constexpr double kAepsBSig4 = kAeps * kBigB * kSigSq * kSigSq;   // A eps B sigma^4 (molint.F90:460)
+
 // `queue` points at this thread's column of an LDS array [kQCap][BLOCK] (entry q at queue[q*BLOCK]:
-// consecutive threads, consecutive banks).  The list is read eight slots at a time and ONE CHUNK
-// AHEAD: `cur` arrives holding this molecule's first eight entries; while a chunk is being tested the
-// next one -- of this molecule, or the first of the thread's next molecule `inext` -- is already in
-// flight, so the HBM latency of the list stream hides behind the LDS gathers and distance tests.
+// consecutive threads, consecutive banks).  `t` is the thread's list column (-1: none), `mol` the molecule
+// it belongs to, `n` its row length and `nmax` (wave-uniform) the longest row among the wavefront's
+// columns.  The list is read eight slots at a time and ONE CHUNK AHEAD: `cur` arrives holding this
+// column's first eight entries; while a chunk is being tested the next one -- of this column, or the first
+// of the thread's next column `tnext` -- is already in flight, so the HBM latency of the list stream hides
+// behind the LDS gathers and distance tests.
 template <int BLOCK, typename PosFn, typename IvFn>
-__device__ __forceinline__ AtomSum atom_energy(int i, int n, const uint32_t* __restrict__ L, int N, int S,
+__device__ __forceinline__ AtomSum atom_energy(int t, int mol, int n, int nmax, const uint32_t* __restrict__ L, int N, int S,
                                                uint32_t* __restrict__ queue, PosFn getpos, IvFn getiv,
-                                               uint32_t (&cur)[8], int inext)
+                                               uint32_t (&cur)[8], int tnext)
 {
     double xi, yi, zi;
-    getpos(i, xi, yi, zi);
+    getpos(mol, xi, yi, zi);
 
     // phase 1: cheap distance test over all list slots; the in-range entries are parked in LDS.
     int cnt = 0;
     unsigned long long over = 0ull;             // in-range slots beyond the LDS queue (re-read later)
-    for (int s0 = 0; s0 < n || s0 == 0; s0 += 8) {
+    for (int s0 = 0; s0 < nmax || s0 == 0; s0 += 8) {
         uint32_t nxt[8];
-        const bool last = s0 + 8 >= n;
-        const int pi = last ? inext : i;                      // whose chunk comes next
+        const bool last = s0 + 8 >= nmax;                     // wave-uniform
+        const int pt = last ? tnext : t;                      // whose chunk comes next
         const int ps = last ? 0 : s0 + 8;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) nxt[u] = (pi >= 0 && ps + u < S) ? L[(size_t)(ps + u) * N + pi] : 0u;
+        for (int u = 0; u < 8; ++u) nxt[u] = (pt >= 0 && ps + u < S) ? L[(size_t)(ps + u) * N + pt] : 0u;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            if (s0 + u < n) {
+            if (s0 + u < nmax) {                              // wave-uniform
+                const bool live = s0 + u < n;
+                const uint32_t e = live ? cur[u] : 0u;        // a slot past the row's end: molecule 0, central image, ignored
                 double xj, yj, zj, ix, iy, iz;
-                getpos((int)(cur[u] & kJMask), xj, yj, zj);
-                getiv((int)(cur[u] >> kJBits), ix, iy, iz);
+                getpos((int)(e & kJMask), xj, yj, zj);
+                getiv((int)(e >> kJBits), ix, iy, iz);
                 const double dx = (xj + ix) - xi, dy = (yj + iy) - yi, dz = (zj + iz) - zi;   // molint.F90:447,450
                 const double r2 = dx * dx + dy * dy + dz * dz;
-                if (r2 < kRcSq) {                                                             // :454
-                    if (cnt < kQCap) queue[cnt * BLOCK] = cur[u];
+                if (live && r2 < kRcSq) {                                                     // :454
+                    if (cnt < kQCap) queue[cnt * BLOCK] = e;
                     else over |= 1ull << (s0 + u);
                     ++cnt;
                 }
@@ -93,22 +104,17 @@ __device__ __forceinline__ AtomSum atom_energy(int i, int n, const uint32_t* __r
     auto accumulate = [&](const double (&v)[6]) {
         const double dx = (v[0] + v[3]) - xi, dy = (v[1] + v[4]) - yi, dz = (v[2] + v[5]) - zi;
         const double r2 = dx * dx + dy * dy + dz * dz;
-        const double rinv = fast_rsqrt(r2);
-        const double den = fma_sc(r2, rinv, -kSigA);   // r - a sigma: < 0 inside the cutoff
-        // r2 < rc^2 but r rounded onto rc: the pair's energy is exactly 0 in the limit
-        const double w = fast_rcp(__builtin_fmin(den, -1.0e-300));
-        const double t = fast_exp_neg(0.2 * kSigma * w);
-        const double t2 = t * t, t4 = t2 * t2;
-        const double e1 = t4 * t;                   // exp(sigma/(r - a sigma))       :459
-        const double g  = t4 * t2;                  // exp(gamma sigma/(r - a sigma)) :462
-        const double q = kSigSq * rinv * rinv;
-        e2 += (kAeps * (kBigB * (q * q) - 1.0)) * e1;                                 // :460-461
-        const double ux = dx * rinv, uy = dy * rinv, uz = dz * rinv;
-        const double gx = g * ux, gy = g * uy, gz = g * uz;
-        S0 += g;  Q += g * g;
-        S1x += gx; S1y += gy; S1z += gz;
-        Sxx += gx * ux; Syy += gy * uy; Szz += gz * uz;
-        Sxy += gx * uy; Sxz += gx * uz; Syz += gy * uz;
+        double rinv, e1, g;
+        pair_terms(r2, rinv, e1, g);                                                  // :456-462
+        const double ri2 = rinv * rinv, ri4 = ri2 * ri2;
+        e2 = __builtin_fma(fma_sc(ri4, kAepsBSig4, -kAeps), e1, e2);                  // A eps (B (sigma/r)^4 - 1) e1  :460-461
+        // moments of g u with u = d / r: S1 += (g/r) d, S2 += (g/r^2) d d^T
+        const double w1 = g * rinv, w2 = g * ri2;
+        const double hx = w2 * dx, hy = w2 * dy, hz = w2 * dz;
+        S0 += g;  Q = __builtin_fma(g, g, Q);
+        S1x = __builtin_fma(w1, dx, S1x); S1y = __builtin_fma(w1, dy, S1y); S1z = __builtin_fma(w1, dz, S1z);
+        Sxx = __builtin_fma(hx, dx, Sxx); Syy = __builtin_fma(hy, dy, Syy); Szz = __builtin_fma(hz, dz, Szz);
+        Sxy = __builtin_fma(hx, dy, Sxy); Sxz = __builtin_fma(hx, dz, Sxz); Syz = __builtin_fma(hy, dz, Syz);
     };
     const int nq = cnt < kQCap ? cnt : kQCap;
     if (nq > 0) {
@@ -126,7 +132,7 @@ __device__ __forceinline__ AtomSum atom_energy(int i, int n, const uint32_t* __r
         const int s = __ffsll((long long)over) - 1;
         over &= over - 1ull;
         double v[6];
-        gather(L[(size_t)s * N + i], v);
+        gather(L[(size_t)s * N + t], v);
         accumulate(v);
     }
     const double F2 = Sxx * Sxx + Syy * Syy + Szz * Szz + 2.0 * (Sxy * Sxy + Sxz * Sxz + Syz * Syz);
@@ -143,8 +149,8 @@ template <bool LDSPOS, int BLOCK>
 __global__ __launch_bounds__(BLOCK)
 void k_model_energy(const double* __restrict__ pos, const double* __restrict__ ivect,
                     const int* __restrict__ nivect, const uint32_t* __restrict__ list,
-                    const int* __restrict__ nn, double* __restrict__ partial,
-                    unsigned long long* __restrict__ cpartial,
+                    const int* __restrict__ order, const int* __restrict__ nns, const int* __restrict__ cmax,
+                    double* __restrict__ partial, unsigned long long* __restrict__ cpartial,
                     int N, int S, int ivcap, int box0, int nsplit, int chunk)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -154,10 +160,13 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
     const int b = box0 + blockIdx.y;
     const int split = blockIdx.x;
     const int tid = threadIdx.x;
+    const int ngroups = (N + 63) >> 6;
     const double* P  = pos + (size_t)b * N * 3;
     const double* IV = ivect + (size_t)b * ivcap * 3;
     const uint32_t* L = list + (size_t)b * S * N;
-    const int* NN = nn + (size_t)b * N;
+    const int* ORD = order + (size_t)b * N;
+    const int* NNS = nns + (size_t)b * N;
+    const int* CM = cmax + (size_t)b * ngroups;
     const int niv = nivect[b];
 
     // dynamic LDS: [positions when LDSPOS][image vectors][in-range queue kQCap x BLOCK u32]; the positions
@@ -179,22 +188,30 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
 
     double esum = 0.0;
     unsigned long long np = 0, nt = 0;
-    const int a0 = split * chunk;
+    const int a0 = split * chunk;                        // a multiple of 64: a wavefront's columns are one group
     const int a1 = min(N, a0 + chunk);
-    int i = a0 + tid;
+    const int wbase = __builtin_amdgcn_readfirstlane(a0 + (tid & ~63));
     uint32_t cur[8];
-    int n_cur = 0;
-    if (i < a1) {
-        n_cur = NN[i];
+    int n_cur = 0, mol = 0;
+    {
+        const int t = a0 + tid;
+        if (t < a1) {
+            n_cur = NNS[t]; mol = ORD[t];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cur[u] = u < S ? L[(size_t)u * N + i] : 0u;
+            for (int u = 0; u < 8; ++u) cur[u] = u < S ? L[(size_t)u * N + t] : 0u;
+        }
     }
-    for (; i < a1; i += BLOCK) {
-        const int inext = i + BLOCK < a1 ? i + BLOCK : -1;
-        const int n_next = inext >= 0 ? NN[inext] : 0;          // one molecule ahead, like the list chunks
-        AtomSum a = atom_energy<BLOCK>(i, n_cur, L, N, S, queue, getpos, getiv, cur, inext);
-        esum += a.e; np += a.np; nt += a.nt;
-        n_cur = n_next;
+    for (int base = wbase; base < a1; base += BLOCK) {           // wave-uniform
+        const int t = base + (tid & 63);
+        const int tn = t + BLOCK;
+        const bool act = t < a1;
+        const int tnext = tn < a1 ? tn : -1;
+        int n_next = 0, mol_next = 0;
+        if (tnext >= 0) { n_next = NNS[tnext]; mol_next = ORD[tnext]; }      // one column ahead, like the list chunks
+        const int nmax = CM[base >> 6];
+        AtomSum a = atom_energy<BLOCK>(act ? t : -1, mol, act ? n_cur : 0, nmax, L, N, S, queue, getpos, getiv, cur, tnext);
+        if (act) { esum += a.e; np += a.np; nt += a.nt; }
+        n_cur = n_next; mol = mol_next;
     }
 
     esum = wave_sum(esum); np = wave_sum_u64(np); nt = wave_sum_u64(nt);

@@ -38,18 +38,6 @@ __device__ __forceinline__ void load_pos(const double* __restrict__ P, int j, co
     if (j == o2.idx) { x = o2.x; y = o2.y; z = o2.z; }
 }
 
-__device__ __forceinline__ void pair_terms(double r2, double& rinv, double& e1, double& g)
-{
-    rinv = fast_rsqrt(r2);                       // molint.F90:278
-    const double den = fma_sc(r2, rinv, -kSigA); // r - a sigma, r = r2 / sqrt(r2)        :286
-    // r2 < rc^2 but r rounded onto rc: the term is exactly 0 in that limit          :288
-    const double w = fast_rcp(__builtin_fmin(den, -1.0e-300));
-    const double t = fast_exp_neg(0.2 * kSigma * w);
-    const double t2 = t * t, t4 = t2 * t2;
-    e1 = t4 * t;                                 // :291
-    g  = t4 * t2;                                // :292
-}
-
 // Returns the local energy in every lane.  `ninter` / `nslots` (wave-uniform) receive the number
 // of in-range interactions as the reference enumerates them (pairs + triplet slots with
 // cos(theta) < 0.99) and the number of list slots visited (n_i + sum of n_j over in-range j),

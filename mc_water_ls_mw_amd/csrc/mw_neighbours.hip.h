@@ -19,8 +19,9 @@ namespace mw {
 // =====================================================================================
 __global__ __launch_bounds__(256)
 void k_build_neighbours(const double* __restrict__ pos, const double* __restrict__ ivect,
-                        const int* __restrict__ nivect, uint32_t* __restrict__ list,
-                        uint32_t* __restrict__ listm, int* __restrict__ nn, int* __restrict__ stats,
+                        const int* __restrict__ nivect,
+                        uint32_t* __restrict__ listm, int* __restrict__ nn, unsigned char* __restrict__ cin,
+                        int* __restrict__ stats,
                         const int* __restrict__ use_grid, int N, int S, int ivcap, int box0)
 {
 #pragma clang fp contract(off)
@@ -30,12 +31,11 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
     const double* P  = pos + (size_t)b * N * 3;
     const double* IV = ivect + (size_t)b * ivcap * 3;
     const int niv = nivect[b];
-    uint32_t* L = list + (size_t)b * S * N;
     uint32_t* LM = listm + ((size_t)b * N + (i < N ? i : 0)) * kRow;
     const bool active = i < N;
     const int ii = active ? i : 0;
     const double xi = P[3 * ii], yi = P[3 * ii + 1], zi = P[3 * ii + 2];   // molint.F90:522
-    int cnt = 0;
+    int cnt = 0, cin_ = 0;                 // cin_: entries already inside the energy cutoff (a sort key, k_list_order)
 
     for (int j = 0; j < N; ++j) {                                           // :525
         const double vx = P[3 * j] - xi, vy = P[3 * j + 1] - yi, vz = P[3 * j + 2] - zi;   // :529
@@ -43,12 +43,13 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
             const double tx = vx + IV[3 * k], ty = vy + IV[3 * k + 1], tz = vz + IV[3 * k + 2];   // :534
             const double r2 = tx * tx + ty * ty + tz * tz;                  // :535
             if (r2 < kRnSq && !(k == 0 && j == i)) {                        // :532,537
-                if (active && cnt < S) { const uint32_t e = pack_entry(j, k); L[(size_t)cnt * N + i] = e; LM[cnt] = e; }
+                if (active && cnt < S) LM[cnt] = pack_entry(j, k);
                 ++cnt;
+                cin_ += r2 < kRcSq ? 1 : 0;
             }
         }
     }
-    if (active) nn[(size_t)b * N + i] = cnt < S ? cnt : S;
+    if (active) { nn[(size_t)b * N + i] = cnt < S ? cnt : S; cin[(size_t)b * N + i] = (unsigned char)(cin_ < 255 ? cin_ : 255); }
 
     // per-box statistics: min nn, max nn (max > S means overflow)
     int mn = wave_min_i(active ? cnt : 0x7fffffff);
@@ -70,7 +71,8 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
 //     same table the reference builds -- an image outside that table is not a candidate, exactly
 //     as the reference never tests it.
 //   * The accepted entries are rank-sorted by (j, image) in LDS, which is the reference's
-//     enumeration order, before they are written in both list layouts.
+//     enumeration order, before they are written to the molecule-major list (k_list_order derives the
+//     slot-major layout).
 // Needs >= 3 grid cells along every cell vector; smaller boxes use k_build_neighbours.
 // Four launches per batch: bin (count), scan, scatter, search.
 // =====================================================================================
@@ -166,8 +168,8 @@ __global__ __launch_bounds__(256)
 void k_cell_search(const double* __restrict__ pos, const double* __restrict__ ivect,
                    const GridDesc* __restrict__ grid, const int* __restrict__ cellid,
                    const int* __restrict__ shift, const int* __restrict__ start, const int* __restrict__ sorted,
-                   uint32_t* __restrict__ list, uint32_t* __restrict__ listm,
-                   int* __restrict__ nn, int* __restrict__ stats,
+                   uint32_t* __restrict__ listm,
+                   int* __restrict__ nn, unsigned char* __restrict__ cin, int* __restrict__ stats,
                    int N, int S, int ivcap, int cstride, int box0)
 {
 #pragma clang fp contract(off)
@@ -191,7 +193,7 @@ void k_cell_search(const double* __restrict__ pos, const double* __restrict__ iv
     const int si0 = (shi & 1023) - 512, si1 = ((shi >> 10) & 1023) - 512, si2 = ((shi >> 20) & 1023) - 512;
     const int w1 = 2 * G.im[1] + 1, w2 = 2 * G.im[2] + 1;
     const int central = (G.im[0] * w1 + G.im[1]) * w2 + G.im[2];
-    int cnt = 0;
+    int cnt = 0, cin_ = 0;
 
     if (active) {
         for (int d0 = -1; d0 <= 1; ++d0) {
@@ -223,6 +225,7 @@ void k_cell_search(const double* __restrict__ pos, const double* __restrict__ iv
                         if (r2 < kRnSq) {                                                                  // :537
                             if (cnt < S) buf[cnt * 256] = ((uint32_t)j << 10) | (uint32_t)k;   // sort key: j, then image
                             ++cnt;
+                            cin_ += r2 < kRcSq ? 1 : 0;
                         }
                     }
                 }
@@ -230,23 +233,121 @@ void k_cell_search(const double* __restrict__ pos, const double* __restrict__ iv
         }
         // rank sort (keys are unique): entry a goes to slot #{keys smaller than key a}
         const int n = cnt < S ? cnt : S;
-        uint32_t* L = list + (size_t)b * S * N;
         uint32_t* LM = listm + ((size_t)b * N + i) * kRow;
         for (int a = 0; a < n; ++a) {
             const uint32_t ka = buf[a * 256];
             int r = 0;
             for (int c = 0; c < n; ++c) r += (buf[c * 256] < ka) ? 1 : 0;
-            const uint32_t e = pack_entry((int)(ka >> 10), (int)(ka & 1023u));
-            L[(size_t)r * N + i] = e;
-            LM[r] = e;
+            LM[r] = pack_entry((int)(ka >> 10), (int)(ka & 1023u));
         }
         nn[(size_t)b * N + i] = n;
+        cin[(size_t)b * N + i] = (unsigned char)(cin_ < 255 ? cin_ : 255);
     }
     int mn = wave_min_i(active ? cnt : 0x7fffffff);
     int mx = wave_max_i(active ? cnt : 0);
     if ((threadIdx.x & 63) == 0) {
         atomicMin(&stats[2 * b], mn);
         atomicMax(&stats[2 * b + 1], mx);
+    }
+}
+
+// =====================================================================================
+// Sorted slot-major copy of the list for the full-box kernel (one molecule per lane): the molecules of a box
+// are ordered by (neighbours inside the energy cutoff at build time, row length), so that the 64 lanes of a
+// wavefront run the same number of cheap distance tests and the same number of expensive pair evaluations.
+// Stable counting sort -- a box always gets the same order, so energies stay bitwise reproducible:
+//   A  histogram over (key, group of 64 consecutive molecules) in LDS,
+//   scan in (key, group) order,
+//   B  every molecule's destination = start of its (key, group) cell + its rank among the group's lanes
+//      with the same key (ballots),
+//   C  column t of the slot-major list <- row order[t] of the molecule-major list (coalesced stores).
+// kbits = number of key bits kept (the (key, group) table must fit kOrderSlots); kbits < 0: identity order.
+//   grid = boxes, block = 1024
+// =====================================================================================
+constexpr int kOrderSlots = 32768;      // ints of dynamic LDS at most (128 KiB)
+
+__global__ __launch_bounds__(1024)
+void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn, const unsigned char* __restrict__ cin,
+                  const int* __restrict__ stats, uint32_t* __restrict__ list, int* __restrict__ order,
+                  int* __restrict__ nns, int* __restrict__ cmax, int N, int S, int box0, int kbits)
+{
+    extern __shared__ __attribute__((aligned(16))) int hist[];       // [keys][groups], dynamic
+    __shared__ int wsum[16];
+    const int b = box0 + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ngroups = (N + 63) >> 6;
+    const uint32_t* LM = listm + (size_t)b * N * kRow;
+    const int* NN = nn + (size_t)b * N;
+    const unsigned char* CI = cin + (size_t)b * N;
+    uint32_t* L = list + (size_t)b * S * N;
+    int* ORD = order + (size_t)b * N;
+    int* NNS = nns + (size_t)b * N;
+    int* CM = cmax + (size_t)b * ngroups;
+    const int nmin = stats[2 * b];
+
+    auto keyof = [&](int i, int n) {
+        const int c = min((int)CI[i], 31);
+        const int nb = min(7, max(0, n - nmin) >> 1);
+        return ((c << 3) | nb) >> (8 - kbits);
+    };
+
+    if (kbits < 0) {
+        for (int i = tid; i < N; i += 1024) { ORD[i] = i; NNS[i] = min(NN[i], S); }
+    } else {
+        const int K = 1 << kbits, M = K * ngroups;
+        for (int e = tid; e < M; e += 1024) hist[e] = 0;
+        __syncthreads();
+        for (int i = tid; i < N; i += 1024) atomicAdd(&hist[keyof(i, NN[i]) * ngroups + (i >> 6)], 1);
+        __syncthreads();
+        // exclusive scan of hist[0..M): `per` consecutive elements per thread
+        const int per = (M + 1023) / 1024;
+        const int e0 = tid * per, e1 = min(M, e0 + per);
+        int local = 0;
+        for (int e = e0; e < e1; ++e) local += hist[e];
+        int incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        int run = incl - local;
+        for (int w = 0; w < wid; ++w) run += wsum[w];
+        for (int e = e0; e < e1; ++e) { const int v = hist[e]; hist[e] = run; run += v; }
+        __syncthreads();
+        for (int base = 0; base < N; base += 1024) {
+            const int i = base + tid;
+            const bool valid = i < N;
+            const int n = valid ? NN[i] : 0;
+            const int key = valid ? keyof(i, n) : 0;
+            unsigned long long same = __ballot(valid);
+            for (int bit = 0; bit < kbits; ++bit) {
+                const unsigned long long m = __ballot((key >> bit) & 1);
+                same &= ((key >> bit) & 1) ? m : ~m;
+            }
+            const int rank = __popcll(same & ((1ull << lane) - 1ull));
+            if (valid) {
+                const int dst = hist[key * ngroups + (i >> 6)] + rank;
+                ORD[dst] = i; NNS[dst] = min(n, S);
+            }
+        }
+    }
+    __syncthreads();   // ORD / NNS of this box are read back below by other threads of this workgroup
+    for (int base = 0; base < N; base += 1024) {
+        const int t = base + tid;
+        const bool valid = t < N;
+        const int i = valid ? ORD[t] : 0;
+        const int n = valid ? NNS[t] : 0;
+        const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i(n));
+        if (lane == 0 && (t >> 6) < ngroups) CM[t >> 6] = nmax;
+        const uint4* row = reinterpret_cast<const uint4*>(LM + (size_t)i * kRow);
+        for (int s4 = 0; s4 < nmax; s4 += 4) {
+            if (s4 < n) {
+                const uint4 v = row[s4 >> 2];
+                L[(size_t)s4 * N + t] = v.x;
+                if (s4 + 1 < n) L[(size_t)(s4 + 1) * N + t] = v.y;
+                if (s4 + 2 < n) L[(size_t)(s4 + 2) * N + t] = v.z;
+                if (s4 + 3 < n) L[(size_t)(s4 + 3) * N + t] = v.w;
+            }
+        }
     }
 }
 

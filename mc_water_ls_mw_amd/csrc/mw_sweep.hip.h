@@ -112,8 +112,10 @@ struct VolCtx {
     double* vol_g;
     double* ivect_g;
     int* nivect_g;
-    const uint32_t* list_g;   // slot-major list, walker's first box
-    const int* nn_g;
+    const uint32_t* list_g;   // slot-major list (columns in k_list_order's order), walker's first box
+    const int* order_g;       // molecule of each column
+    const int* nns_g;         // row length of each column
+    const int* cmax_g;        // longest row per group of 64 columns
     uint32_t* queue;          // this lane's column of an LDS queue [kQCap][64]
     int N, S, ivcap, L;
 };
@@ -185,27 +187,32 @@ __device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, 
     const double* Ps = c.spos ? c.spos + (size_t)l * c.N * 3 : nullptr;
     const double* IVl = c.siv + (size_t)l * c.ivcap * 3;
     const uint32_t* Lg = c.list_g + (size_t)l * c.S * c.N;
-    const int* NN = c.nn_g + (size_t)l * c.N;
+    const int* ORD = c.order_g + (size_t)l * c.N;
+    const int* NNS = c.nns_g + (size_t)l * c.N;
+    const int* CM = c.cmax_g + (size_t)l * ((c.N + 63) >> 6);
     auto getiv = [&](int k, double& x, double& y, double& z) { x = IVl[3 * k]; y = IVl[3 * k + 1]; z = IVl[3 * k + 2]; };
     auto getpos = [&](int j, double& x, double& y, double& z) {
         const double* p = Ps ? Ps + 3 * (size_t)j : Pg + 3 * (size_t)j;
         x = p[0]; y = p[1]; z = p[2];
     };
     double esum = 0.0;
-    int i = lane;
     uint32_t cur[8];
-    int n_cur = 0;
-    if (i < c.N) {
-        n_cur = NN[i];
+    int n_cur = 0, mol = 0;
+    if (lane < c.N) {
+        n_cur = NNS[lane]; mol = ORD[lane];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cur[u] = u < c.S ? Lg[(size_t)u * c.N + i] : 0u;
+        for (int u = 0; u < 8; ++u) cur[u] = u < c.S ? Lg[(size_t)u * c.N + lane] : 0u;
     }
-    for (; i < c.N; i += 64) {
-        const int inext = i + 64 < c.N ? i + 64 : -1;
-        const int n_next = inext >= 0 ? NN[inext] : 0;
-        AtomSum a = atom_energy<64>(i, n_cur, Lg, c.N, c.S, c.queue, getpos, getiv, cur, inext);
-        esum += a.e;
-        n_cur = n_next;
+    for (int base = 0; base < c.N; base += 64) {                 // wave-uniform: one group of 64 list columns per pass
+        const int t = base + lane;
+        const bool act = t < c.N;
+        const int tnext = t + 64 < c.N ? t + 64 : -1;
+        int n_next = 0, mol_next = 0;
+        if (tnext >= 0) { n_next = NNS[tnext]; mol_next = ORD[tnext]; }
+        const int nmax = CM[base >> 6];
+        AtomSum a = atom_energy<64>(act ? t : -1, mol, act ? n_cur : 0, nmax, Lg, c.N, c.S, c.queue, getpos, getiv, cur, tnext);
+        if (act) esum += a.e;
+        n_cur = n_next; mol = mol_next;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off, 64);
@@ -326,7 +333,8 @@ template <bool LDSPOS, bool LDSLIST, bool WITHVOL>
 __global__ __launch_bounds__(64)
 void k_sweep_translation(double* pos, double* hmat, double* ivect,
                          int* nivect, const uint32_t* __restrict__ listm, const uint32_t* __restrict__ list,
-                         const int* __restrict__ nn, double* __restrict__ energy,
+                         const int* __restrict__ nn, const int* __restrict__ order, const int* __restrict__ nns,
+                         const int* __restrict__ cmax, double* __restrict__ energy,
                          int* __restrict__ wls, double* __restrict__ wmu, unsigned long long* __restrict__ wacc,
                          unsigned long long* __restrict__ wswitch, double* __restrict__ wshift,
                          SweepParams sp, double* wweight, double* whist, double* wuhist,
@@ -400,7 +408,8 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
     vc.pos_g = pos + (size_t)box0 * N * 3; vc.spos = LDSPOS ? spos : nullptr;
     vc.shmat = &shmat[0][0]; vc.srecip = &srecip[0][0]; vc.svol = svol; vc.siv = siv; vc.sniv = sniv;
     vc.hmat_g = hmat + (size_t)box0 * 9; vc.vol_g = volume + box0; vc.ivect_g = ivect + (size_t)box0 * ivcap * 3;
-    vc.nivect_g = nivect + box0; vc.list_g = list + (size_t)box0 * S * N; vc.nn_g = nn + (size_t)box0 * N;
+    vc.nivect_g = nivect + box0; vc.list_g = list + (size_t)box0 * S * N;
+    vc.order_g = order + (size_t)box0 * N; vc.nns_g = nns + (size_t)box0 * N; vc.cmax_g = cmax + (size_t)box0 * ((N + 63) >> 6);
     vc.queue = squeue + lane; vc.N = N; vc.S = S; vc.ivcap = ivcap; vc.L = L;
     unsigned long long nvol_try = 0, nvol_acc = 0;
     int flag = 0;

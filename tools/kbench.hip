@@ -1,0 +1,114 @@
+// kbench.hip -- side-by-side timing of kernel variants on one MI355X (development tool, not product code).
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-fast-math -o tools/kbench tools/kbench.hip
+//   python tools/dump_workload.py /tmp/w.bin && tools/kbench /tmp/w.bin [rounds] [only-variant]
+//
+// The whole engine is compiled into this program (the include below), so the variants run on the engine's own
+// device state: lists built by the product builder, energies checked against the product kernel.
+#include "../mc_water_ls_mw_amd/csrc/mw_api.hip"
+#include "kbench_variants.hip.h"
+
+#include <algorithm>
+#include <functional>
+#include <map>
+
+#define CK(x) do { if ((x)) { fprintf(stderr, "FAIL %s: %s\n", #x, mw_last_error()); return 1; } } while (0)
+#define HK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP FAIL %s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+struct Variant { std::string name; std::function<void()> launch; std::vector<float> us; };
+
+template <int VAR>
+static void launch_me(int nboxes)
+{
+    const size_t shmem = (size_t)(mw::kQCap + 1) * 1024 * sizeof(uint32_t) + (size_t)(3 * (size_t)g.N + 3 * (size_t)g.ivcap) * sizeof(double);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kb::k_me<VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; }
+    const int grid = (VAR & kb::V_PERSIST) ? std::min(nboxes, g.cu) : nboxes;
+    hipLaunchKernelGGL(kb::k_me<VAR>, dim3(grid), dim3(1024), shmem, g.stream, g.d_pos, g.d_ivect, g.d_nivect, g.d_list,
+                       g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, nboxes);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: kbench workload.bin [rounds] [only]\n"); return 2; }
+    const int rounds = argc > 2 ? atoi(argv[2]) : 5;
+    const char* only = argc > 3 ? argv[3] : nullptr;
+    FILE* fh = fopen(argv[1], "rb");
+    if (!fh) { perror(argv[1]); return 2; }
+    int hdr[3];
+    double h[9];
+    if (fread(hdr, 4, 3, fh) != 3 || fread(h, 8, 9, fh) != 9) return 2;
+    const int W = hdr[0], N = hdr[1], M = hdr[2];
+    std::vector<double> pos((size_t)W * N * 3);
+    if (fread(pos.data(), 8, pos.size(), fh) != pos.size()) return 2;
+    std::vector<int> imol((size_t)W * M);
+    std::vector<double> trial((size_t)W * M * 3);
+    if (fread(imol.data(), 4, imol.size(), fh) != imol.size() || fread(trial.data(), 8, trial.size(), fh) != trial.size()) return 2;
+    fclose(fh);
+    printf("workload: %d walkers x %d molecules, %d moves/walker\n", W, N, M);
+
+    CK(mw_init(0, N, W, 50));
+    for (int b = 1; b <= W; ++b) { int niv; CK(mw_set_cell(b, h, &niv)); }
+    CK(mw_upload_positions_range(1, W, pos.data()));
+    int mn, mx;
+    CK(mw_build_neighbours_batch(1, W, &mn, &mx));
+    printf("lists: nn %d..%d\n", mn, mx);
+    std::vector<double> eref(W);
+    CK(mw_model_energy_batch(1, W, eref.data()));
+    long long np_ref, nt_ref;
+    CK(mw_model_energy_counts_total(1, W, &np_ref, &nt_ref));
+
+    std::vector<Variant> vs;
+    vs.push_back({"product", [&] { (void)launch_model_energy(1, W); }, {}});
+    vs.push_back({"me<0> same as product, variant frame", [&] { launch_me<0>(W); }, {}});
+    vs.push_back({"me<SERP>", [&] { launch_me<kb::V_SERP>(W); }, {}});
+    vs.push_back({"me<DYN>", [&] { launch_me<kb::V_DYN>(W); }, {}});
+    vs.push_back({"me<PIPE>", [&] { launch_me<kb::V_PIPE>(W); }, {}});
+    vs.push_back({"me<DYN|PIPE>", [&] { launch_me<kb::V_DYN | kb::V_PIPE>(W); }, {}});
+    vs.push_back({"me<DYN|PERSIST>", [&] { launch_me<kb::V_DYN | kb::V_PERSIST>(W); }, {}});
+    vs.push_back({"me<DYN|PIPE|PERSIST>", [&] { launch_me<kb::V_DYN | kb::V_PIPE | kb::V_PERSIST>(W); }, {}});
+    vs.push_back({"me<DYN|NOP2> (phase 1 only)", [&] { launch_me<kb::V_DYN | kb::V_NOP2>(W); }, {}});
+    vs.push_back({"me<DYN|PIPE|NOP2> (phase 1 only)", [&] { launch_me<kb::V_DYN | kb::V_PIPE | kb::V_NOP2>(W); }, {}});
+    vs.push_back({"me<DYN|NOP1> (phase 2 only, 7 entries)", [&] { launch_me<kb::V_DYN | kb::V_NOP1>(W); }, {}});
+
+    hipEvent_t e0, e1;
+    HK(hipEventCreate(&e0)); HK(hipEventCreate(&e1));
+    // correctness of every variant first (energies of all boxes against the product kernel)
+    for (auto& v : vs) {
+        if (only && v.name.find(only) == std::string::npos) continue;
+        HK(hipMemsetAsync(g.d_partial, 0, sizeof(double) * W, g.stream));
+        v.launch();
+        HK(hipGetLastError());
+        std::vector<double> e(W);
+        std::vector<unsigned long long> c((size_t)2 * W);
+        HK(hipMemcpyAsync(e.data(), g.d_partial, sizeof(double) * W, hipMemcpyDeviceToHost, g.stream));
+        HK(hipMemcpyAsync(c.data(), g.d_cpartial, sizeof(unsigned long long) * 2 * W, hipMemcpyDeviceToHost, g.stream));
+        HK(hipStreamSynchronize(g.stream));
+        double worst = 0.0;
+        long long np = 0, nt = 0;
+        for (int b = 0; b < W; ++b) { worst = std::max(worst, fabs(e[b] - eref[b]) / fabs(eref[b])); np += (long long)c[2 * b]; nt += (long long)c[2 * b + 1]; }
+        printf("check %-44s max rel diff %.2e  counts %s\n", v.name.c_str(), worst, (np == np_ref && nt == nt_ref) ? "equal" : "DIFFER");
+    }
+    // timing: interleaved rounds, 5 launches per variant per round
+    for (int r = 0; r < rounds; ++r) {
+        for (auto& v : vs) {
+            if (only && v.name.find(only) == std::string::npos) continue;
+            for (int k = 0; k < 5; ++k) {
+                HK(hipEventRecord(e0, g.stream));
+                v.launch();
+                HK(hipEventRecord(e1, g.stream));
+                HK(hipEventSynchronize(e1));
+                float ms = 0.f;
+                HK(hipEventElapsedTime(&ms, e0, e1));
+                if (r > 0 || k > 1) v.us.push_back(ms * 1e3f);
+            }
+        }
+    }
+    for (auto& v : vs) {
+        if (v.us.empty()) continue;
+        std::sort(v.us.begin(), v.us.end());
+        printf("time  %-44s median %8.1f us   min %8.1f us   (n=%zu)\n", v.name.c_str(), v.us[v.us.size() / 2], v.us[0], v.us.size());
+    }
+    CK(mw_finalize());
+    return 0;
+}
