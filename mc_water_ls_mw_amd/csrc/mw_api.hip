@@ -137,11 +137,12 @@ struct DeviceGuard {
     ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
 };
 
-constexpr size_t kQueue1024 = (size_t)mw::kQCap * 1024 * sizeof(uint32_t);
-constexpr size_t kQueue256 = (size_t)mw::kQCap * 256 * sizeof(uint32_t);
+constexpr size_t kQueue1024 = (size_t)(mw::kQCap + 1) * 1024 * sizeof(uint32_t);
+constexpr size_t kQueue256 = (size_t)(mw::kQCap + 1) * 256 * sizeof(uint32_t);
+constexpr int kFullLayout = mw::kLayoutPair;      // LDS layout of the full-box kernel's staged vectors (mw_full_energy.hip.h)
 bool lds_fits(int N, int ivcap)
 {
-    return kQueue1024 + (size_t)(3 * (size_t)N + 3 * (size_t)ivcap) * sizeof(double) <= (size_t)kLdsBudget;
+    return kQueue1024 + mw::lds_vec_bytes((size_t)N) + mw::lds_vec_bytes((size_t)ivcap) <= (size_t)kLdsBudget;
 }
 constexpr size_t kMoveScratch = 16 * sizeof(mw::WaveScratch);
 constexpr size_t kMoveStage = (size_t)mw::kMoveChunk * sizeof(int);   // the molecules of an item's requests in LDS (at most)
@@ -275,11 +276,11 @@ Geo model_geo(int count)
         int want = (2 * g.cu + count - 1) / count;
         int maxsplit = (g.N + ge.block - 1) / ge.block;
         ge.nsplit = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
-        ge.shmem = kQueue1024 + (size_t)(3 * (size_t)g.N + 3 * (size_t)g.ivcap) * sizeof(double);
+        ge.shmem = kQueue1024 + mw::lds_vec_bytes((size_t)g.N) + mw::lds_vec_bytes((size_t)g.ivcap);
     } else {
         ge.block = 256;
         ge.nsplit = (g.N + ge.block - 1) / ge.block;
-        ge.shmem = kQueue256 + (size_t)(3 * (size_t)g.ivcap) * sizeof(double);
+        ge.shmem = kQueue256 + mw::lds_vec_bytes((size_t)g.ivcap);
     }
     if (ge.nsplit > g.nsplit_max) ge.nsplit = g.nsplit_max;
     ge.chunk = (((g.N + ge.nsplit - 1) / ge.nsplit) + 63) & ~63;   // whole groups of 64 list columns (cmax is per group)
@@ -292,10 +293,10 @@ int launch_model_energy(int first, int count)
     dim3 grid(ge.nsplit, count);
     const int box0 = first - 1;
     if (ge.lds)
-        hipLaunchKernelGGL((mw::k_model_energy<true, 1024>), grid, dim3(1024), ge.shmem, g.stream, g.d_pos, g.d_ivect,
+        hipLaunchKernelGGL((mw::k_model_energy<true, 1024, kFullLayout>), grid, dim3(1024), ge.shmem, g.stream, g.d_pos, g.d_ivect,
                            g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
     else
-        hipLaunchKernelGGL((mw::k_model_energy<false, 256>), grid, dim3(256), ge.shmem, g.stream, g.d_pos, g.d_ivect,
+        hipLaunchKernelGGL((mw::k_model_energy<false, 256, kFullLayout>), grid, dim3(256), ge.shmem, g.stream, g.d_pos, g.d_ivect,
                            g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
     HIPCHK(hipGetLastError());
     // the partials of box b live at [b*nsplit .. b*nsplit+nsplit): same nsplit in both kernels
@@ -480,7 +481,7 @@ int mw_init(int device, int nwater, int nboxes, int maxneigh)
     g.h_ivect.assign(nb * g.ivcap * 3, 0.0);
     g.h_nivect.assign(nb, 0);
     // the LDS-staged kernel asks for more than the default 64 KiB of dynamic LDS
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_model_energy<true, 1024>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_model_energy<true, 1024, kFullLayout>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_list_order),
                                hipFuncAttributeMaxDynamicSharedMemorySize, mw::kOrderSlots * (int)sizeof(int)));

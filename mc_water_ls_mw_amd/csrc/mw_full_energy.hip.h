@@ -36,55 +36,74 @@ namespace mw {
 // the mean (7 instead of 10 passes on the thermal 4096-molecule boxes) -- rather than its longest row.
 //
 // LDSPOS = true : one workgroup stages the whole box's positions in LDS
-//                 (N*24 B: 96 KiB at N = 4096) and gathers r_j from there.
+//                 (N*24 B: 96 KiB at N = 4096) and gathers r_j from there (layouts: LdsVecs below).
 // LDSPOS = false: r_j gathered from global memory (L2-resident for the sizes
 //                 that do not fit LDS, e.g. 786 KiB at N = 32768).
 //   grid = (nsplit, nboxes_in_launch); each block takes list columns [split*chunk, ...), chunk % 64 == 0
 // =====================================================================================
-struct AtomSum { double e; unsigned long long np, nt; };
+struct AtomSum { double e; int cnt; };   // energy of one molecule, its in-range neighbours
 
 constexpr int kQCap = 12;   // in-range entries per molecule parked in LDS between the two phases
 
 constexpr double kAepsBSig4 = kAeps * kBigB * kSigSq * kSigSq;   // A eps B sigma^4 (molint.F90:460)
 
-// `queue` points at this thread's column of an LDS array [kQCap][BLOCK] (entry q at queue[q*BLOCK]:
-// consecutive threads, consecutive banks).  `t` is the thread's list column (-1: none), `mol` the molecule
-// it belongs to, `n` its row length and `nmax` (wave-uniform) the longest row among the wavefront's
-// columns.  The list is read eight slots at a time and ONE CHUNK AHEAD: `cur` arrives holding this
-// column's first eight entries; while a chunk is being tested the next one -- of this column, or the first
-// of the thread's next column `tnext` -- is already in flight, so the HBM latency of the list stream hides
-// behind the LDS gathers and distance tests.
+// The list streams through buffer loads: the row of slot s is a scalar offset, the column a per-lane offset, and a
+// lane without a column (offset kNoColumn) reads 0 -- no address arithmetic in vector registers at all.
+using ListRsrc = __amdgpu_buffer_rsrc_t;
+constexpr uint32_t kNoColumn = 0x7fffffffu;
+__device__ __forceinline__ ListRsrc list_rsrc(const uint32_t* L, int N, int S)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(L), 0, (int)((size_t)N * S * sizeof(uint32_t)), 0x00020000);
+}
+__device__ __forceinline__ uint32_t list_load(ListRsrc rs, uint32_t column_bytes, int slot, int N, int S)
+{
+    const int s = slot < S ? slot : S - 1;                                   // (uniform; such a slot is never live)
+    return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)column_bytes, s * N * (int)sizeof(uint32_t), 0);
+}
+
+// `queue` points at this thread's column of an LDS array [kQCap + 1][BLOCK] (entry q at queue[q*BLOCK]:
+// consecutive threads, consecutive banks; row kQCap takes what does not fit).  `col` is the byte offset of the
+// thread's list column (kNoColumn: none), `mol` the molecule it belongs to, `n` its row length, `nmax`
+// (wave-uniform) the longest row among the wavefront's columns and `c0min` (wave-uniform) the number of
+// leading slots that hold a central-image entry in EVERY column of the wavefront (columns list their central
+// entries first and are zero-padded to nmax): those slots skip the image-vector gather.  The list is read eight
+// slots at a time and ONE CHUNK AHEAD: `cur` arrives holding this column's first eight entries; while a chunk is
+// being tested the next one -- of this column, or the first of the thread's next column `col_next` -- is already
+// in flight, so the HBM latency of the list stream hides behind the LDS gathers and distance tests.
 template <int BLOCK, typename PosFn, typename IvFn>
-__device__ __forceinline__ AtomSum atom_energy(int t, int mol, int n, int nmax, const uint32_t* __restrict__ L, int N, int S,
-                                               uint32_t* __restrict__ queue, PosFn getpos, IvFn getiv,
-                                               uint32_t (&cur)[8], int tnext)
+__device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32_t col_next, int mol, int n, int nmax, int c0min,
+                                               int N, int S, uint32_t* __restrict__ queue, PosFn getpos, IvFn getiv,
+                                               uint32_t (&cur)[8])
 {
     double xi, yi, zi;
     getpos(mol, xi, yi, zi);
 
     // phase 1: cheap distance test over all list slots; the in-range entries are parked in LDS.
     int cnt = 0;
-    unsigned long long over = 0ull;             // in-range slots beyond the LDS queue (re-read later)
     for (int s0 = 0; s0 < nmax || s0 == 0; s0 += 8) {
         uint32_t nxt[8];
         const bool last = s0 + 8 >= nmax;                     // wave-uniform
-        const int pt = last ? tnext : t;                      // whose chunk comes next
+        const uint32_t pc = last ? col_next : col;            // whose chunk comes next
         const int ps = last ? 0 : s0 + 8;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) nxt[u] = (pt >= 0 && ps + u < S) ? L[(size_t)(ps + u) * N + pt] : 0u;
+        for (int u = 0; u < 8; ++u) nxt[u] = list_load(rs, pc, ps + u, N, S);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (s0 + u < nmax) {                              // wave-uniform
-                const bool live = s0 + u < n;
-                const uint32_t e = live ? cur[u] : 0u;        // a slot past the row's end: molecule 0, central image, ignored
-                double xj, yj, zj, ix, iy, iz;
+                const uint32_t e = cur[u];                    // past the row's end: 0 = molecule 0, central image; not live
+                double xj, yj, zj;
                 getpos((int)(e & kJMask), xj, yj, zj);
-                getiv((int)(e >> kJBits), ix, iy, iz);
-                const double dx = (xj + ix) - xi, dy = (yj + iy) - yi, dz = (zj + iz) - zi;   // molint.F90:447,450
+                double dx, dy, dz;
+                if (s0 + u < c0min) {                         // wave-uniform: the central image vector is exactly 0 (molint.F90:197)
+                    dx = xj - xi; dy = yj - yi; dz = zj - zi;
+                } else {
+                    double ix, iy, iz;
+                    getiv((int)(e >> kJBits), ix, iy, iz);
+                    dx = (xj + ix) - xi; dy = (yj + iy) - yi; dz = (zj + iz) - zi;            // molint.F90:447,450
+                }
                 const double r2 = dx * dx + dy * dy + dz * dz;
-                if (live && r2 < kRcSq) {                                                     // :454
-                    if (cnt < kQCap) queue[cnt * BLOCK] = e;
-                    else over |= 1ull << (s0 + u);
+                if (s0 + u < n && r2 < kRcSq) {                                               // :454
+                    queue[(cnt < kQCap ? cnt : kQCap) * BLOCK] = e;
                     ++cnt;
                 }
             }
@@ -128,24 +147,63 @@ __device__ __forceinline__ AtomSum atom_energy(int t, int mol, int n, int nmax, 
             for (int c = 0; c < 6; ++c) va[c] = vb[c];
         }
     }
-    while (over) {
-        const int s = __ffsll((long long)over) - 1;
-        over &= over - 1ull;
-        double v[6];
-        gather(L[(size_t)s * N + t], v);
-        accumulate(v);
+    if (cnt > kQCap) {          // rare (dense configurations): rescan the column for the in-range entries the queue had no room for
+        int seen = 0;
+        for (int s = 0; s < n; ++s) {
+            double v[6];
+            gather(list_load(rs, col, s, N, S), v);
+            const double dx = (v[0] + v[3]) - xi, dy = (v[1] + v[4]) - yi, dz = (v[2] + v[5]) - zi;
+            if (dx * dx + dy * dy + dz * dz < kRcSq) { if (seen >= kQCap) accumulate(v); ++seen; }
+        }
     }
     const double F2 = Sxx * Sxx + Syy * Syy + Szz * Szz + 2.0 * (Sxy * Sxy + Sxz * Sxz + Syz * Syz);
     const double F1 = S1x * S1x + S1y * S1y + S1z * S1z;
     const double T = 0.5 * ((F2 - Q) - 2.0 * kCos0 * (F1 - Q) + kCos0 * kCos0 * (S0 * S0 - Q));
     AtomSum out;
     out.e  = 0.5 * e2 + kLamEps * T;                                                   // :464,483
-    out.np = (unsigned long long)cnt;
-    out.nt = (unsigned long long)(cnt * (cnt - 1) / 2);
+    out.cnt = cnt;
     return out;
 }
 
-template <bool LDSPOS, int BLOCK>
+// LDS layout of the staged positions and image vectors (what a random gather costs the LDS: MI355X_MICROARCH.md,
+// LDS table -- the plain [N][3] layout makes the compiler fuse x,y into ds_read2_b64, which runs at HALF the rate of
+// ds_read_b64 / ds_read_b128: 10 LDS cycles per gathered position instead of 6):
+//   kLayoutAoS  : r[j][3]                      (ds_read2_b64 + ds_read_b64)
+//   kLayoutPair : xy[j] 16-byte pairs, z[j]    (ds_read_b128 + ds_read_b64)
+//   kLayoutSoA  : x[j], y[j], z[j]             (3 x ds_read_b64)
+constexpr int kLayoutAoS = 0, kLayoutPair = 1, kLayoutSoA = 2;
+constexpr int kMaxGroups = 128;          // groups of 64 list columns per workgroup (chunk <= 8192)
+
+__host__ __device__ constexpr size_t lds_vec_bytes(size_t n) { return (n * 24 + 15) & ~(size_t)15; }   // n vectors, 16-byte granules
+
+template <int LAYOUT>
+struct LdsVecs {
+    const double* base;
+    int n;
+    __device__ __forceinline__ void get(int j, double& x, double& y, double& z) const
+    {
+        if constexpr (LAYOUT == kLayoutAoS) {
+            const double* p = base + 3 * (size_t)j; x = p[0]; y = p[1]; z = p[2];
+        } else if constexpr (LAYOUT == kLayoutPair) {
+            const double2 xy = reinterpret_cast<const double2*>(base)[j]; x = xy.x; y = xy.y; z = base[2 * (size_t)n + j];
+        } else {
+            x = base[j]; y = base[(size_t)n + j]; z = base[2 * (size_t)n + j];
+        }
+    }
+    // element t of the flat [n][3] source goes here
+    __device__ __forceinline__ static size_t slot(int t, int n)
+    {
+        if constexpr (LAYOUT == kLayoutAoS) return (size_t)t;
+        const int j = t / 3, c = t - 3 * j;
+        if constexpr (LAYOUT == kLayoutPair) return c < 2 ? 2 * (size_t)j + c : 2 * (size_t)n + j;
+        else return (size_t)c * n + j;
+    }
+};
+
+// The wavefronts of a workgroup draw groups of 64 list columns from an LDS ticket, heaviest group first (the
+// columns are sorted by work, ascending): a wavefront that drew cheap groups serves more of them, and the
+// workgroup's tail is made of the cheapest groups.
+template <bool LDSPOS, int BLOCK, int LAYOUT>
 __global__ __launch_bounds__(BLOCK)
 void k_model_energy(const double* __restrict__ pos, const double* __restrict__ ivect,
                     const int* __restrict__ nivect, const uint32_t* __restrict__ list,
@@ -154,12 +212,13 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
                     int N, int S, int ivcap, int box0, int nsplit, int chunk)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ double red_e[BLOCK / 64];
-    __shared__ unsigned long long red_p[BLOCK / 64], red_t[BLOCK / 64];
+    __shared__ double gsum[kMaxGroups];                  // per group of 64 columns: summed in group order at the end,
+    __shared__ unsigned long long red_p[BLOCK / 64], red_t[BLOCK / 64];   // so the energy does not depend on who drew what
+    __shared__ int s_ticket;
 
     const int b = box0 + blockIdx.y;
     const int split = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int ngroups = (N + 63) >> 6;
     const double* P  = pos + (size_t)b * N * 3;
     const double* IV = ivect + (size_t)b * ivcap * 3;
@@ -169,58 +228,68 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
     const int* CM = cmax + (size_t)b * ngroups;
     const int niv = nivect[b];
 
-    // dynamic LDS: [positions when LDSPOS][image vectors][in-range queue kQCap x BLOCK u32]; the positions
-    // sit at offset 0 so that a gather's address is one multiply and the ds_read offsets are immediates.
+    // dynamic LDS: [positions when LDSPOS][image vectors][in-range queue kQCap x BLOCK u32]
     double* spos = smem;
-    double* siv = smem + (LDSPOS ? 3 * (size_t)N : 0);
-    uint32_t* queue = reinterpret_cast<uint32_t*>(siv + (size_t)ivcap * 3) + tid;
-    for (int t = tid; t < niv * 3; t += BLOCK) siv[t] = IV[t];
+    double* siv = smem + (LDSPOS ? lds_vec_bytes((size_t)N) / 8 : 0);
+    uint32_t* queue = reinterpret_cast<uint32_t*>(siv + lds_vec_bytes((size_t)ivcap) / 8) + tid;   // [kQCap + 1][BLOCK]
+    for (int t = tid; t < niv * 3; t += BLOCK) siv[LdsVecs<LAYOUT>::slot(t, ivcap)] = IV[t];
     if (LDSPOS) {
-        for (int t = tid; t < 3 * N; t += BLOCK) spos[t] = P[t];   // flat, fully coalesced copy
+        for (int t = tid; t < 3 * N; t += BLOCK) spos[LdsVecs<LAYOUT>::slot(t, N)] = P[t];   // coalesced read of the box
     }
+    if (tid == 0) s_ticket = BLOCK / 64;
     __syncthreads();
 
-    auto getiv = [&](int k, double& x, double& y, double& z) { x = siv[3 * k]; y = siv[3 * k + 1]; z = siv[3 * k + 2]; };
+    const LdsVecs<LAYOUT> vpos{spos, N}, viv{siv, ivcap};
+    auto getiv = [&](int k, double& x, double& y, double& z) { viv.get(k, x, y, z); };
     auto getpos = [&](int j, double& x, double& y, double& z) {
-        const double* p = LDSPOS ? (spos + 3 * (size_t)j) : (P + 3 * (size_t)j);
-        x = p[0]; y = p[1]; z = p[2];
+        if constexpr (LDSPOS) vpos.get(j, x, y, z);
+        else { const double* p = P + 3 * (size_t)j; x = p[0]; y = p[1]; z = p[2]; }
     };
 
-    double esum = 0.0;
-    unsigned long long np = 0, nt = 0;
-    const int a0 = split * chunk;                        // a multiple of 64: a wavefront's columns are one group
+    unsigned int np = 0, nt = 0;                         // directed in-range pairs, i-centred triplets of this lane's molecules
+    const int a0 = split * chunk;                        // a multiple of 64: whole groups (at most kMaxGroups)
     const int a1 = min(N, a0 + chunk);
-    const int wbase = __builtin_amdgcn_readfirstlane(a0 + (tid & ~63));
+    const int g0 = a0 >> 6, G = ((a1 + 63) >> 6) - g0;   // this workgroup's groups: g0 .. g0 + G - 1
+    const ListRsrc rs = list_rsrc(L, N, S);
     uint32_t cur[8];
     int n_cur = 0, mol = 0;
-    {
-        const int t = a0 + tid;
-        if (t < a1) {
-            n_cur = NNS[t]; mol = ORD[t];
+    const int w0 = __builtin_amdgcn_readfirstlane(wid);
+    int grp = w0 < G ? g0 + G - 1 - w0 : -1;             // first tickets: one per wavefront (wave-uniform, in a scalar register)
+    uint32_t col = kNoColumn;
+    if (grp >= 0) {
+        const int t = grp * 64 + lane;
+        if (t < a1) { col = (uint32_t)t * 4u; n_cur = NNS[t]; mol = ORD[t]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) cur[u] = u < S ? L[(size_t)u * N + t] : 0u;
-        }
+        for (int u = 0; u < 8; ++u) cur[u] = list_load(rs, col, u, N, S);
     }
-    for (int base = wbase; base < a1; base += BLOCK) {           // wave-uniform
-        const int t = base + (tid & 63);
-        const int tn = t + BLOCK;
-        const bool act = t < a1;
-        const int tnext = tn < a1 ? tn : -1;
+    while (grp >= 0) {                                   // wave-uniform
+        int tk = 0;
+        if (lane == 0) tk = __hip_atomic_fetch_add(&s_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        const int gnext = tk < G ? g0 + G - 1 - tk : -1;
+        const bool act = col != kNoColumn;
+        uint32_t col_next = kNoColumn;
         int n_next = 0, mol_next = 0;
-        if (tnext >= 0) { n_next = NNS[tnext]; mol_next = ORD[tnext]; }      // one column ahead, like the list chunks
-        const int nmax = CM[base >> 6];
-        AtomSum a = atom_energy<BLOCK>(act ? t : -1, mol, act ? n_cur : 0, nmax, L, N, S, queue, getpos, getiv, cur, tnext);
-        if (act) { esum += a.e; np += a.np; nt += a.nt; }
-        n_cur = n_next; mol = mol_next;
+        if (gnext >= 0) {                                                    // one group ahead, like the list chunks
+            const int tn = gnext * 64 + lane;
+            if (tn < a1) { col_next = (uint32_t)tn * 4u; n_next = NNS[tn]; mol_next = ORD[tn]; }
+        }
+        const int cm = __builtin_amdgcn_readfirstlane(CM[grp]);
+        AtomSum a = atom_energy<BLOCK>(rs, col, col_next, mol, act ? (n_cur & 0xff) : 0, cm & 0xff, cm >> 8, N, S,
+                                       queue, getpos, getiv, cur);
+        if (act) { np += (unsigned int)a.cnt; nt += (unsigned int)(a.cnt * (a.cnt - 1) / 2); }
+        const double ge = dpp_wave_sum(act ? a.e : 0.0);             // fixed tree; total in lane 63
+        if (lane == 63) gsum[grp - g0] = ge;
+        n_cur = n_next; mol = mol_next; col = col_next; grp = gnext;
     }
 
-    esum = wave_sum(esum); np = wave_sum_u64(np); nt = wave_sum_u64(nt);
-    const int wid = tid >> 6;
-    if ((tid & 63) == 0) { red_e[wid] = esum; red_p[wid] = np; red_t[wid] = nt; }
+    const unsigned long long wp = wave_sum_u64(np), wt = wave_sum_u64(nt);
+    if (lane == 0) { red_p[wid] = wp; red_t[wid] = wt; }
     __syncthreads();
     if (tid == 0) {
         double e = 0.0; unsigned long long p = 0, t = 0;
-        for (int w = 0; w < BLOCK / 64; ++w) { e += red_e[w]; p += red_p[w]; t += red_t[w]; }
+        for (int k = 0; k < G; ++k) e += gsum[k];
+        for (int w = 0; w < BLOCK / 64; ++w) { p += red_p[w]; t += red_t[w]; }
         const size_t o = (size_t)(b) * nsplit + split;
         partial[o] = e; cpartial[2 * o] = p; cpartial[2 * o + 1] = t;
     }

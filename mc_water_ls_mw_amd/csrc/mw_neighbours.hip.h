@@ -35,7 +35,8 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
     const bool active = i < N;
     const int ii = active ? i : 0;
     const double xi = P[3 * ii], yi = P[3 * ii + 1], zi = P[3 * ii + 2];   // molint.F90:522
-    int cnt = 0, cin_ = 0;                 // cin_: entries already inside the energy cutoff (a sort key, k_list_order)
+    int cnt = 0, cin_ = 0, bnd_ = 0;       // cin_: entries already inside the energy cutoff, bnd_: any non-central image
+                                           // (both sort keys of k_list_order)
 
     for (int j = 0; j < N; ++j) {                                           // :525
         const double vx = P[3 * j] - xi, vy = P[3 * j + 1] - yi, vz = P[3 * j + 2] - zi;   // :529
@@ -46,10 +47,11 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
                 if (active && cnt < S) LM[cnt] = pack_entry(j, k);
                 ++cnt;
                 cin_ += r2 < kRcSq ? 1 : 0;
+                bnd_ |= k != 0 ? 1 : 0;
             }
         }
     }
-    if (active) { nn[(size_t)b * N + i] = cnt < S ? cnt : S; cin[(size_t)b * N + i] = (unsigned char)(cin_ < 255 ? cin_ : 255); }
+    if (active) { nn[(size_t)b * N + i] = cnt < S ? cnt : S; cin[(size_t)b * N + i] = (unsigned char)((cin_ < 127 ? cin_ : 127) | (bnd_ << 7)); }
 
     // per-box statistics: min nn, max nn (max > S means overflow)
     int mn = wave_min_i(active ? cnt : 0x7fffffff);
@@ -193,7 +195,7 @@ void k_cell_search(const double* __restrict__ pos, const double* __restrict__ iv
     const int si0 = (shi & 1023) - 512, si1 = ((shi >> 10) & 1023) - 512, si2 = ((shi >> 20) & 1023) - 512;
     const int w1 = 2 * G.im[1] + 1, w2 = 2 * G.im[2] + 1;
     const int central = (G.im[0] * w1 + G.im[1]) * w2 + G.im[2];
-    int cnt = 0, cin_ = 0;
+    int cnt = 0, cin_ = 0, bnd_ = 0;
 
     if (active) {
         for (int d0 = -1; d0 <= 1; ++d0) {
@@ -226,6 +228,7 @@ void k_cell_search(const double* __restrict__ pos, const double* __restrict__ iv
                             if (cnt < S) buf[cnt * 256] = ((uint32_t)j << 10) | (uint32_t)k;   // sort key: j, then image
                             ++cnt;
                             cin_ += r2 < kRcSq ? 1 : 0;
+                            bnd_ |= k != 0 ? 1 : 0;
                         }
                     }
                 }
@@ -241,7 +244,7 @@ void k_cell_search(const double* __restrict__ pos, const double* __restrict__ iv
             LM[r] = pack_entry((int)(ka >> 10), (int)(ka & 1023u));
         }
         nn[(size_t)b * N + i] = n;
-        cin[(size_t)b * N + i] = (unsigned char)(cin_ < 255 ? cin_ : 255);
+        cin[(size_t)b * N + i] = (unsigned char)((cin_ < 127 ? cin_ : 127) | (bnd_ << 7));
     }
     int mn = wave_min_i(active ? cnt : 0x7fffffff);
     int mx = wave_max_i(active ? cnt : 0);
@@ -253,8 +256,9 @@ void k_cell_search(const double* __restrict__ pos, const double* __restrict__ iv
 
 // =====================================================================================
 // Sorted slot-major copy of the list for the full-box kernel (one molecule per lane): the molecules of a box
-// are ordered by (neighbours inside the energy cutoff at build time, row length), so that the 64 lanes of a
-// wavefront run the same number of cheap distance tests and the same number of expensive pair evaluations.
+// are ordered by (neighbours inside the energy cutoff at build time, interior / boundary, row length), so that
+// the 64 lanes of a wavefront run the same number of cheap distance tests and the same number of expensive pair
+// evaluations, and whole wavefronts of interior molecules never touch the image vectors.
 // Stable counting sort -- a box always gets the same order, so energies stay bitwise reproducible:
 //   A  histogram over (key, group of 64 consecutive molecules) in LDS,
 //   scan in (key, group) order,
@@ -285,10 +289,12 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
     int* CM = cmax + (size_t)b * ngroups;
     const int nmin = stats[2 * b];
 
+    // key = in-range neighbours at build time (4 bits) | has entries of a non-central image (1 bit) | row length (3 bits)
     auto keyof = [&](int i, int n) {
-        const int c = min((int)CI[i], 31);
+        const int c = min((int)(CI[i] & 0x7f), 15);
+        const int bnd = CI[i] >> 7;
         const int nb = min(7, max(0, n - nmin) >> 1);
-        return ((c << 3) | nb) >> (8 - kbits);
+        return ((c << 4) | (bnd << 3) | nb) >> (8 - kbits);
     };
 
     if (kbits < 0) {
@@ -331,21 +337,34 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
         }
     }
     __syncthreads();   // ORD / NNS of this box are read back below by other threads of this workgroup
+    // Column t <- row ORD[t], entries of the central image first: the full-box kernel then skips the image-vector
+    // gather for the slots every lane of a wavefront knows to be central (c0min).  NNS[t] = n | n0 << 8 (n0 = central
+    // entries), CM[group] = longest row | smallest n0 << 8.
     for (int base = 0; base < N; base += 1024) {
         const int t = base + tid;
         const bool valid = t < N;
         const int i = valid ? ORD[t] : 0;
         const int n = valid ? NNS[t] : 0;
         const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i(n));
-        if (lane == 0 && (t >> 6) < ngroups) CM[t >> 6] = nmax;
         const uint4* row = reinterpret_cast<const uint4*>(LM + (size_t)i * kRow);
-        for (int s4 = 0; s4 < nmax; s4 += 4) {
-            if (s4 < n) {
-                const uint4 v = row[s4 >> 2];
-                L[(size_t)s4 * N + t] = v.x;
-                if (s4 + 1 < n) L[(size_t)(s4 + 1) * N + t] = v.y;
-                if (s4 + 2 < n) L[(size_t)(s4 + 2) * N + t] = v.z;
-                if (s4 + 3 < n) L[(size_t)(s4 + 3) * N + t] = v.w;
+        int w = 0;                                            // next slot of the column
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int s4 = 0; s4 < nmax; s4 += 4) {
+                if (s4 < n) {
+                    const uint4 v = row[s4 >> 2];
+                    const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (s4 + u < n && ((e[u] >> kJBits) == 0u) == (pass == 0)) { L[(size_t)w * N + t] = e[u]; ++w; }
+                }
+            }
+            if (pass == 1 && valid)
+                for (; w < nmax; ++w) L[(size_t)w * N + t] = 0u;       // zero-padded to the group's longest row
+            if (pass == 0) {
+                const int n0 = w;
+                if (valid) NNS[t] = n | (n0 << 8);
+                const int c0min = __builtin_amdgcn_readfirstlane(wave_min_i(valid ? n0 : 0x7fff));
+                if (lane == 0 && (t >> 6) < ngroups) CM[t >> 6] = nmax | ((c0min > 255 ? 255 : c0min) << 8);
             }
         }
     }

@@ -196,23 +196,23 @@ __device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, 
         x = p[0]; y = p[1]; z = p[2];
     };
     double esum = 0.0;
+    const ListRsrc rs = list_rsrc(Lg, c.N, c.S);
     uint32_t cur[8];
     int n_cur = 0, mol = 0;
-    if (lane < c.N) {
-        n_cur = NNS[lane]; mol = ORD[lane];
+    uint32_t col = kNoColumn;
+    if (lane < c.N) { col = (uint32_t)lane * 4u; n_cur = NNS[lane]; mol = ORD[lane]; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cur[u] = u < c.S ? Lg[(size_t)u * c.N + lane] : 0u;
-    }
+    for (int u = 0; u < 8; ++u) cur[u] = list_load(rs, col, u, c.N, c.S);
     for (int base = 0; base < c.N; base += 64) {                 // wave-uniform: one group of 64 list columns per pass
-        const int t = base + lane;
-        const bool act = t < c.N;
-        const int tnext = t + 64 < c.N ? t + 64 : -1;
+        const bool act = col != kNoColumn;
+        const int tn = base + 64 + lane;
+        uint32_t col_next = kNoColumn;
         int n_next = 0, mol_next = 0;
-        if (tnext >= 0) { n_next = NNS[tnext]; mol_next = ORD[tnext]; }
-        const int nmax = CM[base >> 6];
-        AtomSum a = atom_energy<64>(act ? t : -1, mol, act ? n_cur : 0, nmax, Lg, c.N, c.S, c.queue, getpos, getiv, cur, tnext);
+        if (tn < c.N) { col_next = (uint32_t)tn * 4u; n_next = NNS[tn]; mol_next = ORD[tn]; }
+        const int cm = __builtin_amdgcn_readfirstlane(CM[base >> 6]);
+        AtomSum a = atom_energy<64>(rs, col, col_next, mol, act ? (n_cur & 0xff) : 0, cm & 0xff, cm >> 8, c.N, c.S, c.queue, getpos, getiv, cur);
         if (act) esum += a.e;
-        n_cur = n_next; mol = mol_next;
+        n_cur = n_next; mol = mol_next; col = col_next;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off, 64);
@@ -345,7 +345,7 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ WaveScratch ws;
-    __shared__ uint32_t squeue[WITHVOL ? kQCap * 64 : 1];   // in-range queue of the volume move's full-box energy
+    __shared__ uint32_t squeue[WITHVOL ? (kQCap + 1) * 64 : 1];   // in-range queue of the volume move's full-box energy
     __shared__ double shmat[2][9], svol[2];      // the walker's cells: volume moves change them in place
     __shared__ int sniv[2];
     const int lane = threadIdx.x;

@@ -17,15 +17,14 @@
 
 struct Variant { std::string name; std::function<void()> launch; std::vector<float> us; };
 
-template <int VAR>
+template <int LAYOUT>
 static void launch_me(int nboxes)
 {
-    const size_t shmem = (size_t)(mw::kQCap + 1) * 1024 * sizeof(uint32_t) + (size_t)(3 * (size_t)g.N + 3 * (size_t)g.ivcap) * sizeof(double);
+    const Geo ge = model_geo(nboxes);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kb::k_me<VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; }
-    const int grid = (VAR & kb::V_PERSIST) ? std::min(nboxes, g.cu) : nboxes;
-    hipLaunchKernelGGL(kb::k_me<VAR>, dim3(grid), dim3(1024), shmem, g.stream, g.d_pos, g.d_ivect, g.d_nivect, g.d_list,
-                       g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, nboxes);
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_model_energy<true, 1024, LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget); attr = true; }
+    hipLaunchKernelGGL((mw::k_model_energy<true, 1024, LAYOUT>), dim3(ge.nsplit, nboxes), dim3(1024), ge.shmem, g.stream, g.d_pos, g.d_ivect,
+                       g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, 0, ge.nsplit, ge.chunk);
 }
 
 int main(int argc, char** argv)
@@ -59,17 +58,10 @@ int main(int argc, char** argv)
     CK(mw_model_energy_counts_total(1, W, &np_ref, &nt_ref));
 
     std::vector<Variant> vs;
-    vs.push_back({"product", [&] { (void)launch_model_energy(1, W); }, {}});
-    vs.push_back({"me<0> same as product, variant frame", [&] { launch_me<0>(W); }, {}});
-    vs.push_back({"me<SERP>", [&] { launch_me<kb::V_SERP>(W); }, {}});
-    vs.push_back({"me<DYN>", [&] { launch_me<kb::V_DYN>(W); }, {}});
-    vs.push_back({"me<PIPE>", [&] { launch_me<kb::V_PIPE>(W); }, {}});
-    vs.push_back({"me<DYN|PIPE>", [&] { launch_me<kb::V_DYN | kb::V_PIPE>(W); }, {}});
-    vs.push_back({"me<DYN|PERSIST>", [&] { launch_me<kb::V_DYN | kb::V_PERSIST>(W); }, {}});
-    vs.push_back({"me<DYN|PIPE|PERSIST>", [&] { launch_me<kb::V_DYN | kb::V_PIPE | kb::V_PERSIST>(W); }, {}});
-    vs.push_back({"me<DYN|NOP2> (phase 1 only)", [&] { launch_me<kb::V_DYN | kb::V_NOP2>(W); }, {}});
-    vs.push_back({"me<DYN|PIPE|NOP2> (phase 1 only)", [&] { launch_me<kb::V_DYN | kb::V_PIPE | kb::V_NOP2>(W); }, {}});
-    vs.push_back({"me<DYN|NOP1> (phase 2 only, 7 entries)", [&] { launch_me<kb::V_DYN | kb::V_NOP1>(W); }, {}});
+    vs.push_back({"product (2 launches)", [&] { (void)launch_model_energy(1, W); }, {}});
+    vs.push_back({"k_model_energy<AoS>", [&] { launch_me<mw::kLayoutAoS>(W); }, {}});
+    vs.push_back({"k_model_energy<Pair>", [&] { launch_me<mw::kLayoutPair>(W); }, {}});
+    vs.push_back({"k_model_energy<SoA>", [&] { launch_me<mw::kLayoutSoA>(W); }, {}});
 
     hipEvent_t e0, e1;
     HK(hipEventCreate(&e0)); HK(hipEventCreate(&e1));
