@@ -151,6 +151,124 @@ def _cpu_model():
     return "unknown"
 
 
+# ---- roofline bookkeeping ------------------------------------------------------------------------------
+SIMDS, CUS, CLOCK_HZ = 1024, 256, 2.4e9     # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz max clock
+VALU_F64_PEAK = SIMDS * CLOCK_HZ / 4.0      # wave64 f64 instructions / s: 16 lanes per clock per SIMD (78.6 TFLOP/s FMA)
+
+
+def load_counters(W, M):
+    """profiles/counters.json: raw rocprofv3 counters per kernel for one bench configuration (tools/collect_counters.py
+    from separate --pmc passes).  Returns {} unless it was taken on this configuration."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
+    try:
+        cj = json.load(open(path))
+    except (OSError, ValueError):
+        return {}
+    return cj if cj.get("walkers") == W and cj.get("moves") == M else {}
+
+
+def kernel_roofline(name, alg_bytes, avg_ms, units, counters, copy_gbs):
+    """SURVEY.md 8(d) convention (`achieved` = algorithmic bytes / launch time, against 8 TB/s) next to what the
+    counters say binds: VALU issue, LDS, or HBM traffic (each as a fraction of its own ceiling)."""
+    sec = avg_ms * 1e-3
+    ach = alg_bytes / sec / 1e9
+    r = {"kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+         "convention": "achieved = SURVEY.md 8(d) algorithmic bytes per launch / launch time; NOT the kernel's HBM traffic",
+         "traffic": None, "hbm_traffic_frac": None, "bound": None}
+    c = counters.get(name)
+    if c:
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0                        # the counter sums the 8 XCDs
+        r["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
+        if r["traffic"] is not None:
+            r["hbm_traffic_frac"] = r["traffic"] / (c["avg_us"] * 1e-6) / (HBM_PEAK_GBS * 1e9)
+        busy = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * cyc)
+        r["valu"] = {"busy": busy, "insts_per_unit": c["SQ_INSTS_VALU"] * 64.0 / units,
+                     "wave_insts_per_s": c["SQ_INSTS_VALU"] / (c["avg_us"] * 1e-6), "peak_wave_insts_per_s_f64": VALU_F64_PEAK,
+                     "unit_of_work": "molecule" if name == "k_model_energy" else "trial move (old + new)"}
+        r["lds_busy"] = c["SQ_LDS_IDX_ACTIVE"] / (CUS * cyc) if "SQ_LDS_IDX_ACTIVE" in c else None
+        ceilings = {"valu": busy, "lds": r["lds_busy"] or 0.0, "hbm": r["hbm_traffic_frac"] or 0.0}
+        r["bound"] = max(ceilings, key=ceilings.get)
+        r["counters_tag"] = counters.get("tag")
+    elif copy_gbs and ach > copy_gbs:
+        r["bound"] = "not hbm: the algorithmic rate exceeds this box's measured copy ceiling (operands served from LDS / L2)"
+    else:
+        r["bound"] = "unknown: no counter summary for this configuration under profiles/"
+    r["measured_copy_GBps"] = copy_gbs
+    r["frac_of_measured_copy"] = ach / copy_gbs if copy_gbs else None
+    return r
+
+
+def secondary_measurements(device):
+    """The figures BASELINE.json's other configurations ask for, measured live after the timed run (own engine
+    contexts, HIP events on the engine's stream): configs[2] 1536-molecule Ic/Ih pairs on the single-move path,
+    configs[4] 32768-molecule boxes (list rebuild + full energy, 64 per launch and one per launch)."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.energy import load_boxes
+    out = []
+
+    def timed(em, slot, fn, reps):
+        fn(); em.sync()
+        em.timer_start(slot)
+        for _ in range(reps):
+            fn()
+        em.timer_stop(slot)
+        return em.timer_ms(slot) / reps
+
+    # configs[4]: 32768-molecule ice Ih
+    h, x = lat.ice_box("ih", (16, 16, 16), 0.15, seed=20250228)
+    ideal = lat.ice_box("ih", (16, 16, 16), 0.0)[1]
+    N = len(x)
+    gold = os.path.join(ROOT, "tests", "golden", "ih32768_t015.npz")
+    ref = float(np.load(gold)["model_energy"]) if os.path.exists(gold) else None
+    for B in (64, 1):
+        xs = [x] + [lat.thermalise(ideal, 0.15, 500 + b) for b in range(1, B)]
+        em = load_boxes([h] * B, xs, device=device)
+        try:
+            ms_list = timed(em, 0, lambda: em.build_neighbours_launch(1, B), 5)
+            ms_full = timed(em, 1, lambda: em.model_energy_launch(1, B), 10)
+            entries = em.neighbour_total(1, B)
+            npairs, ntrip = em.model_energy_counts_total(1, B)
+            e = em.model_energy_fetch(1, 1)[0]
+            b_list, b_full = B * N * (24 + 4) + 8 * entries, B * N * (24 + 8) + 8 * entries
+            out.append({"name": f"configs[4] ih32768_t015 x {B} box{'es' if B > 1 else ''} per launch", "molecules": N, "boxes": B,
+                        "list_rebuild_ms": ms_list, "list_algorithmic_GBps": b_list / ms_list / 1e6,
+                        "list_frac_of_hbm_peak": b_list / ms_list / 1e6 / HBM_PEAK_GBS,
+                        "full_energy_ms": ms_full, "full_algorithmic_GBps": b_full / ms_full / 1e6,
+                        "full_frac_of_hbm_peak": b_full / ms_full / 1e6 / HBM_PEAK_GBS,
+                        "full_interactions_per_s": (npairs + ntrip) / (ms_full * 1e-3),
+                        "box1_rel_err_vs_golden": None if ref is None else abs(e - ref) / abs(ref),
+                        "note": "positions (786 KiB) do not fit LDS: gathered through L2" + ("" if B > 1 else "; one box per launch is latency, not throughput")})
+        finally:
+            em.energy_deinit()
+
+    # configs[2]: the 1536-molecule Ic <-> Ih lattice-switch pair, single-move path
+    g1p, g2p = (os.path.join(ROOT, "tests", "golden", f) for f in ("ic1536.npz", "ih1536.npz"))
+    if os.path.exists(g1p) and os.path.exists(g2p):
+        g1, g2 = np.load(g1p), np.load(g2p)
+        W, M = 256, 1536
+        hs, xs = [], []
+        for w in range(W):
+            hs += [g1["h"], g2["h"]]
+            xs += [lat.thermalise(g1["xyz"], 0.12, 1000 + w), lat.thermalise(g2["xyz"], 0.12, 2000 + w)]
+        em = load_boxes(hs, xs, device=device)
+        try:
+            ils = np.repeat(np.arange(1, 2 * W + 1, dtype=np.int32), M)
+            mv = [lat.trial_moves(xs[b], M, seed=b) for b in range(2 * W)]
+            em.moves_upload(ils, np.concatenate([m[0] for m in mv]), np.concatenate([m[1] for m in mv]))
+            ms = timed(em, 2, em.moves_launch, 10)
+            io, so, inw, sn = em.moves_counts()
+            nmv = 2 * W * M
+            b_mv = 24 * 2 * nmv + 32 * (so + sn)
+            out.append({"name": "configs[2] 1536-molecule Ic/Ih lattice-switch pairs, single-move path", "walkers": W,
+                        "moves_per_lattice": M, "ms_per_launch": ms, "interactions_per_s": (io + inw) / (ms * 1e-3),
+                        "move_evaluations_per_s": 2 * nmv / (ms * 1e-3), "algorithmic_GBps": b_mv / ms / 1e6,
+                        "frac_of_hbm_peak": b_mv / ms / 1e6 / HBM_PEAK_GBS})
+        finally:
+            em.energy_deinit()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,11 +284,25 @@ def main():
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank computes on device 0 (use with --backend gloo)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements (configs[2] 1536 LS pairs, configs[4] 32768 boxes) after the timed run")
+    ap.add_argument("--no-exchange", action="store_true",
+                    help="N = 1 only: skip the per-step weight/histogram all-reduce (by default a one-rank process group "
+                         "is created so that the N = 1 line times the same step as the N > 1 lines)")
     args = ap.parse_args()
+
+    # Libraries print to stdout too (RCCL announces its version when the communicator is created): the process's
+    # stdout carries ONE JSON line, everything else goes to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
 
     if args.cpu_worker:                       # child of cpu_all_cores(): never touches the GPU
         h, xs = make_walkers(0, 1, args.sigma)
-        print(json.dumps(cpu_baseline(h, xs[0], args.moves, args.cpu_budget)), flush=True)
+        emit(cpu_baseline(h, xs[0], args.moves, args.cpu_budget))
         return
     all_cores = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
@@ -189,12 +321,24 @@ def main():
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    exchange = world > 1 or not args.no_exchange
+    exchange_note = None
+    if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+        except Exception as err:                      # noqa: BLE001  (N = 1 only: the bench still measures the kernels)
+            if world > 1:
+                raise
+            exchange, exchange_note = False, f"none at N=1 ({args.backend} process group unavailable: {err})"
 
     from mc_water_ls_mw_amd import lattice as lat
     from mc_water_ls_mw_amd.comms import WalkerComms
@@ -237,7 +381,7 @@ def main():
         else:
             em.model_energy_launch(1, W)
             em.moves_launch()
-        if world > 1:
+        if exchange:
             hist[(k * 7 + rank) % NBINS] += 1.0
             weight[(k * 7 + rank) % NBINS] += 0.05
             uhist[(k * 3 + rank) % NBINS] += 0.5
@@ -246,7 +390,7 @@ def main():
     def fence():
         em.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -259,7 +403,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if exchange:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -313,17 +457,10 @@ def main():
             if sanity > 1e-10:
                 raise SystemExit(f"walker 0 energy {e_walker0!r} differs from the golden vector {ref!r}")
         dominant = "k_model_energy" if ms_full >= ms_moves else "k_move_energy"
-        dom_bytes, dom_ms = (bytes_full, ms_full) if dominant == "k_model_energy" else (bytes_moves, ms_moves)
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        side = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(side):
-            try:
-                tj = json.load(open(side))
-                if tj.get("walkers") == W and tj.get("moves") == M:
-                    traffic = tj.get(dominant)
-            except (OSError, ValueError):
-                traffic = None
+        counters = load_counters(W, M)
+        rl = {"k_model_energy": kernel_roofline("k_model_energy", bytes_full, ms_full, W * N_MOL, counters, copy_gbs),
+              "k_move_energy": kernel_roofline("k_move_energy", bytes_moves, ms_moves, W * M, counters, copy_gbs)}
+        entries_bytes = W * N_MOL * (24 + 4) + 8 * entries         # N*(24 + 4 + 8*nbar)
         out = {
             "metric": "mW interactions/sec/GPU (full-box + single-move ΔE), 4096-mol ice; 1/2/4/8-GPU replica scaling",
             "value": (i_full + i_moves) * args.steps * world / elapsed,
@@ -337,15 +474,13 @@ def main():
                             "per step: full-box energy of every walker + old/new local energy of every trial move",
                 "walkers_per_gpu": W, "moves_per_walker": M, "molecules": N_MOL,
                 "parallelism": f"replica farm: {world} x {W} independent walkers, one process per GPU",
-                "exchange": (f"one {args.backend} all-reduce of 3 x 101 f64 per step" if world > 1 else "none at N=1"),
+                "exchange": (f"one {args.backend} all-reduce of 3 x 101 f64 per step"
+                             + (" (one-rank process group)" if world == 1 else "")) if exchange
+                            else (exchange_note or "none at N=1 (--no-exchange)"),
             },
             "per_gpu": (i_full + i_moves) * args.steps / elapsed,
-            "roofline": {
-                "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
-                "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
-            },
+            "roofline": rl[dominant],
+            "roofline_model_energy": rl["k_model_energy"],     # the kernel of configs[1] itself, whichever dominates the step
             "kernels": {
                 "k_model_energy": {"avg_ms": ms_full, "interactions_per_launch": i_full,
                                    "interactions_per_s": i_full / (ms_full * 1e-3),
@@ -355,7 +490,9 @@ def main():
                                    "interactions_per_s": i_moves / (ms_moves * 1e-3),
                                    "algorithmic_GBps": bytes_moves / (ms_moves * 1e-3) / 1e9,
                                    "evaluations_per_s": 2 * W * M / (ms_moves * 1e-3)},
-                "k_build_neighbours": {"ms_for_all_walkers": list_ms, "nn_min": mn, "nn_max": mx},
+                "k_build_neighbours": {"ms_for_all_walkers": list_ms, "nn_min": mn, "nn_max": mx,
+                                       "algorithmic_GBps": entries_bytes / (list_ms * 1e-3) / 1e9,
+                                       "frac_of_hbm_peak": entries_bytes / (list_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             },
             "device": {"name": name, "compute_units": cus, "hbm_bytes": mem},
             "walker0_rel_err_vs_golden": sanity,
@@ -366,10 +503,13 @@ def main():
             out["cpu_baseline"]["all_cores"] = all_cores
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-
     em.energy_deinit()
-    if world > 1:
+    if rank == 0:
+        if not args.no_secondary and world == 1:
+            out["secondary"] = secondary_measurements(local_rank)
+        emit(out)
+
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -171,6 +171,10 @@ int mw_sweep_options(int record, int samplerun, int always_switch, int npt,
  * and refreshes the host-side image vectors / neighbour-grid descriptors exactly as mw_set_cell does. */
 int mw_sweep_moves(double transP, double dv_max_bohr);
 int mw_sweep_get_volume_moves(int walker, long long *attempted, long long *accepted);
+/* Nonzero (with the walker named in mw_last_error) if a volume move of any walker of the range needed more image
+ * vectors than the table holds: that move was rejected and undone, the walker's state is consistent, but its chain
+ * no longer follows mc_volume.  mw_sweep_moves reserves one extra shell of images, so this means a collapsing cell. */
+int mw_sweep_check_flags(int first_walker, int count);
 int mw_sweep_sync_cells(int first_ils, int count, double *h_out);
 int mw_sweep_get_tables(int walker, double *weight, double *histogram, double *unbiased_hist);
 int mw_sweep_set_tables(int walker, const double *weight, const double *histogram, const double *unbiased_hist);

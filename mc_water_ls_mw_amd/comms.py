@@ -51,8 +51,9 @@ class WalkerComms:
     def _allreduce(self, delta):
         """Sum a float64 host vector over all walkers; returns a host vector."""
         n = len(delta)
-        if not dist.is_initialized() or self.world_size == 1:
+        if not dist.is_initialized():                 # no process group at all: a single walker process
             return np.array(delta, dtype=np.float64)
+        # (with a process group the collective is issued even for one rank: N = 1 and N = 8 run the same code)
         self._stage[:n].copy_(torch.from_numpy(np.ascontiguousarray(delta, dtype=np.float64)))
         buf = self._buf[:n]
         buf.copy_(self._stage[:n], non_blocking=True)
@@ -103,7 +104,7 @@ class WalkerComms:
     # serial Recv loop: one gather to rank 0 (gather_object of 808-byte arrays is latency, not bandwidth), the
     # stitching in rank order exactly as the reference does it, one broadcast.
     def _gather_to_root(self, arr):
-        if not dist.is_initialized() or self.world_size == 1:
+        if not dist.is_initialized():
             return [np.array(arr, dtype=np.float64)]
         t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.device)
         out = [torch.empty_like(t) for _ in range(self.world_size)]
@@ -111,7 +112,7 @@ class WalkerComms:
         return [o.cpu().numpy() for o in out]
 
     def _bcast(self, arr):
-        if not dist.is_initialized() or self.world_size == 1:
+        if not dist.is_initialized():
             return arr
         t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.device)
         dist.broadcast(t, src=0, group=self.group)
@@ -152,7 +153,7 @@ class WalkerComms:
 
     def get_max(self, value):
         """comms_get_max (comms_mpi.f90:279-297)."""
-        if not dist.is_initialized() or self.world_size == 1:
+        if not dist.is_initialized():
             return float(value)
         t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
@@ -160,12 +161,12 @@ class WalkerComms:
 
     def bcast_flag(self, flag):
         """comms_bcastlog (comms_mpi.f90): rank 0's logical for everybody."""
-        if not dist.is_initialized() or self.world_size == 1:
+        if not dist.is_initialized():
             return bool(flag)
         t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
         dist.broadcast(t, src=0, group=self.group)
         return bool(int(t.item()))
 
     def barrier(self):                                # comms_barrier, comms_mpi.f90:601-618
-        if dist.is_initialized() and self.world_size > 1:
+        if dist.is_initialized():
             dist.barrier(group=self.group)

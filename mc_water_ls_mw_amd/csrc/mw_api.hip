@@ -65,7 +65,7 @@ struct Ctx {
     int* d_nns = nullptr;          // [box][N]   row length of column t
     int* d_cmax = nullptr;         // [box][ceil(N/64)] longest row of each group of 64 columns
     unsigned char* d_cin = nullptr;   // [box][N]   neighbours inside the energy cutoff when the list was built
-    int order_kbits = -1;
+    int order_kbits = -1, order_seg = 0;   // sort-key bits and segment length of k_list_order
     // cell-grid neighbour builder
     mw::GridDesc* d_grid = nullptr;
     int* d_usegrid = nullptr;
@@ -250,7 +250,11 @@ int ensure_moves(int n)
 {
     if (n <= g.mcap) return 0;
     HIPCHK(hipStreamSynchronize(g.stream));
-    if (g.d_mimol) { hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); hipFree(g.d_mcnt); hipFree(g.d_mperm); }
+    if (g.d_mimol) {
+        HIPCHK(hipFree(g.d_mimol)); HIPCHK(hipFree(g.d_mtrial)); HIPCHK(hipFree(g.d_meold));
+        HIPCHK(hipFree(g.d_menew)); HIPCHK(hipFree(g.d_mcnt)); HIPCHK(hipFree(g.d_mperm));
+        g.d_mimol = nullptr; g.mcap = 0;
+    }
     int cap = 1024;
     while (cap < n) cap *= 2;
     HIPCHK(hipMalloc(&g.d_mimol, sizeof(int) * cap));
@@ -296,7 +300,7 @@ int launch_model_energy(int first, int count)
         hipLaunchKernelGGL((mw::k_model_energy<true, 1024, kFullLayout>), grid, dim3(1024), ge.shmem, g.stream, g.d_pos, g.d_ivect,
                            g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
     else
-        hipLaunchKernelGGL((mw::k_model_energy<false, 256, kFullLayout>), grid, dim3(256), ge.shmem, g.stream, g.d_pos, g.d_ivect,
+        hipLaunchKernelGGL((mw::k_model_energy<false, 256, kFullLayout, true>), grid, dim3(256), ge.shmem, g.stream, g.d_pos, g.d_ivect,
                            g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
     HIPCHK(hipGetLastError());
     // the partials of box b live at [b*nsplit .. b*nsplit+nsplit): same nsplit in both kernels
@@ -310,11 +314,8 @@ int launch_build(int first, int count)
 {
     const int box0 = first - 1;
     ++g.list_version;
-    // stats: {min, max} per box
-    std::vector<int> init((size_t)count * 2);
-    for (int b = 0; b < count; ++b) { init[2 * b] = 0x7fffffff; init[2 * b + 1] = 0; }
-    HIPCHK(hipMemcpyAsync(g.d_stats + 2 * box0, init.data(), sizeof(int) * 2 * count, hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));   // `init` is pageable: make sure it was consumed
+    hipLaunchKernelGGL(mw::k_init_stats, dim3((count + 255) / 256), dim3(256), 0, g.stream, g.d_stats, box0, count);   // {min, max} per box
+    HIPCHK(hipGetLastError());
     int ngrid = 0;
     for (int b = box0; b < box0 + count; ++b) ngrid += g.h_usegrid[b] ? 1 : 0;
     dim3 grid((g.N + 255) / 256, count);
@@ -341,10 +342,11 @@ int launch_build(int first, int count)
     }
     // the slot-major layout of the full-box kernel, columns sorted by work (mw_neighbours.hip.h, k_list_order)
     {
-        const int ngroups = (g.N + 63) / 64;
+        const int nseg = (g.N + g.order_seg - 1) / g.order_seg;
+        const int ngroups = (std::min(g.N, g.order_seg) + 63) / 64;
         const size_t shmem = g.order_kbits < 0 ? 0 : sizeof(int) * ((size_t)ngroups << g.order_kbits);
-        hipLaunchKernelGGL(mw::k_list_order, dim3(count), dim3(1024), shmem, g.stream, g.d_listm, g.d_nn, g.d_cin, g.d_stats,
-                           g.d_list, g.d_order, g.d_nns, g.d_cmax, g.N, g.S, box0, g.order_kbits);
+        hipLaunchKernelGGL(mw::k_list_order, dim3(nseg, count), dim3(1024), shmem, g.stream, g.d_listm, g.d_nn, g.d_cin, g.d_stats,
+                           g.d_list, g.d_order, g.d_nns, g.d_cmax, g.N, g.S, box0, g.order_kbits, g.order_seg);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -367,6 +369,26 @@ int finish_build(int first, int count, int* min_nn, int* max_nn)
     return 0;
 }
 
+// Free everything the context holds (any subset may be allocated: mw_init's failure path comes here too).
+void release_all()
+{
+    if (g.stream) { (void)hipSetDevice(g.device); (void)hipStreamSynchronize(g.stream); }
+    void* ptrs[] = {g.d_hmat, g.d_sw_mubin, g.d_sw_binwidth, g.d_wweight, g.d_whist, g.d_wuhist, g.d_wls, g.d_wmu, g.d_wacc,
+                    g.d_wswitch, g.d_wshift, g.d_wvol, g.d_wflag, g.d_volume, g.d_swlog, g.d_tabscratch, g.d_pos, g.d_ivect,
+                    g.d_nivect, g.d_list, g.d_listm, g.d_nn, g.d_stats, g.d_order, g.d_nns, g.d_cmax, g.d_cin, g.d_grid,
+                    g.d_usegrid, g.d_cellid, g.d_shift, g.d_sorted, g.d_ccount, g.d_cstart, g.d_ccursor, g.d_partial,
+                    g.d_cpartial, g.d_energy, g.d_counts, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.d_mperm,
+                    g.d_mwork};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (g.h_pin) (void)hipHostFree(g.h_pin);
+    for (int s = 0; s < kTimerSlots; ++s) {
+        if (g.ev[s][0]) (void)hipEventDestroy(g.ev[s][0]);
+        if (g.ev[s][1]) (void)hipEventDestroy(g.ev[s][1]);
+    }
+    if (g.stream) (void)hipStreamDestroy(g.stream);
+    g = Ctx();
+}
+
 }  // namespace
 
 extern "C" {
@@ -383,10 +405,23 @@ int mw_constants(double out[8])
     return 0;
 }
 
+static int init_impl(int device, int nwater, int nboxes, int maxneigh);
+
 int mw_init(int device, int nwater, int nboxes, int maxneigh)
 {
     MW_LOCK;
     if (g.live) return fail("mw_init: already initialised (call mw_finalize first)");
+    const int rc = init_impl(device, nwater, nboxes, maxneigh);
+    if (rc != 0) {                       // a failed allocation half way: give back what was taken, keep the message
+        const std::string msg = g_err;
+        release_all();
+        g_err = msg;
+    }
+    return rc;
+}
+
+static int init_impl(int device, int nwater, int nboxes, int maxneigh)
+{
     if (nwater < 1 || nboxes < 1) return fail("mw_init: nwater = %d, nboxes = %d must be positive", nwater, nboxes);
     if (nwater > (1 << mw::kJBits)) return fail("mw_init: nwater = %d exceeds the %d-bit packed index", nwater, mw::kJBits);
     if (maxneigh < 1 || maxneigh > MW_MAXNEIGH_LIMIT)
@@ -443,10 +478,17 @@ int mw_init(int device, int nwater, int nboxes, int maxneigh)
         std::vector<int> ident(nb * N);
         for (size_t b = 0; b < nb; ++b) for (size_t i = 0; i < N; ++i) ident[b * N + i] = (int)i;
         HIPCHK(hipMemcpy(g.d_order, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
-        // sort key bits: (key, group) table of k_list_order within kOrderSlots ints of LDS
+        // Segments of k_list_order: the whole box when the full-box kernel stages its positions in LDS; when it gathers
+        // them through the caches a wavefront keeps its 64 consecutive molecules (neighbours in index are neighbours in
+        // space: measured on 64 x 32768 molecules, sorting over 256 / 1024 / 32768 molecules costs 16 / 80 / 95 % in
+        // cache misses, more than the balance gains).  MW_ORDER_SEG overrides (a multiple of 64).
+        // Sort key bits: the (key, group) table must fit kOrderSlots.
+        g.order_seg = lds_fits(nwater, 32) ? ((nwater + 63) & ~63) : 64;
+        if (const char* sg = std::getenv("MW_ORDER_SEG")) { const int v = std::atoi(sg); if (v >= 64) g.order_seg = (v + 63) & ~63; }
+        const size_t seg_groups = ((size_t)std::min(nwater, g.order_seg) + 63) / 64;
         g.order_kbits = -1;
         for (int kb = 8; kb >= 0; --kb)
-            if ((ngroups << kb) <= (size_t)mw::kOrderSlots) { g.order_kbits = kb; break; }
+            if ((seg_groups << kb) <= (size_t)mw::kOrderSlots) { g.order_kbits = kb; break; }
     }
     g.cstride = nwater + 64;
     HIPCHK(hipMalloc(&g.d_grid, nb * sizeof(mw::GridDesc)));
@@ -489,6 +531,16 @@ int mw_init(int device, int nwater, int nboxes, int maxneigh)
                                hipFuncAttributeMaxDynamicSharedMemorySize, MW_MAXNEIGH_LIMIT * 256 * (int)sizeof(uint32_t)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_move_energy<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    {   // the sweep driver's dynamic LDS (image vectors of small or sheared cells, staged positions and rows) can pass 64 KiB
+        const void* sweeps[] = {reinterpret_cast<const void*>(&mw::k_sweep_translation<true, true, true>),
+                                reinterpret_cast<const void*>(&mw::k_sweep_translation<true, false, true>),
+                                reinterpret_cast<const void*>(&mw::k_sweep_translation<false, false, true>),
+                                reinterpret_cast<const void*>(&mw::k_sweep_translation<true, true, false>),
+                                reinterpret_cast<const void*>(&mw::k_sweep_translation<true, false, false>),
+                                reinterpret_cast<const void*>(&mw::k_sweep_translation<false, false, false>)};
+        for (const void* f : sweeps)
+            HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+    }
     g.live = true;
     return 0;
 }
@@ -497,28 +549,7 @@ int mw_finalize(void)
 {
     MW_LOCK;
     if (!g.live) return 0;
-    hipSetDevice(g.device);
-    hipStreamSynchronize(g.stream);
-    hipFree(g.d_hmat);
-    if (g.d_sw_mubin) { hipFree(g.d_sw_mubin); hipFree(g.d_sw_binwidth); hipFree(g.d_wweight); hipFree(g.d_whist); hipFree(g.d_wuhist); }
-    if (g.d_wls) { hipFree(g.d_wls); hipFree(g.d_wmu); hipFree(g.d_wacc); hipFree(g.d_wswitch); hipFree(g.d_wshift); hipFree(g.d_wvol); hipFree(g.d_wflag); }
-    hipFree(g.d_volume);
-    if (g.d_swlog) hipFree(g.d_swlog);
-    if (g.d_tabscratch) hipFree(g.d_tabscratch);
-    hipFree(g.d_pos); hipFree(g.d_ivect); hipFree(g.d_nivect); hipFree(g.d_list); hipFree(g.d_listm); hipFree(g.d_nn); hipFree(g.d_stats);
-    hipFree(g.d_order); hipFree(g.d_nns); hipFree(g.d_cmax); hipFree(g.d_cin);
-    hipFree(g.d_grid); hipFree(g.d_usegrid); hipFree(g.d_cellid); hipFree(g.d_shift); hipFree(g.d_sorted);
-    hipFree(g.d_ccount); hipFree(g.d_cstart); hipFree(g.d_ccursor);
-    hipFree(g.d_partial); hipFree(g.d_cpartial); hipFree(g.d_energy); hipFree(g.d_counts);
-    if (g.d_mimol) { hipFree(g.d_mimol); hipFree(g.d_mtrial); hipFree(g.d_meold); hipFree(g.d_menew); hipFree(g.d_mcnt); hipFree(g.d_mperm); }
-    if (g.d_mwork) hipFree(g.d_mwork);
-    hipHostFree(g.h_pin);
-    for (int s = 0; s < kTimerSlots; ++s) {
-        if (g.ev[s][0]) hipEventDestroy(g.ev[s][0]);
-        if (g.ev[s][1]) hipEventDestroy(g.ev[s][1]);
-    }
-    hipStreamDestroy(g.stream);
-    g = Ctx();
+    release_all();
     return 0;
 }
 
@@ -1051,6 +1082,33 @@ int mw_sweep_moves(double transP, double dv_max_bohr)
     if (!g.sweep_ready) return fail("mw_sweep_moves: call mw_sweep_configure first");
     if (!(transP > 0.0)) return fail("mw_sweep_moves: transP = %g must be positive", transP);
     g.sp.transP = transP; g.sp.dv_max = dv_max_bohr;
+    if (transP < 1.0) {
+        // volume moves shrink cells on the device: keep room for one more shell of images along any one axis
+        // (a move that still outgrows the table is rejected and flagged, mw_sweep_check_flags)
+        int need = g.ivcap;
+        for (int b = 0; b < g.nbox; ++b) {
+            const int* im = g.h_grid[(size_t)b].im;
+            if (g.h_nivect[(size_t)b] < 1) continue;
+            const int w0 = 2 * im[0] + 1, w1 = 2 * im[1] + 1, w2 = 2 * im[2] + 1;
+            need = std::max(need, std::max((w0 + 2) * w1 * w2, std::max(w0 * (w1 + 2) * w2, w0 * w1 * (w2 + 2))));
+        }
+        if (need > MW_MAX_IVECT) need = MW_MAX_IVECT;
+        if (need > g.ivcap && grow_ivcap(need)) return 1;
+    }
+    return 0;
+}
+
+int mw_sweep_check_flags(int first_walker, int count)
+{
+    MW_LOCK;
+    if (check_live() || check_walker(first_walker, count)) return 1;
+    std::vector<int> flags((size_t)count, 0);
+    HIPCHK(hipMemcpyAsync(flags.data(), g.d_wflag + (first_walker - 1), sizeof(int) * count, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (int w = 0; w < count; ++w)
+        if (flags[(size_t)w])
+            return fail("mw_sweep: a volume move of walker %d shrank a cell below what %d image vectors cover (the move was rejected)",
+                        first_walker + w, g.ivcap);
     return 0;
 }
 
@@ -1279,6 +1337,11 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
     const size_t shmem = iv_bytes + (ldspos ? pos_bytes : 0) + (ldslist ? list_bytes : 0)
                          + (g.sp.nlat == 2 ? (size_t)3 * g.sp.nbins * sizeof(double) : 0);   // weight, mu_bin, binwidth
     const bool withvol = g.sp.transP < 1.0;          // volume moves: the build that carries the out-of-line mc_volume
+    // static LDS of the sweep kernel: one WaveScratch, the volume move's queue, cells (generous bound)
+    const size_t static_lds = sizeof(mw::WaveScratch) + (withvol ? (size_t)(mw::kQCap + 1) * 64 * sizeof(uint32_t) : 4) + 1024;
+    if (shmem + static_lds > (size_t)160 * 1024)
+        return fail("mw_sweep: %zu bytes of LDS per walker (image vectors %zu, positions %zu, list rows %zu) exceed the CU's 160 KiB",
+                    shmem + static_lds, iv_bytes, ldspos ? pos_bytes : (size_t)0, ldslist ? list_bytes : (size_t)0);
     auto kern = withvol ? (ldslist ? mw::k_sweep_translation<true, true, true>
                                    : (ldspos ? mw::k_sweep_translation<true, false, true> : mw::k_sweep_translation<false, false, true>))
                         : (ldslist ? mw::k_sweep_translation<true, true, false>

@@ -70,7 +70,7 @@ __device__ __forceinline__ uint32_t list_load(ListRsrc rs, uint32_t column_bytes
 // slots at a time and ONE CHUNK AHEAD: `cur` arrives holding this column's first eight entries; while a chunk is
 // being tested the next one -- of this column, or the first of the thread's next column `col_next` -- is already
 // in flight, so the HBM latency of the list stream hides behind the LDS gathers and distance tests.
-template <int BLOCK, typename PosFn, typename IvFn>
+template <int BLOCK, bool BATCH4, typename PosFn, typename IvFn>
 __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32_t col_next, int mol, int n, int nmax, int c0min,
                                                int N, int S, uint32_t* __restrict__ queue, PosFn getpos, IvFn getiv,
                                                uint32_t (&cur)[8])
@@ -87,6 +87,42 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
         const int ps = last ? 0 : s0 + 8;
 #pragma unroll
         for (int u = 0; u < 8; ++u) nxt[u] = list_load(rs, pc, ps + u, N, S);
+        if constexpr (BATCH4) {
+        // four slots at a time: their gathers are issued together, then the four tests (a slot past the longest
+        // row holds whatever the prefetch brought -- never live, and an LDS gather cannot fault)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int sb = s0 + 4 * h;
+            if (sb < nmax) {                                  // wave-uniform
+                double d[4][3];
+                if (sb + 4 <= c0min) {                        // wave-uniform: central image only, its vector is exactly 0 (molint.F90:197)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) getpos((int)(cur[4 * h + u] & kJMask), d[u][0], d[u][1], d[u][2]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { d[u][0] -= xi; d[u][1] -= yi; d[u][2] -= zi; }
+                } else {
+                    double iv[4][3];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        getpos((int)(cur[4 * h + u] & kJMask), d[u][0], d[u][1], d[u][2]);
+                        getiv((int)(cur[4 * h + u] >> kJBits), iv[u][0], iv[u][1], iv[u][2]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {                                             // molint.F90:447,450
+                        d[u][0] = (d[u][0] + iv[u][0]) - xi; d[u][1] = (d[u][1] + iv[u][1]) - yi; d[u][2] = (d[u][2] + iv[u][2]) - zi;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double r2 = d[u][0] * d[u][0] + d[u][1] * d[u][1] + d[u][2] * d[u][2];
+                    if (sb + u < n && r2 < kRcSq) {                                           // :454
+                        queue[(cnt < kQCap ? cnt : kQCap) * BLOCK] = cur[4 * h + u];
+                        ++cnt;
+                    }
+                }
+            }
+        }
+        } else {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (s0 + u < nmax) {                              // wave-uniform
@@ -107,6 +143,7 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
                     ++cnt;
                 }
             }
+        }
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
@@ -203,7 +240,7 @@ struct LdsVecs {
 // The wavefronts of a workgroup draw groups of 64 list columns from an LDS ticket, heaviest group first (the
 // columns are sorted by work, ascending): a wavefront that drew cheap groups serves more of them, and the
 // workgroup's tail is made of the cheapest groups.
-template <bool LDSPOS, int BLOCK, int LAYOUT>
+template <bool LDSPOS, int BLOCK, int LAYOUT, bool BATCH4 = false>
 __global__ __launch_bounds__(BLOCK)
 void k_model_energy(const double* __restrict__ pos, const double* __restrict__ ivect,
                     const int* __restrict__ nivect, const uint32_t* __restrict__ list,
@@ -275,7 +312,7 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
             if (tn < a1) { col_next = (uint32_t)tn * 4u; n_next = NNS[tn]; mol_next = ORD[tn]; }
         }
         const int cm = __builtin_amdgcn_readfirstlane(CM[grp]);
-        AtomSum a = atom_energy<BLOCK>(rs, col, col_next, mol, act ? (n_cur & 0xff) : 0, cm & 0xff, cm >> 8, N, S,
+        AtomSum a = atom_energy<BLOCK, BATCH4>(rs, col, col_next, mol, act ? (n_cur & 0xff) : 0, cm & 0xff, cm >> 8, N, S,
                                        queue, getpos, getiv, cur);
         if (act) { np += (unsigned int)a.cnt; nt += (unsigned int)(a.cnt * (a.cnt - 1) / 2); }
         const double ge = dpp_wave_sum(act ? a.e : 0.0);             // fixed tree; total in lane 63

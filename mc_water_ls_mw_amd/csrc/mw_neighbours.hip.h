@@ -86,6 +86,13 @@ struct GridDesc {
     int pad;
 };
 
+// {min, max} row length of each box of a build: reset on the device (no host round trip in front of a build)
+__global__ void k_init_stats(int* __restrict__ stats, int box0, int count)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < count) { stats[2 * (box0 + b)] = 0x7fffffff; stats[2 * (box0 + b) + 1] = 0; }
+}
+
 // shift (floor of the fractional coordinate) packed 10 bits per component, biased by 512
 __device__ __forceinline__ int pack_shift(int a, int b, int c) { return (a + 512) | ((b + 512) << 10) | ((c + 512) << 20); }
 
@@ -259,34 +266,40 @@ void k_cell_search(const double* __restrict__ pos, const double* __restrict__ iv
 // are ordered by (neighbours inside the energy cutoff at build time, interior / boundary, row length), so that
 // the 64 lanes of a wavefront run the same number of cheap distance tests and the same number of expensive pair
 // evaluations, and whole wavefronts of interior molecules never touch the image vectors.
+// The sort runs inside SEGMENTS of `seg` consecutive molecules (seg % 64 == 0; the whole box when its positions
+// are staged in LDS, 1024 molecules when they are gathered through the caches, where neighbours in index are
+// neighbours in space and a wavefront's gathers should stay close together), one workgroup per segment.
 // Stable counting sort -- a box always gets the same order, so energies stay bitwise reproducible:
 //   A  histogram over (key, group of 64 consecutive molecules) in LDS,
 //   scan in (key, group) order,
 //   B  every molecule's destination = start of its (key, group) cell + its rank among the group's lanes
 //      with the same key (ballots),
-//   C  column t of the slot-major list <- row order[t] of the molecule-major list (coalesced stores).
+//   C  column t of the slot-major list <- row order[t] of the molecule-major list (coalesced stores), central-image
+//      entries first, zero-padded to the longest row of the column's group of 64.
 // kbits = number of key bits kept (the (key, group) table must fit kOrderSlots); kbits < 0: identity order.
-//   grid = boxes, block = 1024
+//   grid = (segments, boxes), block = 1024
 // =====================================================================================
 constexpr int kOrderSlots = 32768;      // ints of dynamic LDS at most (128 KiB)
 
 __global__ __launch_bounds__(1024)
 void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn, const unsigned char* __restrict__ cin,
                   const int* __restrict__ stats, uint32_t* __restrict__ list, int* __restrict__ order,
-                  int* __restrict__ nns, int* __restrict__ cmax, int N, int S, int box0, int kbits)
+                  int* __restrict__ nns, int* __restrict__ cmax, int N, int S, int box0, int kbits, int seg)
 {
-    extern __shared__ __attribute__((aligned(16))) int hist[];       // [keys][groups], dynamic
+    extern __shared__ __attribute__((aligned(16))) int hist[];       // [keys][groups of the segment], dynamic
     __shared__ int wsum[16];
-    const int b = box0 + blockIdx.x;
+    const int b = box0 + blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int ngroups = (N + 63) >> 6;
+    const int i0 = blockIdx.x * seg, i1 = min(N, i0 + seg);          // this workgroup's molecules = its list columns
+    const int ngroups = (i1 - i0 + 63) >> 6;
+    const int ngroups_box = (N + 63) >> 6;
     const uint32_t* LM = listm + (size_t)b * N * kRow;
     const int* NN = nn + (size_t)b * N;
     const unsigned char* CI = cin + (size_t)b * N;
     uint32_t* L = list + (size_t)b * S * N;
     int* ORD = order + (size_t)b * N;
     int* NNS = nns + (size_t)b * N;
-    int* CM = cmax + (size_t)b * ngroups;
+    int* CM = cmax + (size_t)b * ngroups_box;
     const int nmin = stats[2 * b];
 
     // key = in-range neighbours at build time (4 bits) | has entries of a non-central image (1 bit) | row length (3 bits)
@@ -298,16 +311,16 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
     };
 
     if (kbits < 0) {
-        for (int i = tid; i < N; i += 1024) { ORD[i] = i; NNS[i] = min(NN[i], S); }
+        for (int i = i0 + tid; i < i1; i += 1024) { ORD[i] = i; NNS[i] = min(NN[i], S); }
     } else {
         const int K = 1 << kbits, M = K * ngroups;
         for (int e = tid; e < M; e += 1024) hist[e] = 0;
         __syncthreads();
-        for (int i = tid; i < N; i += 1024) atomicAdd(&hist[keyof(i, NN[i]) * ngroups + (i >> 6)], 1);
+        for (int i = i0 + tid; i < i1; i += 1024) atomicAdd(&hist[keyof(i, NN[i]) * ngroups + ((i - i0) >> 6)], 1);
         __syncthreads();
         // exclusive scan of hist[0..M): `per` consecutive elements per thread
         const int per = (M + 1023) / 1024;
-        const int e0 = tid * per, e1 = min(M, e0 + per);
+        const int e0 = min(M, tid * per), e1 = min(M, e0 + per);
         int local = 0;
         for (int e = e0; e < e1; ++e) local += hist[e];
         int incl = local;
@@ -319,9 +332,9 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
         for (int w = 0; w < wid; ++w) run += wsum[w];
         for (int e = e0; e < e1; ++e) { const int v = hist[e]; hist[e] = run; run += v; }
         __syncthreads();
-        for (int base = 0; base < N; base += 1024) {
+        for (int base = i0; base < i1; base += 1024) {
             const int i = base + tid;
-            const bool valid = i < N;
+            const bool valid = i < i1;
             const int n = valid ? NN[i] : 0;
             const int key = valid ? keyof(i, n) : 0;
             unsigned long long same = __ballot(valid);
@@ -331,18 +344,18 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
             }
             const int rank = __popcll(same & ((1ull << lane) - 1ull));
             if (valid) {
-                const int dst = hist[key * ngroups + (i >> 6)] + rank;
+                const int dst = i0 + hist[key * ngroups + ((i - i0) >> 6)] + rank;
                 ORD[dst] = i; NNS[dst] = min(n, S);
             }
         }
     }
-    __syncthreads();   // ORD / NNS of this box are read back below by other threads of this workgroup
+    __syncthreads();   // ORD / NNS of this segment are read back below by other threads of this workgroup
     // Column t <- row ORD[t], entries of the central image first: the full-box kernel then skips the image-vector
     // gather for the slots every lane of a wavefront knows to be central (c0min).  NNS[t] = n | n0 << 8 (n0 = central
     // entries), CM[group] = longest row | smallest n0 << 8.
-    for (int base = 0; base < N; base += 1024) {
+    for (int base = i0; base < i1; base += 1024) {
         const int t = base + tid;
-        const bool valid = t < N;
+        const bool valid = t < i1;
         const int i = valid ? ORD[t] : 0;
         const int n = valid ? NNS[t] : 0;
         const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i(n));
@@ -364,7 +377,7 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
                 const int n0 = w;
                 if (valid) NNS[t] = n | (n0 << 8);
                 const int c0min = __builtin_amdgcn_readfirstlane(wave_min_i(valid ? n0 : 0x7fff));
-                if (lane == 0 && (t >> 6) < ngroups) CM[t >> 6] = nmax | ((c0min > 255 ? 255 : c0min) << 8);
+                if (lane == 0 && valid) CM[t >> 6] = nmax | ((c0min > 255 ? 255 : c0min) << 8);
             }
         }
     }

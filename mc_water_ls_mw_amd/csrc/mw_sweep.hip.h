@@ -210,7 +210,7 @@ __device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, 
         int n_next = 0, mol_next = 0;
         if (tn < c.N) { col_next = (uint32_t)tn * 4u; n_next = NNS[tn]; mol_next = ORD[tn]; }
         const int cm = __builtin_amdgcn_readfirstlane(CM[base >> 6]);
-        AtomSum a = atom_energy<64>(rs, col, col_next, mol, act ? (n_cur & 0xff) : 0, cm & 0xff, cm >> 8, c.N, c.S, c.queue, getpos, getiv, cur);
+        AtomSum a = atom_energy<64, false>(rs, col, col_next, mol, act ? (n_cur & 0xff) : 0, cm & 0xff, cm >> 8, c.N, c.S, c.queue, getpos, getiv, cur);
         if (act) esum += a.e;
         n_cur = n_next; mol = mol_next; col = col_next;
     }
@@ -244,26 +244,29 @@ int volume_move_wave(const VolCtx& c, const SweepParams& sp, const double* weigh
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     double new_e[2] = {0.0, 0.0};
-    int bad = 0;
+    int bad = 0, nresc = 0;                                                                     // nresc: lattices rescaled so far
     for (int l = 0; l < L; ++l) {                                                               // :1285-1358
         dev_rescale(c, l, recip_used[l], c.shmat + 9 * l, lane);
+        nresc = l + 1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int niv = dev_compute_ivects(c.shmat + 9 * l, c.siv + (size_t)l * c.ivcap * 3,
                                            c.ivect_g + (size_t)l * c.ivcap * 3, c.ivcap, lane);
-        if (niv < 0) { bad = 1; break; }
         if (lane == 0) {
             c.svol[l] = fabs(dev_det3(c.shmat + 9 * l));
             double rcp[9];
             dev_recipmatrix(c.shmat + 9 * l, rcp);
 #pragma unroll
             for (int t = 0; t < 9; ++t) c.srecip[l * 9 + t] = rcp[t];
-            c.sniv[l] = niv; c.nivect_g[l] = niv;
+            if (niv >= 0) { c.sniv[l] = niv; c.nivect_g[l] = niv; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // The new cell needs more image vectors than there is room for: the move counts as rejected (and is
+        // flagged); the lattices rescaled so far -- this one included, its reciprocal matrix is in place -- go back.
+        if (niv < 0) { bad = 1; break; }
         new_e[l] = dev_wave_model_energy(c, l, lane);
     }
     int ok = 0;
@@ -301,7 +304,7 @@ int volume_move_wave(const VolCtx& c, const SweepParams& sp, const double* weigh
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        for (int l = 0; l < L; ++l) {
+        for (int l = 0; l < (bad ? nresc : L); ++l) {
             dev_rescale(c, l, recip_new[l], c.shmat + 9 * l, lane);                              // back through the NEW recip
             const int niv = dev_compute_ivects(c.shmat + 9 * l, c.siv + (size_t)l * c.ivcap * 3,
                                                c.ivect_g + (size_t)l * c.ivcap * 3, c.ivcap, lane);   // :1510-1512
@@ -549,19 +552,22 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
                         uhist[k - 1] = uhist[k - 1] + (sp.av_binwidth / bwk) * exp(etaw - sp.log_unbiased_norm);   // :1627-1629
                     }
                 } else {
-                    // weight(k) += av_binwidth*wl_factor/binwidth(k); then subtract the minimum over the window (:1680-1685)
+                    // weight(k) += av_binwidth*wl_factor/binwidth(k) -- whichever bin k is (:1680); then the minimum over the
+                    // walker's window is subtracted inside the window (:1682-1685; with 'dd' windows k may lie outside)
+                    const double inc = sp.av_binwidth * sp.wl_factor / bwk;
                     double mn = 1.7976931348623157e308;
                     for (int b = sp.start_bin - 1 + lane; b < sp.end_bin; b += 64) {
                         double w = weight[b];
-                        if (b == k - 1) w = w + sp.av_binwidth * sp.wl_factor / bwk;
+                        if (b == k - 1) w = w + inc;
                         mn = w < mn ? w : mn;
                     }
                     mn = readlane_f64(dpp_wave_min(mn), 63);
                     for (int b = sp.start_bin - 1 + lane; b < sp.end_bin; b += 64) {
                         double w = weight[b];
-                        if (b == k - 1) w = w + sp.av_binwidth * sp.wl_factor / bwk;
+                        if (b == k - 1) w = w + inc;
                         weight[b] = w - mn;
                     }
+                    if (lane == 0 && (k < sp.start_bin || k > sp.end_bin)) weight[k - 1] = weight[k - 1] + inc;
                     gauge += mn;
                     if (lane == 0) hist[k - 1] = hist[k - 1] + sp.av_binwidth / bwk;
                 }

@@ -49,7 +49,7 @@ ABI_SYMBOLS = (
     "mw_sweep_options", "mw_sweep_get_tables", "mw_sweep_set_tables", "mw_sweep_get_switches", "mw_sweep_get_shifts_range",
     "mw_sweep_reduce_tables", "mw_sweep_broadcast_tables",
     "mw_sweep_get_tables_range", "mw_sweep_set_tables_range",
-    "mw_sweep_moves", "mw_sweep_get_volume_moves", "mw_sweep_sync_cells",
+    "mw_sweep_moves", "mw_sweep_get_volume_moves", "mw_sweep_sync_cells", "mw_sweep_check_flags",
 )
 
 

@@ -23,12 +23,16 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         list_update_int=10, mpi_sync_int=250, sigma_ang=0.05, seed=2025, device=0, comms=None, rank=0,
         samplerun=False, weight=None, npt=False, pressure_atm=1.0,
         flat_chk_int=10000, wl_schedule=0, wl_flattol=0.05, wl_minhist=20, wl_useinvt=False, file_wl_factor=None,
-        deltaG_int=100000, max_mc_cycles=None, eq_mc_cycles=0, outdir=None, thermalise=True):
+        deltaG_int=100000, max_mc_cycles=None, eq_mc_cycles=0, outdir=None, thermalise=True, regauge=False):
     """Run `cycles` MC cycles of `walkers` two-lattice walkers on this GPU.  Returns a dict of results.
 
     ``flat_chk_int`` ... ``file_wl_factor``: the Wang-Landau schedule (mc_check_flatness, :291-294;
     :mod:`mc_water_ls_mw_amd.schedule`); ``deltaG_int``: free-energy estimate of a sample run (:302-306);
-    ``outdir``: where wlf.dat and the tagged tables go (nothing is written when None)."""
+    ``outdir``: where wlf.dat and the tagged tables go (nothing is written when None).
+    ``regauge``: False (default) is the reference's exchange arithmetic to the letter (comms_mpi.f90:256-270: every
+    rank's increment carries the window minimum it subtracted); True sums the increments proper and subtracts the
+    minimum once (WalkerFarm.synchronise) -- the mode for farms of hundreds of walkers per GPU, where the reference's
+    scheme loses the weights' precision within a few synchronisations (tests/test_sweep.py shows the growth)."""
     from . import lattice as lat
     from .energy import EnergyModule
     from .schedule import WangLandauSchedule, delta_g_from_hist, log_unbiased_norm
@@ -94,7 +98,9 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             farm.sweep_launch(n * (cyc - first + 1), seed=seed + rank, move0=(first - 1) * n)
             if cyc % mpi_sync_int == 0:                            # mc_moves.F90:258-276
                 em.sync()
-                synced = farm.synchronise(comms, regauge=True)
+                if npt:
+                    farm.check_flags()
+                synced = farm.synchronise(comms, regauge=regauge)
             if cyc % flat_chk_int == 0:                            # :291-294
                 em.sync()
                 ev = sched.check_flatness(cyc, n, farm, comms)
@@ -102,7 +108,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                     events.append(ev)
             if samplerun and cyc % deltaG_int == 0:                # :302-306
                 em.sync()
-                synced = farm.synchronise(comms, regauge=True)     # comms_allreduce_uhist (:2532) with the rest
+                synced = farm.synchronise(comms, regauge=regauge)  # comms_allreduce_uhist (:2532) with the rest
                 dg, per, normp = delta_g_from_hist(synced[2], grid.binwidth, n, temperature)
                 delta_g = dict(cycle=cyc, kT=dg, **{"per_molecule_" + k: v for k, v in per.items()})
                 if outdir is not None and comms.rank == 0:         # :2590-2613
@@ -110,6 +116,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                         for m_, p_ in zip(grid.mu_bin, normp):
                             fh.write(f"  {float(m_)!r}        {float(p_)!r}\n")
         em.sync()
+        if npt:
+            farm.check_flags()                                     # every walker, not only the ones read out below
         wall = time.perf_counter() - t0
         states = [farm.state(w) for w in range(1, min(walkers, 32) + 1)]
         fresh = em.model_energy_batch(1, 2)
@@ -146,6 +154,9 @@ def main():
     ap.add_argument("--wl-minhist", type=int, default=20)
     ap.add_argument("--wl-useinvt", action="store_true")
     ap.add_argument("--outdir", default=None, help="directory for wlf.dat / eta_weights.dat_* / histogram.dat_*")
+    ap.add_argument("--regauge", action="store_true",
+                    help="exchange step sums the weight increments proper and subtracts the window minimum once "
+                         "(default: the reference's arithmetic, comms_mpi.f90:256-270)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -166,7 +177,7 @@ def main():
     res = run([z1["h"], z2["h"]], [z1["xyz"], z2["xyz"]], args.walkers, args.cycles, mpi_sync_int=args.sync,
               device=local, comms=comms, rank=rank, npt=args.npt, wl_factor=args.wl_factor, flat_chk_int=args.flat_chk,
               wl_schedule=args.wl_schedule, wl_flattol=args.wl_flattol, wl_minhist=args.wl_minhist,
-              wl_useinvt=args.wl_useinvt, outdir=args.outdir)
+              wl_useinvt=args.wl_useinvt, outdir=args.outdir, regauge=args.regauge)
     tabs = res.pop("tables")
     res.pop("walker1_tables"), res.pop("walker1_positions")
     if world > 1:

@@ -114,6 +114,12 @@ class WalkerFarm:
         self.em._chk(self.L.mw_sweep_get_volume_moves(walker, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    def check_flags(self):
+        """Fail loudly if a volume move of ANY walker outgrew the image-vector table since the last call (such a
+        move is rejected and undone on the device, so the walker's state is consistent, but its chain has left
+        mc_volume's)."""
+        self.em._chk(self.L.mw_sweep_check_flags(1, self.nwalkers))
+
     def sync_cells(self):
         """Bring the host's hmatrix / volume / image vectors / grid descriptors up to date after device-side
         volume moves (call before rebuilding neighbour lists)."""
@@ -197,7 +203,7 @@ class WalkerFarm:
         grows by the factor -(R-1) per synchronisation once no bin is left at weight 0 (the reference carries a
         disabled "negative growth of eta" check for it, comms_mpi.f90:258-263).  Eight ranks live with that for a
         while; eight thousand walkers per GPU lose all precision within a few synchronisations.
-        ``regauge=True`` (what farm.run uses): the device keeps each walker's accumulated minimum, the sum is taken
+        ``regauge=True`` (farm.run's opt-in ``regauge``): the device keeps each walker's accumulated minimum, the sum is taken
         over weight + that (the increments proper), and the window minimum is subtracted once from the result --
         one shared table in the reference's own gauge; identical to the reference for a single walker."""
         comms = self.local_comms() if comms is None else comms

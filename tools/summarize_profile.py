@@ -22,7 +22,7 @@ os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
-for name in ("fetch", "write"):
+for name in ("fetch", "write", "sq1", "sq2"):
     path = os.path.join(src, f"pmc_{name}", f"{name}_counter_collection.csv")
     if not os.path.exists(path):
         continue
@@ -55,4 +55,22 @@ for k, r in stats.items():
 lines += ["", "Bench line of the traced run:", "", "```json", json.dumps(bench), "```", ""]
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines))
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"))
+
+# raw counters per kernel (means over the launches) for bench.py's roofline block: profiles/counters.json
+counters = {"walkers": W, "moves": M, "tag": tag,
+            "source": "rocprofv3 --pmc, separate passes (tools/profile.sh); FETCH_SIZE / WRITE_SIZE in KiB, SQ_* as reported"}
+sq_lines = [f"# SQ / GRBM / TCC counters per kernel, means over the launches of `{tag}` (tools/profile.sh)"]
+for k, cs in sorted(pmc.items()):
+    if not k.startswith("mw::"):
+        continue
+    short = k.replace("mw::", "").split("<")[0]
+    rec = {c: sum(v) / len(v) for c, v in cs.items()}
+    if k in stats:
+        rec["avg_us"] = float(stats[k]["AverageNs"]) / 1e3
+    if short in ("k_model_energy", "k_move_energy"):
+        counters[short] = rec
+    for c, v in sorted(rec.items()):
+        sq_lines.append(f"{k:48s} {c:24s} {v:.6g}")
+json.dump(counters, open(os.path.join(dst, "counters.json"), "w"), indent=1)
+open(os.path.join(dst, f"{tag}_pmc_counters.txt"), "w").write("\n".join(sq_lines) + "\n")
 print("\n".join(lines[:12]))
