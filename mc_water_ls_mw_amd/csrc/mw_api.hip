@@ -70,6 +70,9 @@ struct Ctx {
     mw::GridDesc* d_grid = nullptr;
     int* d_usegrid = nullptr;
     int *d_cellid = nullptr, *d_shift = nullptr, *d_sorted = nullptr;
+    float4 *d_wrel = nullptr, *d_wpos = nullptr;   // wrapped cell-relative positions (single precision) by molecule / by cell-sorted slot
+    int* d_wsh = nullptr;                          // packed shifts by cell-sorted slot
+    bool legacy_search = false;                    // MW_CELL_SEARCH=legacy: the one-thread-per-molecule search (cross-check)
     int *d_ccount = nullptr, *d_cstart = nullptr, *d_ccursor = nullptr;
     int cstride = 0;
     std::vector<mw::GridDesc> h_grid;
@@ -226,6 +229,21 @@ mw::GridDesc make_grid(const double h[9], const int imv[3], int max_cells)
     }
     G.nc[0] = nc[0]; G.nc[1] = nc[1]; G.nc[2] = nc[2];
     G.ncell = nc[0] * nc[1] * nc[2];
+    for (int d = 0; d < 9; ++d) G.h[d] = h[d];
+    // Error bound of k_cell_pairs' single-precision squared distance.  Coordinates there are relative to a grid
+    // cell's origin: |.| <= 2 D for a candidate, D for the molecule itself, D = the grid cell's longest diagonal.
+    // Each coordinate difference carries at most 8 ulp(D) of rounding (conversions, the piece offset, the
+    // subtraction), the squared sum 2 sqrt(3) r delta + 4 ulp(r^2) at r ~ rn.  Doubled for safety; a pair whose
+    // single-precision r^2 lies within eps of rn^2 is re-decided in double precision by the reference's expression.
+    double D = 0.0;
+    for (int sg = 0; sg < 4; ++sg) {
+        const double s1 = (sg & 1) ? -1.0 : 1.0, s2 = (sg & 2) ? -1.0 : 1.0;
+        double v[3];
+        for (int d = 0; d < 3; ++d) v[d] = a[d] / nc[0] + s1 * b[d] / nc[1] + s2 * c[d] / nc[2];
+        D = std::max(D, std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]));
+    }
+    const double ulp = 5.9604644775390625e-08, r = mw::kRn + 1.0;      // 2^-24
+    G.eps = (float)(2.0 * (2.0 * std::sqrt(3.0) * r * 8.0 * ulp * D + 4.0 * ulp * r * r));
     return G;
 }
 
@@ -321,18 +339,36 @@ int launch_build(int first, int count)
     dim3 grid((g.N + 255) / 256, count);
     if (ngrid > 0) {
         HIPCHK(hipMemsetAsync(g.d_ccount + (size_t)box0 * g.cstride, 0, sizeof(int) * (size_t)count * g.cstride, g.stream));
-        hipLaunchKernelGGL(mw::k_cell_bin, grid, dim3(256), 0, g.stream, g.d_pos, g.d_grid, g.d_cellid, g.d_shift, g.d_ccount,
+        hipLaunchKernelGGL(mw::k_cell_bin, grid, dim3(256), 0, g.stream, g.d_pos, g.d_grid, g.d_cellid, g.d_shift, g.d_wrel, g.d_ccount,
                            g.N, g.cstride, box0);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(mw::k_cell_scan, dim3(count), dim3(1024), 0, g.stream, g.d_grid, g.d_ccount, g.d_cstart, g.d_ccursor,
                            g.cstride, box0);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(mw::k_cell_scatter, grid, dim3(256), 0, g.stream, g.d_grid, g.d_cellid, g.d_ccursor, g.d_sorted,
-                           g.N, g.cstride, box0);
+        hipLaunchKernelGGL(mw::k_cell_scatter, grid, dim3(256), 0, g.stream, g.d_grid, g.d_cellid, g.d_shift, g.d_wrel, g.d_ccursor,
+                           g.d_sorted, g.d_wpos, g.d_wsh, g.N, g.cstride, box0);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(mw::k_cell_search, grid, dim3(256), (size_t)g.S * 256 * sizeof(uint32_t), g.stream, g.d_pos, g.d_ivect,
-                           g.d_grid, g.d_cellid, g.d_shift, g.d_cstart, g.d_sorted, g.d_listm, g.d_nn, g.d_cin, g.d_stats,
-                           g.N, g.S, g.ivcap, g.cstride, box0);
+        if (g.legacy_search) {
+            hipLaunchKernelGGL(mw::k_cell_search, grid, dim3(256), (size_t)g.S * 256 * sizeof(uint32_t), g.stream, g.d_pos, g.d_ivect,
+                               g.d_grid, g.d_cellid, g.d_shift, g.d_cstart, g.d_sorted, g.d_listm, g.d_nn, g.d_cin, g.d_stats,
+                               g.N, g.S, g.ivcap, g.cstride, box0);
+        } else {
+            // one wavefront per block of grid cells along the third axis, four per workgroup; cells per block: enough
+            // for ~13 molecules per wavefront (MW_PAIR_BCELLS overrides)
+            int bcells = 1, maxblocks = 0;
+            for (int b = box0; b < box0 + count; ++b)
+                if (g.h_usegrid[b]) { bcells = std::max(bcells, (int)(13.0 * g.h_grid[(size_t)b].ncell / g.N + 0.5)); }
+            if (const char* ev = std::getenv("MW_PAIR_BCELLS")) bcells = std::atoi(ev);
+            bcells = std::max(1, std::min(bcells, mw::kPairMaxB));
+            for (int b = box0; b < box0 + count; ++b) {
+                if (!g.h_usegrid[b]) continue;
+                const mw::GridDesc& G = g.h_grid[(size_t)b];
+                const int B = std::min(bcells, G.nc[2]);
+                maxblocks = std::max(maxblocks, G.nc[0] * G.nc[1] * ((G.nc[2] + B - 1) / B));
+            }
+            hipLaunchKernelGGL(mw::k_cell_pairs, dim3((maxblocks + 3) / 4, count), dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_grid,
+                               g.d_cstart, g.d_wpos, g.d_wsh, g.d_listm, g.d_nn, g.d_cin, g.d_stats, g.N, g.S, g.ivcap, g.cstride, box0, bcells);
+        }
         HIPCHK(hipGetLastError());
     }
     if (ngrid < count) {
@@ -376,7 +412,7 @@ void release_all()
     void* ptrs[] = {g.d_hmat, g.d_sw_mubin, g.d_sw_binwidth, g.d_wweight, g.d_whist, g.d_wuhist, g.d_wls, g.d_wmu, g.d_wacc,
                     g.d_wswitch, g.d_wshift, g.d_wvol, g.d_wflag, g.d_volume, g.d_swlog, g.d_tabscratch, g.d_pos, g.d_ivect,
                     g.d_nivect, g.d_list, g.d_listm, g.d_nn, g.d_stats, g.d_order, g.d_nns, g.d_cmax, g.d_cin, g.d_grid,
-                    g.d_usegrid, g.d_cellid, g.d_shift, g.d_sorted, g.d_ccount, g.d_cstart, g.d_ccursor, g.d_partial,
+                    g.d_usegrid, g.d_cellid, g.d_shift, g.d_sorted, g.d_wrel, g.d_wpos, g.d_wsh, g.d_ccount, g.d_cstart, g.d_ccursor, g.d_partial,
                     g.d_cpartial, g.d_energy, g.d_counts, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.d_mperm,
                     g.d_mwork};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -496,6 +532,10 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
     HIPCHK(hipMalloc(&g.d_cellid, nb * N * sizeof(int)));
     HIPCHK(hipMalloc(&g.d_shift, nb * N * sizeof(int)));
     HIPCHK(hipMalloc(&g.d_sorted, nb * N * sizeof(int)));
+    HIPCHK(hipMalloc(&g.d_wrel, nb * N * sizeof(float4)));
+    HIPCHK(hipMalloc(&g.d_wpos, nb * N * sizeof(float4)));
+    HIPCHK(hipMalloc(&g.d_wsh, nb * N * sizeof(int)));
+    { const char* cs = std::getenv("MW_CELL_SEARCH"); g.legacy_search = cs && std::strcmp(cs, "legacy") == 0; }
     HIPCHK(hipMalloc(&g.d_ccount, nb * (size_t)g.cstride * sizeof(int)));
     HIPCHK(hipMalloc(&g.d_cstart, nb * ((size_t)g.cstride + 1) * sizeof(int)));
     HIPCHK(hipMalloc(&g.d_ccursor, nb * (size_t)g.cstride * sizeof(int)));

@@ -80,10 +80,11 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
 // =====================================================================================
 struct GridDesc {
     double hinv[9];        // s = hinv * r (row-major 3x3): fractional coordinates
+    double h[9];           // cell vectors (column-major hmatrix: h[3k + d] = component d of vector k)
     int nc[3];             // grid cells along h1, h2, h3 (0: box uses the brute-force kernel)
     int im[3];             // image-table half widths (molint.F90:189-191)
     int ncell;             // nc[0]*nc[1]*nc[2]
-    int pad;
+    float eps;             // bound on the error of the float pre-filter's squared distance (k_cell_pairs)
 };
 
 // {min, max} row length of each box of a build: reset on the device (no host round trip in front of a build)
@@ -98,7 +99,7 @@ __device__ __forceinline__ int pack_shift(int a, int b, int c) { return (a + 512
 
 __global__ __launch_bounds__(256)
 void k_cell_bin(const double* __restrict__ pos, const GridDesc* __restrict__ grid,
-                int* __restrict__ cellid, int* __restrict__ shift, int* __restrict__ count,
+                int* __restrict__ cellid, int* __restrict__ shift, float4* __restrict__ wrel, int* __restrict__ count,
                 int N, int cstride, int box0)
 {
     const int b = box0 + blockIdx.y;
@@ -109,6 +110,7 @@ void k_cell_bin(const double* __restrict__ pos, const GridDesc* __restrict__ gri
     const double* p = pos + ((size_t)b * N + i) * 3;
     const double x = p[0], y = p[1], z = p[2];
     int c[3], f[3];
+    double u[3];           // position inside the grid cell, in units of the cell vectors / nc
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const double sd = G.hinv[3 * d] * x + G.hinv[3 * d + 1] * y + G.hinv[3 * d + 2] * z;
@@ -116,12 +118,18 @@ void k_cell_bin(const double* __restrict__ pos, const GridDesc* __restrict__ gri
         int ci = (int)((sd - fl) * (double)G.nc[d]);
         ci = ci < 0 ? 0 : (ci >= G.nc[d] ? G.nc[d] - 1 : ci);
         c[d] = ci;
+        u[d] = ((sd - fl) * (double)G.nc[d] - (double)ci) / (double)G.nc[d];
         int sh = (int)fl;
         f[d] = sh < -511 ? -511 : (sh > 511 ? 511 : sh);   // farther out than the image table reaches anyway
     }
     const int cid = (c[0] * G.nc[1] + c[1]) * G.nc[2] + c[2];
     cellid[(size_t)b * N + i] = cid;
     shift[(size_t)b * N + i] = pack_shift(f[0], f[1], f[2]);
+    // the wrapped position relative to its grid cell's origin: small numbers, so single precision keeps ~1e-6 bohr
+    // (k_cell_pairs' pre-filter); .w carries the molecule index
+    wrel[(size_t)b * N + i] = make_float4((float)(u[0] * G.h[0] + u[1] * G.h[3] + u[2] * G.h[6]),
+                                          (float)(u[0] * G.h[1] + u[1] * G.h[4] + u[2] * G.h[7]),
+                                          (float)(u[0] * G.h[2] + u[1] * G.h[5] + u[2] * G.h[8]), __int_as_float(i));
     atomicAdd(&count[(size_t)b * cstride + cid], 1);
 }
 
@@ -160,8 +168,9 @@ void k_cell_scan(const GridDesc* __restrict__ grid, const int* __restrict__ coun
 }
 
 __global__ __launch_bounds__(256)
-void k_cell_scatter(const GridDesc* __restrict__ grid, const int* __restrict__ cellid,
-                    int* __restrict__ cursor, int* __restrict__ sorted, int N, int cstride, int box0)
+void k_cell_scatter(const GridDesc* __restrict__ grid, const int* __restrict__ cellid, const int* __restrict__ shift,
+                    const float4* __restrict__ wrel, int* __restrict__ cursor, int* __restrict__ sorted,
+                    float4* __restrict__ wpos, int* __restrict__ wsh, int N, int cstride, int box0)
 {
     const int b = box0 + blockIdx.y;
     if (grid[b].nc[0] == 0) return;
@@ -170,6 +179,8 @@ void k_cell_scatter(const GridDesc* __restrict__ grid, const int* __restrict__ c
     const int cid = cellid[(size_t)b * N + i];
     const int slot = atomicAdd(&cursor[(size_t)b * cstride + cid], 1);
     sorted[(size_t)b * N + slot] = i;      // order inside a cell is arbitrary: the final lists are sorted
+    wpos[(size_t)b * N + slot] = wrel[(size_t)b * N + i];    // cell-ordered copies: a cell's molecules are one contiguous load
+    wsh[(size_t)b * N + slot] = shift[(size_t)b * N + i];
 }
 
 // One thread per molecule, taken in grid order so that a wavefront walks the same cells.
@@ -262,6 +273,294 @@ void k_cell_search(const double* __restrict__ pos, const double* __restrict__ iv
 }
 
 // =====================================================================================
+// The list builder proper: one WAVEFRONT per block of `bcells` consecutive grid cells along the third grid axis
+// (~4 molecules per grid cell on ice, so a single cell is too little work to cover a wavefront's memory latencies).
+//   * The candidates of the block -- the molecules of the 9 x (bcells + 2) grid cells around it, ~240 on ice for
+//     bcells = 4 -- are loaded once (contiguous 16-byte records, cell-ordered by k_cell_scatter) and held in
+//     registers, 64 per chunk: wrapped positions relative to the block's origin in single precision, and the list
+//     entry (j, image) each would become.  The image number follows from the wrap offsets and the two molecules'
+//     cell shifts (m = wrap + floor(s_i) - floor(s_j): positions are never wrapped, G8); a candidate whose image is
+//     not in the reference's image table is dropped here, exactly as the reference never tests it.  Every molecule
+//     of a block normally has the same shift; if not, the candidates are re-staged when the shift changes.
+//   * The enumeration is ordered by slab along the third axis, so a molecule only meets the chunks that overlap
+//     the three slabs around its own cell.  For each molecule i of the block (wave-uniform) the 64 lanes test 64
+//     candidates per step in single precision against rn^2 + eps: 6 instructions per 64 tests and nothing to wait
+//     for; the ~20 hits go straight into the molecule's row in LDS as finished entries (ballot + mbcnt).
+//   * A hit whose single-precision distance lies within eps of rn^2 -- about one molecule in 2000 -- flags its row:
+//     such a row is re-decided entry by entry with the reference's own double-precision expression on the
+//     unwrapped positions, unfused (molint.F90:529-537).  eps bounds the pre-filter's rounding error (make_grid),
+//     so the list is the reference's entry for entry.
+//   * Rows are rank-sorted by (j, image), the reference's enumeration order, two per pass, and written to the
+//     molecule-major list; k_list_order derives the slot-major layout.
+// Needs >= 3 grid cells along every cell vector and bcells <= nc[2] (each (cell, wrap) pair, hence each image of a
+// molecule, is a candidate at most once).
+//   grid = (ceil(max blocks of cells / 4), boxes), block = 256 (wavefront w of workgroup x takes cell block 4x + w)
+// =====================================================================================
+constexpr int kPairChunks = 6;      // candidate chunks (of 64) held in registers per batch (more candidates: more batches)
+constexpr int kPairIB = 16;         // molecules of the cell block per block of rows (more molecules: more passes)
+constexpr int kPairRowCap = 64;     // single-precision hits kept per molecule
+constexpr int kPairMaxB = 5;        // grid cells per wavefront at most
+constexpr int kPairPieces = 9 * (kPairMaxB + 2);
+constexpr int kPairLookup = 512;    // enumeration positions with a one-read piece lookup (beyond: binary search)
+constexpr uint32_t kNoEntry = 0xffffffffu;
+
+struct PairsLds {
+    __attribute__((aligned(16))) uint32_t rows[kPairIB][kPairRowCap];   // hits as sort keys: j << 10 | image
+    float4 own[kPairIB];                         // the block's molecules (position relative to the block origin, index)
+    int ownsh[kPairIB];                          // their packed shifts
+    int ownrange[kPairIB];                       // enumeration positions each has to meet: first | last + 1 << 16
+    int cnt[kPairIB];                            // hits per molecule (bit 30: an ambiguous hit, re-decide in double precision)
+    int ncin[kPairIB];                           // hits already inside the energy cutoff (single precision: a sort key only)
+    int pstart[kPairPieces + 1], pq[kPairPieces], po[kPairPieces];   // pieces of the enumeration (one grid cell each): first position, first sorted slot, wrap offsets
+    int pk[kPairPieces];                         // image number of the piece's molecules for equal shifts (m = wrap offsets); -1: not in the table
+    float poff[kPairPieces][3];                  // origin of the piece's grid cell relative to the block's
+    unsigned char tpiece[kPairLookup];           // piece of enumeration position t (t < kPairLookup)
+};
+
+__device__ __forceinline__ int piece_of(const PairsLds& W, int t, int npieces)
+{
+    if (t < kPairLookup) return W.tpiece[t];
+    int lo = 0, hi = npieces;                    // the largest r with pstart[r] <= t (empty pieces share a start: the last one holds t)
+#pragma unroll
+    for (int it = 0; it < 6; ++it) { const int mid = (lo + hi) >> 1; if (W.pstart[mid] <= t) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256)
+void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ivect,
+                  const GridDesc* __restrict__ grid, const int* __restrict__ start,
+                  const float4* __restrict__ wpos, const int* __restrict__ wsh,
+                  uint32_t* __restrict__ listm, int* __restrict__ nn, unsigned char* __restrict__ cin,
+                  int* __restrict__ stats, int N, int S, int ivcap, int cstride, int box0, int bcells_max)
+{
+    __shared__ PairsLds lds[4];
+    const int b = box0 + blockIdx.y;
+    const GridDesc& G = grid[b];
+    if (G.nc[0] == 0) return;                                             // this box keeps the brute-force kernel
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nc0 = G.nc[0], nc1 = G.nc[1], nc2 = G.nc[2];
+    const int B = bcells_max < nc2 ? bcells_max : nc2;                    // cells per wavefront
+    const int nb2 = (nc2 + B - 1) / B;                                    // blocks along the third axis
+    const int blk = blockIdx.x * 4 + wave;
+    if (blk >= nc0 * nc1 * nb2) return;
+    PairsLds& W = lds[wave];
+    const int* ST = start + (size_t)b * (cstride + 1);
+    const float4* WP = wpos + (size_t)b * N;
+    const int* WS = wsh + (size_t)b * N;
+    const double* P = pos + (size_t)b * N * 3;
+    const double* IV = ivect + (size_t)b * ivcap * 3;
+    uint32_t* LM = listm + (size_t)b * N * kRow;
+    const int c2a = (blk % nb2) * B, c1 = (blk / nb2) % nc1, c0 = blk / (nb2 * nc1);
+    const int Bw = min(B, nc2 - c2a);                                     // this block's cells: (c0, c1, c2a .. c2a + Bw - 1)
+    const int crow = (c0 * nc1 + c1) * nc2;
+    const int qc0 = ST[crow + c2a], nmol = ST[crow + c2a + Bw] - qc0;     // its molecules: one contiguous range of sorted slots
+    if (nmol == 0) return;
+
+    // ---- the pieces of the candidate enumeration, slab by slab along the third axis: piece r = e * 9 + (d0 + 1) * 3 +
+    // (d1 + 1) is the grid cell (c0 + d0, c1 + d1, c2a - 1 + e), wrapped; lane r describes piece r ---------------------
+    const int span = Bw + 2, npieces = 9 * span;
+    int pcnt = 0;
+    if (lane < npieces) {
+        const int e = lane / 9, dd = lane % 9;
+        const int d0 = dd / 3 - 1, d1 = dd % 3 - 1, d2 = e - 1;            // d2: offset from the block's first cell
+        int n0 = c0 + d0, n1 = c1 + d1, n2 = c2a + d2, o0 = 0, o1 = 0, o2 = 0;
+        if (n0 < 0) { n0 += nc0; o0 = -1; } else if (n0 >= nc0) { n0 -= nc0; o0 = 1; }
+        if (n1 < 0) { n1 += nc1; o1 = -1; } else if (n1 >= nc1) { n1 -= nc1; o1 = 1; }
+        if (n2 < 0) { n2 += nc2; o2 = -1; } else if (n2 >= nc2) { n2 -= nc2; o2 = 1; }
+        const int ncl = (n0 * nc1 + n1) * nc2 + n2;
+        const int q0 = ST[ncl];
+        pcnt = ST[ncl + 1] - q0;
+        W.pq[lane] = q0;
+        W.po[lane] = (o0 + 1) | ((o1 + 1) << 2) | ((o2 + 1) << 4);
+        {
+            const int im0_ = G.im[0], im1_ = G.im[1], im2_ = G.im[2];            // (>= 1: the wrap offsets are always in the table)
+            const int w1_ = 2 * im1_ + 1, w2_ = 2 * im2_ + 1;
+            const int central_ = (im0_ * w1_ + im1_) * w2_ + im2_;
+            const int lin = ((o0 + im0_) * w1_ + (o1 + im1_)) * w2_ + (o2 + im2_);
+            W.pk[lane] = lin == central_ ? 0 : (lin < central_ ? lin + 1 : lin);                                    // molint.F90:197-213
+        }
+        const double f0 = (double)d0 / (double)nc0, f1 = (double)d1 / (double)nc1, f2 = (double)d2 / (double)nc2;
+        W.poff[lane][0] = (float)(f0 * G.h[0] + f1 * G.h[3] + f2 * G.h[6]);
+        W.poff[lane][1] = (float)(f0 * G.h[1] + f1 * G.h[4] + f2 * G.h[7]);
+        W.poff[lane][2] = (float)(f0 * G.h[2] + f1 * G.h[5] + f2 * G.h[8]);
+    }
+    int incl = pcnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+    if (lane < npieces) {
+        W.pstart[lane] = incl - pcnt;
+        for (int t = incl - pcnt; t < incl && t < kPairLookup; ++t) W.tpiece[t] = (unsigned char)lane;
+    }
+    if (lane == npieces - 1) W.pstart[npieces] = incl;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int T = W.pstart[npieces];
+    const float rn2_hi = (float)kRnSq + G.eps, rn2_lo = (float)kRnSq - G.eps;
+    const int im0 = G.im[0], im1 = G.im[1], im2 = G.im[2];
+    const int w1 = 2 * im1 + 1, w2 = 2 * im2 + 1;
+    const int central = (im0 * w1 + im1) * w2 + im2;
+    int wmin = 0x7fffffff, wmax = 0;                                      // row lengths seen by this wavefront
+
+    for (int ib0 = 0; ib0 < nmol; ib0 += kPairIB) {
+        const int nib = min(kPairIB, nmol - ib0);
+        // ---- the block's molecules: cell (hence slab range), position relative to the block origin, shift ----------
+        if (lane < nib) {
+            const int q = qc0 + ib0 + lane;
+            int cell = 0;                                                  // which of the block's cells holds it
+            for (int k = 1; k < Bw; ++k) cell += (ST[crow + c2a + k] <= q) ? 1 : 0;
+            const int r = (cell + 1) * 9 + 4;                              // its piece: slab cell + 1, (d0, d1) = (0, 0)
+            float4 v = WP[q];
+            v.x += W.poff[r][0]; v.y += W.poff[r][1]; v.z += W.poff[r][2];
+            W.own[lane] = v;
+            W.ownsh[lane] = WS[q];
+            W.ownrange[lane] = W.pstart[cell * 9] | (W.pstart[(cell + 3) * 9] << 16);   // slabs cell .. cell + 2 (T < 65536 checked below)
+            W.cnt[lane] = 0; W.ncin[lane] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (T > 65535) { if (lane == 0) atomicMax(&stats[2 * b + 1], 0x7ffffff0); return; }   // absurd density: reported as an overflow
+
+        for (int t0 = 0; t0 < T; t0 += kPairChunks * 64) {
+            float cx[kPairChunks], cy[kPairChunks], cz[kPairChunks];
+            uint32_t ck[kPairChunks];                                      // the entry (j << 10 | image) each candidate would become
+            // ---- a batch of candidates into registers, for molecules of shift `sh` -------------------------------
+            auto stage = [&](int sh) {
+                const int s0 = (sh & 1023) - 512, s1 = ((sh >> 10) & 1023) - 512, s2 = ((sh >> 20) & 1023) - 512;
+#pragma unroll
+                for (int ch = 0; ch < kPairChunks; ++ch) {
+                    const int t = t0 + ch * 64 + lane;
+                    cx[ch] = 3.0e18f; cy[ch] = 3.0e18f; cz[ch] = 3.0e18f; ck[ch] = kNoEntry;   // no candidate: never within range
+                    if (t0 + ch * 64 < T && t < T) {
+                        const int r = piece_of(W, t, npieces);
+                        const int q = W.pq[r] + (t - W.pstart[r]);
+                        const float4 v = WP[q];
+                        const int shj = WS[q];
+                        int k = W.pk[r];                                                         // same shift (the rule): the piece's image
+                        if (__builtin_amdgcn_ballot_w64(shj != sh) != 0ull) {                    // wave-uniform
+                            if (shj != sh) {
+                                const int po = W.po[r];
+                                const int m0 = ((po & 3) - 1) + s0 - ((shj & 1023) - 512);
+                                const int m1 = (((po >> 2) & 3) - 1) + s1 - (((shj >> 10) & 1023) - 512);
+                                const int m2 = (((po >> 4) & 3) - 1) + s2 - (((shj >> 20) & 1023) - 512);
+                                k = -1;
+                                if (!(m0 < -im0 || m0 > im0 || m1 < -im1 || m1 > im1 || m2 < -im2 || m2 > im2)) {   // in the image table
+                                    const int lin = ((m0 + im0) * w1 + (m1 + im1)) * w2 + (m2 + im2);
+                                    k = lin == central ? 0 : (lin < central ? lin + 1 : lin);                        // molint.F90:197-213
+                                }
+                            }
+                        }
+                        if (k >= 0) {
+                            cx[ch] = v.x + W.poff[r][0]; cy[ch] = v.y + W.poff[r][1]; cz[ch] = v.z + W.poff[r][2];
+                            ck[ch] = ((uint32_t)__builtin_bit_cast(int, v.w) << 10) | (uint32_t)k;
+                        }
+                    }
+                }
+            };
+            int shcur = 0;
+            // ---- every molecule of the block against the batch -------------------------------------------------
+            for (int il = 0; il < nib; ++il) {
+                const int shi = __builtin_amdgcn_readfirstlane(W.ownsh[il]);
+                if (il == 0 || shi != shcur) { shcur = shi; stage(shcur); }   // (again only for a molecule that left the box unwrapped)
+                const float4 o = W.own[il];
+                const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.x)));
+                const float yi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.y)));
+                const float zi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.z)));
+                const int rg = __builtin_amdgcn_readfirstlane(W.ownrange[il]);
+                const int ta = rg & 0xffff, tb = rg >> 16;
+                int cnt = __builtin_amdgcn_readfirstlane(W.cnt[il]);
+                int ninner = 0;
+                unsigned long long amb = 0ull;
+#pragma unroll
+                for (int ch = 0; ch < kPairChunks; ++ch) {
+                    const int tc = t0 + ch * 64;
+                    if (tc < tb && tc + 64 > ta) {                                     // wave-uniform: the chunk overlaps the molecule's slabs
+                        const float dx = cx[ch] - xi, dy = cy[ch] - yi, dz = cz[ch] - zi;
+                        const float r2 = dx * dx + dy * dy + dz * dz;
+                        // (one compare per ballot: the molecule itself, r2 = 0, is let in here and dropped when its row is sorted)
+                        const bool hit = r2 < rn2_hi;
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);         // (no branch on it: most chunks hold a hit)
+                        const int p = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                        if (hit && p < kPairRowCap) W.rows[il][p] = ck[ch];
+                        cnt += __popcll(m);
+                        amb |= m & __builtin_amdgcn_ballot_w64(r2 > rn2_lo);
+                        ninner += __popcll(__builtin_amdgcn_ballot_w64(r2 < (float)kRcSq));
+                    }
+                }
+                if (lane == 0) {
+                    W.cnt[il] = (cnt & 0x3fffffff) | (amb != 0ull ? 0x40000000 : (W.cnt[il] & 0x40000000));
+                    W.ncin[il] += ninner;                                  // (counts the molecule itself once: taken off below)
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- sort the rows and write them: LPR lanes per row (two rows per pass unless a row is long) ----------------
+        int longest = lane < nib ? (W.cnt[lane] & 0x3fffffff) : 0;
+        longest = __builtin_amdgcn_readfirstlane(wave_max_i(longest));
+        const int lpr = longest > 32 ? 64 : 32, rpp = 64 / lpr;                       // lanes per row, rows per pass
+        for (int r0 = 0; r0 < nib; r0 += rpp) {
+            const int sub = lane / lpr, sl = lane - sub * lpr;
+            const int il = r0 + sub;
+            const bool rowok = il < nib;
+            const int craw = rowok ? W.cnt[il] : 0;
+            const int nraw = craw & 0x3fffffff;
+            const int nrow = nraw < kPairRowCap ? nraw : kPairRowCap;
+            const bool active = sl < nrow;
+            uint32_t key = active ? W.rows[il][sl] : kNoEntry;
+            int i = 0;
+            if (rowok) i = __builtin_bit_cast(int, W.own[il].w);
+            if (key == ((uint32_t)i << 10)) key = kNoEntry;                   // (i, central image) is not an entry (molint.F90:532)
+            if (__builtin_amdgcn_ballot_w64((craw & 0x40000000) != 0) != 0ull) {
+                // a row with a hit too close to call in single precision: every entry of it by the reference's
+                // expression, unfused (:529-537); what fails goes (about one row in 2000)
+                if (active && key != kNoEntry && (craw & 0x40000000)) {
+#pragma clang fp contract(off)
+                    const int j = (int)(key >> 10), k = (int)(key & 1023u);
+                    const double vx = P[3 * j] - P[3 * i], vy = P[3 * j + 1] - P[3 * i + 1], vz = P[3 * j + 2] - P[3 * i + 2];
+                    const double tx = vx + IV[3 * k], ty = vy + IV[3 * k + 1], tz = vz + IV[3 * k + 2];
+                    const double r2 = tx * tx + ty * ty + tz * tz;
+                    if (!(r2 < kRnSq)) key = kNoEntry;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (rowok) W.rows[il][sl] = key;                                   // the rank loop reads the rows from LDS: dropped entries and the
+                                                                               // lanes past the row's end as kNoEntry (never smaller than a key)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bool valid = key != kNoEntry;
+            const int nloop = __builtin_amdgcn_readfirstlane(wave_max_i(nrow));
+            int rank = 0;                                                     // keys are unique; dropped ones sort last
+            const uint4* k4 = reinterpret_cast<const uint4*>(&W.rows[rowok ? il : 0][0]);
+            for (int e = 0; e < nloop; e += 4) {
+                const uint4 kk = k4[e >> 2];
+                rank += (kk.x < key ? 1 : 0) + (kk.y < key ? 1 : 0) + (kk.z < key ? 1 : 0) + (kk.w < key ? 1 : 0);
+            }
+            const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid), bm = __builtin_amdgcn_ballot_w64(valid && (key & 1023u) != 0u);
+            const unsigned long long rowmask = lpr == 64 ? ~0ull : (0xffffffffull << (32 * sub));
+            const int nvalid = __popcll(vm & rowmask), nbnd = __popcll(bm & rowmask);
+            const int ncin = rowok ? max(W.ncin[il] - 1, 0) : 0;
+            if (valid && rank < S) LM[(size_t)i * kRow + rank] = pack_entry((int)(key >> 10), (int)(key & 1023u));
+            if (rowok && sl == 0) {
+                const int total = nraw > kPairRowCap ? nraw : nvalid;        // more single-precision hits than a row holds: reported as an overflow
+                nn[(size_t)b * N + i] = nvalid < S ? nvalid : S;
+                cin[(size_t)b * N + i] = (unsigned char)((ncin < 127 ? ncin : 127) | (nbnd ? 0x80 : 0));
+                wmin = total < wmin ? total : wmin;
+                wmax = total > wmax ? total : wmax;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                      // rows are reused by the next block of molecules
+    }
+    wmin = wave_min_i(wmin); wmax = wave_max_i(wmax);
+    if (lane == 0) { atomicMin(&stats[2 * b], wmin); atomicMax(&stats[2 * b + 1], wmax); }
+}
+
+// =====================================================================================
 // Sorted slot-major copy of the list for the full-box kernel (one molecule per lane): the molecules of a box
 // are ordered by (neighbours inside the energy cutoff at build time, interior / boundary, row length), so that
 // the 64 lanes of a wavefront run the same number of cheap distance tests and the same number of expensive pair
@@ -313,16 +612,19 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
     if (kbits < 0) {
         for (int i = i0 + tid; i < i1; i += 1024) { ORD[i] = i; NNS[i] = min(NN[i], S); }
     } else {
+        // hist[group][key]: the lanes of a wavefront share the group and differ in key, i.e. in LDS bank (the scan below
+        // walks it in (key, group) order: element e is key e / ngroups, group e % ngroups)
         const int K = 1 << kbits, M = K * ngroups;
+        auto hslot = [&](int key, int grp) { return grp * K + key; };
         for (int e = tid; e < M; e += 1024) hist[e] = 0;
         __syncthreads();
-        for (int i = i0 + tid; i < i1; i += 1024) atomicAdd(&hist[keyof(i, NN[i]) * ngroups + ((i - i0) >> 6)], 1);
+        for (int i = i0 + tid; i < i1; i += 1024) atomicAdd(&hist[hslot(keyof(i, NN[i]), (i - i0) >> 6)], 1);
         __syncthreads();
         // exclusive scan of hist[0..M): `per` consecutive elements per thread
         const int per = (M + 1023) / 1024;
         const int e0 = min(M, tid * per), e1 = min(M, e0 + per);
         int local = 0;
-        for (int e = e0; e < e1; ++e) local += hist[e];
+        for (int e = e0; e < e1; ++e) local += hist[hslot(e / ngroups, e % ngroups)];
         int incl = local;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
@@ -330,7 +632,7 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
         __syncthreads();
         int run = incl - local;
         for (int w = 0; w < wid; ++w) run += wsum[w];
-        for (int e = e0; e < e1; ++e) { const int v = hist[e]; hist[e] = run; run += v; }
+        for (int e = e0; e < e1; ++e) { const int sl = hslot(e / ngroups, e % ngroups), v = hist[sl]; hist[sl] = run; run += v; }
         __syncthreads();
         for (int base = i0; base < i1; base += 1024) {
             const int i = base + tid;
@@ -344,7 +646,7 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
             }
             const int rank = __popcll(same & ((1ull << lane) - 1ull));
             if (valid) {
-                const int dst = i0 + hist[key * ngroups + ((i - i0) >> 6)] + rank;
+                const int dst = i0 + hist[hslot(key, (i - i0) >> 6)] + rank;
                 ORD[dst] = i; NNS[dst] = min(n, S);
             }
         }
@@ -361,7 +663,26 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
         const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i(n));
         const uint4* row = reinterpret_cast<const uint4*>(LM + (size_t)i * kRow);
         int w = 0;                                            // next slot of the column
+        // rows of up to 32 entries (the usual case) are fetched whole before anything is stored: eight independent
+        // 16-byte loads in flight instead of a load -> store chain per four entries
+        const bool fastrow = nmax <= 32;
+        uint4 rv[8];
+        if (fastrow) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rv[u] = (4 * u < n) ? row[u] : make_uint4(0u, 0u, 0u, 0u);
+        }
         for (int pass = 0; pass < 2; ++pass) {
+            if (fastrow) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (4 * u < nmax) {
+                        const uint32_t e[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            if (4 * u + v < n && ((e[v] >> kJBits) == 0u) == (pass == 0)) { L[(size_t)w * N + t] = e[v]; ++w; }
+                    }
+                }
+            } else
             for (int s4 = 0; s4 < nmax; s4 += 4) {
                 if (s4 < n) {
                     const uint4 v = row[s4 >> 2];
