@@ -13,7 +13,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -24,8 +26,15 @@ thread_local std::string g_err;
 // Every entry point takes this lock: the engine is one context per process, calls from several host threads (the
 // reference's dormant OpenMP would evaluate both lattices concurrently, mc_moves.F90:1006-1018) are serialised.
 std::recursive_mutex g_mu;
+// The single local-energy call (the drop-in compute_local_real_energy) does not take g_mu: it holds g_gate shared and
+// its lattice's mail slot, so two host threads can evaluate the two lattices of a move at the same time
+// (mc_moves.F90:1006-1018).  Every other entry point holds g_gate exclusively (outermost level only:
+// entry points call each other) and first stops the resident server those calls talk to.
+std::shared_mutex g_gate;
+int g_depth = 0;                        // nesting of exclusive entry points on the thread that holds g_mu
 struct DeviceGuard;
-#define MW_LOCK std::lock_guard<std::recursive_mutex> mw_lock_(g_mu); DeviceGuard mw_dev_
+struct ExclusiveGuard;
+#define MW_LOCK ExclusiveGuard mw_lock_; DeviceGuard mw_dev_
 
 int fail(const char* fmt, ...)
 {
@@ -118,6 +127,13 @@ struct Ctx {
     double* h_pin = nullptr;
     double* d_pin = nullptr;
     unsigned long long pin_seq = 0;   // completion word of the single-call kernel (h_pin + 8 doubles)
+    // resident server of the single local-energy call (k_local_server): mail slots in host-mapped memory
+    hipStream_t sstream = nullptr;
+    mw::MailHead* h_head = nullptr;  mw::MailHead* d_head = nullptr;
+    mw::MailSlot* h_slots = nullptr; mw::MailSlot* d_slots = nullptr;
+    int nslots = 0;
+    bool srv_running = false, srv_enabled = true;
+    unsigned long long sseq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // host mirrors
     std::vector<double> h_ivect;   // nbox * ivcap * 3
     std::vector<int> h_nivect;     // nbox
@@ -125,6 +141,23 @@ struct Ctx {
 };
 
 Ctx g;
+std::mutex g_slot_mu[8];                // one per mail slot
+std::mutex g_srv_mu;                    // start / stop of the server
+
+int server_stop();                      // defined below (needs the context)
+
+struct ExclusiveGuard {
+    ExclusiveGuard()
+    {
+        g_mu.lock();
+        if (g_depth++ == 0) { g_gate.lock(); if (g.srv_running) (void)server_stop(); }
+    }
+    ~ExclusiveGuard()
+    {
+        if (--g_depth == 0) g_gate.unlock();
+        g_mu.unlock();
+    }
+};
 
 // The current HIP device is per host thread: an entry point called from a thread other than the one that ran
 // mw_init (the reference's OpenMP sections, a Python worker thread) would otherwise allocate and launch on
@@ -151,7 +184,7 @@ constexpr size_t kMoveScratch = 16 * sizeof(mw::WaveScratch);
 constexpr size_t kMoveStage = (size_t)mw::kMoveChunk * sizeof(int);   // the molecules of an item's requests in LDS (at most)
 bool lds_fits_move(int N, int ivcap)
 {
-    return kMoveScratch + (size_t)(3 * (size_t)N + 3 * (size_t)ivcap) * sizeof(double) + (((size_t)N + 7) & ~(size_t)7) + kMoveStage <= (size_t)kLdsBudget;
+    return kMoveScratch + mw::lds_vec_bytes((size_t)N) + mw::lds_vec_bytes((size_t)ivcap) + (((size_t)N + 7) & ~(size_t)7) + kMoveStage <= (size_t)kLdsBudget;
 }
 
 int check_live() { return g.live ? 0 : fail("mw: engine not initialised (call mw_init / energy_init first)"); }
@@ -408,7 +441,11 @@ int finish_build(int first, int count, int* min_nn, int* max_nn)
 // Free everything the context holds (any subset may be allocated: mw_init's failure path comes here too).
 void release_all()
 {
+    if (g.srv_running) (void)server_stop();
     if (g.stream) { (void)hipSetDevice(g.device); (void)hipStreamSynchronize(g.stream); }
+    if (g.sstream) { (void)hipStreamSynchronize(g.sstream); (void)hipStreamDestroy(g.sstream); }
+    if (g.h_head) (void)hipHostFree(g.h_head);
+    if (g.h_slots) (void)hipHostFree(g.h_slots);
     void* ptrs[] = {g.d_hmat, g.d_sw_mubin, g.d_sw_binwidth, g.d_wweight, g.d_whist, g.d_wuhist, g.d_wls, g.d_wmu, g.d_wacc,
                     g.d_wswitch, g.d_wshift, g.d_wvol, g.d_wflag, g.d_volume, g.d_swlog, g.d_tabscratch, g.d_pos, g.d_ivect,
                     g.d_nivect, g.d_list, g.d_listm, g.d_nn, g.d_stats, g.d_order, g.d_nns, g.d_cmax, g.d_cin, g.d_grid,
@@ -560,6 +597,18 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
     HIPCHK(hipHostMalloc(&g.h_pin, 4096, hipHostMallocMapped));
     std::memset(g.h_pin, 0, 4096);
     HIPCHK(hipHostGetDevicePointer((void**)&g.d_pin, g.h_pin, 0));
+    {   // mail slots of the resident local-energy server: one per lattice, at most 8
+        g.nslots = std::min(nboxes, 8);
+        HIPCHK(hipStreamCreateWithFlags(&g.sstream, hipStreamNonBlocking));
+        HIPCHK(hipHostMalloc((void**)&g.h_head, sizeof(mw::MailHead), hipHostMallocMapped));
+        HIPCHK(hipHostMalloc((void**)&g.h_slots, sizeof(mw::MailSlot) * 8, hipHostMallocMapped));
+        std::memset(g.h_head, 0, sizeof(mw::MailHead));
+        std::memset(g.h_slots, 0, sizeof(mw::MailSlot) * 8);
+        HIPCHK(hipHostGetDevicePointer((void**)&g.d_head, g.h_head, 0));
+        HIPCHK(hipHostGetDevicePointer((void**)&g.d_slots, g.h_slots, 0));
+        const char* ev = std::getenv("MW_LOCAL_SERVER");
+        g.srv_enabled = !(ev && *ev == '0');
+    }
     g.h_ivect.assign(nb * g.ivcap * 3, 0.0);
     g.h_nivect.assign(nb, 0);
     // the LDS-staged kernel asks for more than the default 64 KiB of dynamic LDS
@@ -807,26 +856,116 @@ int mw_model_energy_counts(int ils, long long* npairs, long long* ntriplets)
     return 0;
 }
 
+// Launch the resident server if it is not running (g_srv_mu held by the caller).
+static int server_start_locked()
+{
+    if (g.srv_running) return 0;
+    int prev = -1;
+    const bool sw = hipGetDevice(&prev) == hipSuccess && prev != g.device && hipSetDevice(g.device) == hipSuccess;
+    g.h_head->quit = 0; g.h_head->exited = 0;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    // a few tenths of a second of empty polls (one poll is a PCIe round trip, ~1 us) and the server leaves by itself
+    static const bool stamps = std::getenv("MW_SERVER_STAMPS") != nullptr;
+    static const bool plain = std::getenv("MW_SERVER_PLAIN_LOADS") != nullptr;      // experiment only: L1-cached position loads
+    if (plain)
+        hipLaunchKernelGGL(mw::k_local_server<false>, dim3(1), dim3(64 * g.nslots), 0, g.sstream, g.d_head, g.d_slots, g.d_pos, g.d_ivect,
+                           g.d_nivect, g.d_listm, g.d_nn, g.N, g.ivcap, 300000LL, stamps ? 1 : 0);
+    else
+        hipLaunchKernelGGL(mw::k_local_server<true>, dim3(1), dim3(64 * g.nslots), 0, g.sstream, g.d_head, g.d_slots, g.d_pos, g.d_ivect,
+                           g.d_nivect, g.d_listm, g.d_nn, g.N, g.ivcap, 300000LL, stamps ? 1 : 0);
+    const hipError_t err = hipGetLastError();
+    if (sw) (void)hipSetDevice(prev);
+    if (err != hipSuccess) return fail("mw: launching the local-energy server failed: %s", hipGetErrorString(err));
+    g.srv_running = true;
+    return 0;
+}
+
+namespace {
+// Stop the server and wait for it (called with g_gate held exclusively: no request is in flight).
+int server_stop()
+{
+    std::lock_guard<std::mutex> lk(g_srv_mu);
+    if (!g.srv_running) return 0;
+    reinterpret_cast<volatile int*>(&g.h_head->quit)[0] = 1;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    int prev = -1;
+    const bool sw = hipGetDevice(&prev) == hipSuccess && prev != g.device && hipSetDevice(g.device) == hipSuccess;
+    const hipError_t err = hipStreamSynchronize(g.sstream);
+    if (sw) (void)hipSetDevice(prev);
+    g.srv_running = false;
+    if (err != hipSuccess) return fail("mw: the local-energy server ended with %s", hipGetErrorString(err));
+    return 0;
+}
+}  // namespace
+
+// One request through the resident server: g_gate shared (no exclusive entry point is running) + the slot's mutex.
+static int local_energy_served(int ils, int imol, const mw::Override& o1, const mw::Override& o2, double* e)
+{
+    std::shared_lock<std::shared_mutex> gate(g_gate);
+    if (!g.live) return fail("mw: engine not initialised (call mw_init / energy_init first)");
+    if (ils < 1 || ils > g.nbox) return fail("mw: box index %d outside 1..%d", ils, g.nbox);
+    if (imol < 1 || imol > g.N) return fail("mw: molecule index %d outside 1..%d", imol, g.N);
+    const int sl = (ils - 1) % g.nslots;
+    std::lock_guard<std::mutex> slk(g_slot_mu[sl]);
+    { std::lock_guard<std::mutex> lk(g_srv_mu); if (server_start_locked()) return 1; }
+    volatile mw::MailSlot* m = g.h_slots + sl;
+    m->box = ils - 1; m->imol = imol - 1;
+    m->flags = 1 | (o1.idx >= 0 ? 2 : 0) | (o2.idx >= 0 ? 4 : 0);
+    m->prev = o2.idx >= 0 ? o2.idx : 0;
+    m->x1 = o1.x; m->y1 = o1.y; m->z1 = o1.z;
+    m->x2 = o2.x; m->y2 = o2.y; m->z2 = o2.z;
+    const unsigned long long seq = ++g.sseq[sl];
+    std::atomic_thread_fence(std::memory_order_release);
+    m->seq_a = seq;                     // (x86 stores become visible in program order: fields, seq_a, seq_b)
+    std::atomic_thread_fence(std::memory_order_release);
+    m->seq_b = seq;
+    for (long spin = 1;; ++spin) {
+        if (m->rep_seq == seq) break;
+        __builtin_ia32_pause();
+        if ((spin & 0xfffff) == 0) {                          // every ~million polls: is the server still there?
+            std::lock_guard<std::mutex> lk(g_srv_mu);
+            if (reinterpret_cast<volatile int*>(&g.h_head->exited)[0] != 0) {
+                // it left (idle limit, racing with this request) -- or it faulted: the stream tells
+                int prev = -1;
+                const bool sw = hipGetDevice(&prev) == hipSuccess && prev != g.device && hipSetDevice(g.device) == hipSuccess;
+                const hipError_t err = hipStreamSynchronize(g.sstream);
+                if (sw) (void)hipSetDevice(prev);
+                g.srv_running = false;
+                if (err != hipSuccess) return fail("mw: the local-energy server ended with %s", hipGetErrorString(err));
+                if (m->rep_seq == seq) break;
+                if (server_start_locked()) return 1;          // it picks the pending request up: rep_seq != req_seq
+            }
+            if (spin > (1L << 34)) return fail("mw: no reply from the local-energy server");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    *e = m->energy;
+    return 0;
+}
+
 int mw_local_energy_patched(int ils, int imol, const double r_imol[3], int imol_prev, const double r_prev[3], double* e)
 {
-    MW_LOCK;
-    if (check_live() || check_box(ils) || check_mol(imol)) return 1;
     mw::Override o1, o2;
     o1.idx = -1; o1.x = o1.y = o1.z = 0.0;
     o2 = o1;
     if (r_imol) { o1.idx = imol - 1; o1.x = r_imol[0]; o1.y = r_imol[1]; o1.z = r_imol[2]; }
     if (r_prev && imol_prev >= 1 && imol_prev != imol) {
-        if (check_mol(imol_prev)) return 1;
+        if (g.live && (imol_prev < 1 || imol_prev > g.N)) return fail("mw: molecule index %d outside 1..%d", imol_prev, g.N);
         o2.idx = imol_prev - 1; o2.x = r_prev[0]; o2.y = r_prev[1]; o2.z = r_prev[2];
     }
+    if (g.srv_enabled) return local_energy_served(ils, imol, o1, o2, e);
+
+    // MW_LOCAL_SERVER=0: one launch per call (the path the server replaces; kept as its cross-check)
+    MW_LOCK;
+    if (check_live() || check_box(ils) || check_mol(imol)) return 1;
     const unsigned long long seq = ++g.pin_seq;
     hipLaunchKernelGGL(mw::k_local_energy_single, dim3(1), dim3(64), 0, g.stream, g.d_pos, g.d_ivect, g.d_listm, g.d_nn,
                        ils - 1, imol - 1, o1, o2, 1, g.d_pin, g.N, g.ivcap,
                        reinterpret_cast<unsigned long long*>(g.d_pin + 8), seq);
     HIPCHK(hipGetLastError());
     // The kernel is the only thing in flight on this stream: wait for its completion word in host-visible memory
-    // (a few microseconds less than a stream synchronisation on every call of the drop-in path); if it does not
-    // show up within about a second, fall back to the synchronisation, which also reports a fault.
+    // (a few microseconds less than a stream synchronisation); if it does not show up within about a second, fall
+    // back to the synchronisation, which also reports a fault.
     volatile unsigned long long* done = reinterpret_cast<volatile unsigned long long*>(g.h_pin + 8);
     bool seen = false;
     for (long spin = 0; spin < 200000000L; ++spin) {
@@ -928,10 +1067,10 @@ int mw_moves_upload(int n, const int* ils, const int* imol, const double* trial_
 static int launch_moves(int mode)
 {
     if (g.mn == 0) return 0;
-    const size_t iv_bytes = kMoveScratch + (size_t)3 * g.ivcap * sizeof(double);
+    const size_t iv_bytes = kMoveScratch + mw::lds_vec_bytes((size_t)g.ivcap);
     if (g.mlds)
         hipLaunchKernelGGL(mw::k_move_energy<true>, dim3(g.mwork_n), dim3(1024),
-                           iv_bytes + (size_t)3 * g.N * sizeof(double) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
+                           iv_bytes + mw::lds_vec_bytes((size_t)g.N) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
                            g.d_meold, g.d_menew, g.d_mcnt, g.N, g.ivcap, mode);
     else

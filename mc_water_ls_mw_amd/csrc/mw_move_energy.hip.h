@@ -29,11 +29,20 @@ namespace mw {
 // =====================================================================================
 struct Override { int idx; double x, y, z; };   // idx < 0: none (0-based molecule index)
 
+// COHERENT = true (the resident server below): positions are read past the CU's vector L1 (agent scope, served by
+// L2), because the server itself rewrites single positions between requests while its wavefront lives on.
+template <bool COHERENT = false>
 __device__ __forceinline__ void load_pos(const double* __restrict__ P, int j, const Override& o1, const Override& o2,
                                          double& x, double& y, double& z)
 {
     const double* p = P + 3 * (size_t)j;
-    x = p[0]; y = p[1]; z = p[2];
+    if constexpr (COHERENT) {
+        x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        z = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        x = p[0]; y = p[1]; z = p[2];
+    }
     if (j == o1.idx) { x = o1.x; y = o1.y; z = o1.z; }
     if (j == o2.idx) { x = o2.x; y = o2.y; z = o2.z; }
 }
@@ -42,13 +51,14 @@ __device__ __forceinline__ void load_pos(const double* __restrict__ P, int j, co
 // of in-range interactions as the reference enumerates them (pairs + triplet slots with
 // cos(theta) < 0.99) and the number of list slots visited (n_i + sum of n_j over in-range j),
 // which prices the call's algorithmic bytes.
+template <bool COHERENT = false>
 __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P, const double* __restrict__ IV,
                                                     const uint32_t* __restrict__ LM, const int* __restrict__ NN,
                                                     int i, const Override& o1, const Override& o2, int lane,
                                                     unsigned int& ninter, unsigned int& nslots)
 {
     double xi, yi, zi;
-    load_pos(P, i, o1, o2, xi, yi, zi);                                   // molint.F90:258
+    load_pos<COHERENT>(P, i, o1, o2, xi, yi, zi);                         // molint.F90:258
     const int n_i = NN[i];
 
     // pass 0: imol's own list, one slot per lane
@@ -56,7 +66,7 @@ __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P
     const uint32_t e = has ? LM[(size_t)i * kRow + lane] : 0u;
     const int j = (int)(e & kJMask), kimg = (int)(e >> kJBits);
     double xj, yj, zj;
-    load_pos(P, j, o1, o2, xj, yj, zj);
+    load_pos<COHERENT>(P, j, o1, o2, xj, yj, zj);
     const double jvx = IV[3 * kimg], jvy = IV[3 * kimg + 1], jvz = IV[3 * kimg + 2];
     const double qx = xj + jvx, qy = yj + jvy, qz = zj + jvz;             // :269 position of j's image
     const double dx = qx - xi, dy = qy - yi, dz = qz - zi;                // :272
@@ -94,7 +104,7 @@ __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P
             const uint32_t e2 = LM[(size_t)jj * kRow + lane];
             const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
             double xk, yk, zk;
-            load_pos(P, kk, o1, o2, xk, yk, zk);
+            load_pos<COHERENT>(P, kk, o1, o2, xk, yk, zk);
             const double bx = ((xk + IV[3 * k2]) + sjx) - pjx;            // :332,334
             const double by = ((yk + IV[3 * k2 + 1]) + sjy) - pjy;
             const double bz = ((zk + IV[3 * k2 + 2]) + sjz) - pjz;
@@ -104,6 +114,97 @@ __device__ __forceinline__ double local_energy_wave(const double* __restrict__ P
                 pair_terms(s2, rinv_k, e1_k, g_k);
                 const double ct = (-(ajx * bx + ajy * by + ajz * bz) * rinv_j) * rinv_k;   // :320,341,365
                 if (ct < 0.99) { const double d = ct - kCos0; acc3 += g_j * (g_k * (d * d)); ++ntl; }
+            }
+        }
+    }
+    const double tot = readlane_f64(dpp_wave_sum(acc2 + kLamEps * acc3), 63);                       // :397
+    ninter += (unsigned int)__builtin_amdgcn_readlane(dpp_wave_sum_i32((int)ntl), 63);
+    return tot;
+}
+
+// The same evaluation laid out for LATENCY (the resident server of the drop-in single call): the rows and third-body
+// positions of up to eight in-range neighbours are requested together, so the whole call is four dependent memory
+// round trips (row of imol -> positions of its entries -> rows of the in-range j -> positions of their entries)
+// instead of three per in-range neighbour.  Same terms, same per-term arithmetic as local_energy_wave.
+template <bool COHERENT>
+__device__ __forceinline__ double local_energy_wave_batched(const double* __restrict__ P, const double* __restrict__ IV,
+                                                            const uint32_t* __restrict__ LM, const int* __restrict__ NN,
+                                                            int i, const Override& o1, const Override& o2, int lane,
+                                                            unsigned int& ninter, unsigned int& nslots)
+{
+    constexpr int B = 8;
+    double xi, yi, zi;
+    load_pos<COHERENT>(P, i, o1, o2, xi, yi, zi);                         // molint.F90:258
+    const int n_i = NN[i];
+    const uint32_t e = LM[(size_t)i * kRow + lane];                       // rows are 64 entries long in memory: no need to wait for n_i
+    const bool has = lane < n_i;
+    const int j = has ? (int)(e & kJMask) : 0, kimg = has ? (int)(e >> kJBits) : 0;
+    double xj, yj, zj;
+    load_pos<COHERENT>(P, j, o1, o2, xj, yj, zj);
+    const double jvx = IV[3 * kimg], jvy = IV[3 * kimg + 1], jvz = IV[3 * kimg + 2];
+    const double qx = xj + jvx, qy = yj + jvy, qz = zj + jvz;             // :269
+    const double dx = qx - xi, dy = qy - yi, dz = qz - zi;                // :272
+    const double r2 = dx * dx + dy * dy + dz * dz;                        // :273
+    const bool inr = has && (r2 < kRcSq);                                 // :276
+    double rinv = 0.0, e1 = 0.0, g = 0.0;
+    if (inr) pair_terms(r2, rinv, e1, g);
+    const double q = kSigSq * rinv * rinv;
+    double acc2 = inr ? (kAeps * (kBigB * (q * q) - 1.0)) * e1 : 0.0;     // :294-297
+    double acc3 = 0.0;
+    unsigned int ntl = 0;
+
+    unsigned long long mask = __ballot(inr);
+    ninter = (unsigned int)__popcll(mask);
+    nslots = (unsigned int)n_i;
+    while (mask) {                                                        // wave-uniform: batches of B in-range j
+        // straight-line code, no branches between the loads: a batch shorter than B repeats its last neighbour
+        // (harmless duplicate loads) so that every load of a stage is in flight before the first one is waited for
+        int jls[B], jjs[B], njs[B];
+        uint32_t e2s[B];
+        const int left = __popcll(mask);
+        const int cb = left < B ? left : B;
+        int jlast = 0;
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+            const int jl = mask ? __ffsll((long long)mask) - 1 : jlast;
+            mask = mask ? (mask & (mask - 1ull)) : 0ull;
+            jls[r] = jl; jlast = jl;
+            jjs[r] = __builtin_amdgcn_readlane(j, jl);
+        }
+#pragma unroll
+        for (int r = 0; r < B; ++r) { njs[r] = NN[jjs[r]]; e2s[r] = LM[(size_t)jjs[r] * kRow + lane]; }
+        double xk[B], yk[B], zk[B], kx[B], ky[B], kz[B];
+#pragma unroll
+        for (int r = 0; r < B; ++r) {                                     // (stale slots past a row's end hold valid old entries)
+            const int kk = (int)(e2s[r] & kJMask), k2 = (int)(e2s[r] >> kJBits);
+            load_pos<COHERENT>(P, kk, o1, o2, xk[r], yk[r], zk[r]);
+            kx[r] = IV[3 * k2]; ky[r] = IV[3 * k2 + 1]; kz[r] = IV[3 * k2 + 2];
+        }
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+            if (r < cb) {
+                const int jl = jls[r];
+                const double ajx = readlane_f64(dx, jl), ajy = readlane_f64(dy, jl), ajz = readlane_f64(dz, jl);
+                const double rinv_j = readlane_f64(rinv, jl), g_j = readlane_f64(g, jl);
+                if (inr && lane > jl) {                                               // j--i--k  :302-318
+                    const double ct = ((ajx * dx + ajy * dy + ajz * dz) * rinv_j) * rinv;
+                    if (ct < 0.99) { const double d = ct - kCos0; acc3 += g_j * (g * (d * d)); ++ntl; }
+                }
+                const double sjx = readlane_f64(jvx, jl), sjy = readlane_f64(jvy, jl), sjz = readlane_f64(jvz, jl);
+                const double pjx = readlane_f64(qx, jl), pjy = readlane_f64(qy, jl), pjz = readlane_f64(qz, jl);
+                nslots += (unsigned int)njs[r];
+                if (lane < njs[r]) {                                                  // i--j--k  :324-343
+                    const double bx = ((xk[r] + kx[r]) + sjx) - pjx;
+                    const double by = ((yk[r] + ky[r]) + sjy) - pjy;
+                    const double bz = ((zk[r] + kz[r]) + sjz) - pjz;
+                    const double s2 = bx * bx + by * by + bz * bz;
+                    if (s2 < kRcSq) {
+                        double rinv_k, e1_k, g_k;
+                        pair_terms(s2, rinv_k, e1_k, g_k);
+                        const double ct = (-(ajx * bx + ajy * by + ajz * bz) * rinv_j) * rinv_k;
+                        if (ct < 0.99) { const double d = ct - kCos0; acc3 += g_j * (g_k * (d * d)); ++ntl; }
+                    }
+                }
             }
         }
     }
@@ -145,7 +246,7 @@ struct WaveScratch {
     uint32_t qe[64];                           // queue of in-range third bodies: packed list entry ...
     int qown[64];                              // ... and rank | (image, inverse image, flags of that rank) << 5 of the j whose row it came from
 };
-static_assert(sizeof(WaveScratch) % 8 == 0, "scratch records must keep 8-byte alignment");
+static_assert(sizeof(WaveScratch) % 16 == 0, "scratch records must keep 16-byte alignment");
 
 // Returns false (nothing written) when the request needs the plain routine.
 // `row(j, s)` returns list entry s of molecule j and `nnof(j)` its row length: global memory (molecule-major
@@ -398,7 +499,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
 //   mode bit 0: write e_old (mirrored positions), bit 1: write e_new (trial position)
 constexpr int kMoveChunk = 2048;   // requests per work item when the box is staged in LDS
 
-template <bool LDSPOS>
+template <bool LDSPOS, int LAYOUT = kLayoutPair>
 __global__ __launch_bounds__(1024)
 void k_move_energy(const double* __restrict__ pos, const double* __restrict__ ivect,
                    const int* __restrict__ nivect, const uint32_t* __restrict__ listm,
@@ -420,28 +521,29 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
     const int niv = nivect[b];
 
     // dynamic LDS: [positions when LDSPOS][image vectors][16 wave scratches] and, when LDSPOS, [row lengths, one
-    // byte per molecule][the molecules of the item's requests] (positions at offset 0: a gather's
-    // address is one multiply and the ds_read offsets are immediates)
+    // byte per molecule][the molecules of the item's requests]; positions and image vectors in the layout LAYOUT
+    // (LdsVecs, mw_common.hip.h: the paired layout gathers a vector in 6 LDS cycles instead of 10)
     double* spos = smem;
-    double* siv = smem + (LDSPOS ? 3 * (size_t)N : 0);
-    WaveScratch* ws = reinterpret_cast<WaveScratch*>(siv + (size_t)ivcap * 3) + wave;
-    unsigned char* snn = reinterpret_cast<unsigned char*>(reinterpret_cast<WaveScratch*>(siv + (size_t)ivcap * 3) + 16);
+    double* siv = smem + (LDSPOS ? lds_vec_bytes((size_t)N) / 8 : 0);
+    WaveScratch* ws = reinterpret_cast<WaveScratch*>(siv + lds_vec_bytes((size_t)ivcap) / 8) + wave;
+    unsigned char* snn = reinterpret_cast<unsigned char*>(reinterpret_cast<WaveScratch*>(siv + lds_vec_bytes((size_t)ivcap) / 8) + 16);
     int* simol = reinterpret_cast<int*>(snn + (((size_t)N + 7) & ~(size_t)7));
     __shared__ int s_next;                                                   // next request nobody has taken yet
     const int nreq = w.z - w.y;                                              // <= kMoveChunk when LDSPOS
-    for (int t = tid; t < niv * 3; t += 1024) siv[t] = IV[t];
+    for (int t = tid; t < niv * 3; t += 1024) siv[LdsVecs<LAYOUT>::slot(t, ivcap)] = IV[t];
     if (LDSPOS) {
-        for (int t = tid; t < 3 * N; t += 1024) spos[t] = P[t];
+        for (int t = tid; t < 3 * N; t += 1024) spos[LdsVecs<LAYOUT>::slot(t, N)] = P[t];
         for (int t = tid; t < N; t += 1024) snn[t] = (unsigned char)NN[t];      // maxneigh <= 64
         for (int t = tid; t < nreq; t += 1024) simol[t] = req_imol[w.y + t];
         if (tid == 0) s_next = 16;
     }
     __syncthreads();
 
-    auto getiv = [&](int k, double& x, double& y, double& z) { x = siv[3 * k]; y = siv[3 * k + 1]; z = siv[3 * k + 2]; };
+    const LdsVecs<LAYOUT> vpos{spos, N}, viv{siv, ivcap};
+    auto getiv = [&](int k, double& x, double& y, double& z) { viv.get(k, x, y, z); };
     auto getpos = [&](int jx, double& x, double& y, double& z) {
-        const double* p = LDSPOS ? (spos + 3 * (size_t)jx) : (P + 3 * (size_t)jx);
-        x = p[0]; y = p[1]; z = p[2];
+        if constexpr (LDSPOS) vpos.get(jx, x, y, z);
+        else { const double* p = P + 3 * (size_t)jx; x = p[0]; y = p[1]; z = p[2]; }
     };
     auto row = [&](int jx, int sl) { return LM[(size_t)jx * kRow + sl]; };
     auto nnof = [&](int jx) { return LDSPOS ? (int)snn[jx] : NN[jx]; };
@@ -515,6 +617,129 @@ void k_local_energy_single(double* __restrict__ pos, const double* __restrict__ 
         __threadfence_system();
         __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// =====================================================================================
+// Resident server for the drop-in single call (compute_local_real_energy behind the unchanged Fortran call
+// sites, mc_moves.F90:1010,1083): a kernel launch plus its completion cost ~30 us, fifteen times what the
+// reference spends on the whole evaluation, so the engine keeps ONE small kernel resident instead -- started by
+// the first single call, stopped by any entry point that changes device state behind its back (uploads, list
+// builds, the batch kernels) and by mw_finalize, and by itself after `idle_limit` empty polls.  Wavefront w of
+// its one workgroup serves mail slot w (lattice ils goes to slot (ils - 1) % nslots, so the two lattices of a
+// move can be evaluated concurrently from two host threads): it polls the slot's request word in host-mapped
+// memory, evaluates the request with local_energy_wave (positions read past the L1: this kernel itself commits
+// the two overridden positions between requests), writes energy + counts and then the sequence word back.  The
+// cost of a call is a PCIe round trip plus the evaluation, not a launch.
+// =====================================================================================
+struct MailSlot {                       // host-mapped, 64-byte aligned; one per served slot
+    // request, line A (the host writes the fields of both lines, then seq_a, then seq_b: a 64-byte line read over
+    // PCIe is one snapshot, so a line that shows the new sequence word shows its new fields)
+    unsigned long long seq_a;
+    int box, imol;                      // 0-based
+    double x1, y1, z1;                  // position of imol, if flags & 2
+    int flags, prev;                    // bit 0: commit the positions, bit 1: x1.. present, bit 2: x2.. present; prev 0-based
+    unsigned long long pad_a[2];
+    // request, line B
+    double x2, y2, z2;                  // position of the previously queried molecule, if flags & 4
+    unsigned long long pad_b[4];
+    unsigned long long seq_b;
+    // reply line (device -> host)
+    unsigned long long rep_seq;         // the request this reply belongs to (written last)
+    double energy;
+    unsigned int ninter, nslots;
+    unsigned long long pad_c[5];
+};
+static_assert(sizeof(MailSlot) == 192, "two request lines and one reply line");
+struct MailHead { int quit; int exited; int pad[14]; };
+
+template <bool COHERENT>
+__global__ __launch_bounds__(512)
+void k_local_server(MailHead* __restrict__ head, MailSlot* __restrict__ slots,
+                    double* __restrict__ pos, const double* __restrict__ ivect, const int* __restrict__ nivect,
+                    const uint32_t* __restrict__ listm, const int* __restrict__ nn,
+                    int N, int ivcap, long long idle_limit, int stamps)
+{
+    __shared__ WaveScratch wsall[8];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    MailSlot* m = slots + w;
+    const unsigned long long* words = reinterpret_cast<const unsigned long long*>(m);
+    unsigned long long last = __hip_atomic_load(&m->rep_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    long long idle = 0;
+    auto word = [&](unsigned long long v, int l) {
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, l);
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), l);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    for (;;) {                                                        // every exit condition is reached by every wavefront
+        // one load instruction fetches both request lines (lane l reads word l & 15): two PCIe reads in flight together
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long v = __hip_atomic_load(words + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long seq = word(v, 0);
+        if (seq != last && word(v, 15) == seq) {
+            const unsigned long long w1 = word(v, 1), w5 = word(v, 5);
+            const int b = (int)(unsigned int)w1, i = (int)(unsigned int)(w1 >> 32);
+            const int flags = (int)(unsigned int)w5, prev = (int)(unsigned int)(w5 >> 32);
+            Override o1, o2;
+            o1.idx = (flags & 2) ? i : -1;
+            o1.x = __longlong_as_double((long long)word(v, 2)); o1.y = __longlong_as_double((long long)word(v, 3)); o1.z = __longlong_as_double((long long)word(v, 4));
+            o2.idx = (flags & 4) ? prev : -1;
+            o2.x = __longlong_as_double((long long)word(v, 8)); o2.y = __longlong_as_double((long long)word(v, 9)); o2.z = __longlong_as_double((long long)word(v, 10));
+            double* P = pos + (size_t)b * N * 3;
+            const double* IVb = ivect + (size_t)b * ivcap * 3;
+            const uint32_t* LMb = listm + (size_t)b * N * kRow;
+            const int* NNb = nn + (size_t)b * N;
+            const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+            // The lane-packed evaluation of the batched kernel (old and trial position both = the molecule's position): a
+            // third of the instructions of the plain routine, which matters for ONE wavefront on its own; the plain
+            // routine, with its loads batched, takes the cases that one declines.
+            double xi, yi, zi;
+            load_pos<COHERENT>(P, i, o1, o2, xi, yi, zi);
+            auto getpos = [&](int jx, double& x, double& y, double& z) { load_pos<COHERENT>(P, jx, o1, o2, x, y, z); };
+            auto getiv = [&](int k, double& x, double& y, double& z) { x = IVb[3 * k]; y = IVb[3 * k + 1]; z = IVb[3 * k + 2]; };
+            auto row = [&](int jx, int sl) { return LMb[(size_t)jx * kRow + sl]; };
+            auto nnof = [&](int jx) { return NNb[jx]; };
+            MoveRes res;
+            double e;
+            if (move_energy_wave(getpos, getiv, row, nnof, &wsall[w], nivect[b], i, nnof(i), row(i, lane & 31), xi, yi, zi, xi, yi, zi, lane, res)) {
+                e = res.eo;
+            } else {
+                unsigned int ni, ns;
+                e = local_energy_wave_batched<COHERENT>(P, IVb, LMb, NNb, i, o1, o2, lane, ni, ns);
+            }
+            const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0) {
+                // the reply: energy and sequence word in ONE 16-byte store (one PCIe write: the host reads the word, then the energy)
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                const unsigned long long eb = (unsigned long long)__double_as_longlong(e);
+                const u32x4 rep = {(unsigned int)seq, (unsigned int)(seq >> 32), (unsigned int)eb, (unsigned int)(eb >> 32)};
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(&m->rep_seq), "v"(rep) : "memory");
+                if (stamps) {     // 100 MHz stamps for tools/kbench (poll issued -> request decoded -> evaluated): diagnostics only
+                    __hip_atomic_store(&m->pad_c[0], t1 - t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(&m->pad_c[1], t2 - t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                if (flags & 1) {  // after the reply is on its way: written through to L2 (agent scope); the kernel's end makes
+                                  // them visible to every later launch
+                    if (o1.idx >= 0) {
+                        __hip_atomic_store(P + 3 * o1.idx, o1.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(P + 3 * o1.idx + 1, o1.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(P + 3 * o1.idx + 2, o1.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (o2.idx >= 0 && o2.idx != o1.idx) {
+                        __hip_atomic_store(P + 3 * o2.idx, o2.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(P + 3 * o2.idx + 1, o2.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(P + 3 * o2.idx + 2, o2.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            last = seq;
+            idle = 0;
+        } else {
+            const int q = __hip_atomic_load(&head->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (q != 0 || ++idle > idle_limit) break;
+        }
+    }
+    if (lane == 0) __hip_atomic_fetch_add(&head->exited, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace mw

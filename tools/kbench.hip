@@ -9,6 +9,7 @@
 #include "kbench_variants.hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <map>
 
@@ -25,6 +26,18 @@ static void launch_me(int nboxes)
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_model_energy<true, 1024, LAYOUT, BATCH4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget); attr = true; }
     hipLaunchKernelGGL((mw::k_model_energy<true, 1024, LAYOUT, BATCH4>), dim3(ge.nsplit, nboxes), dim3(1024), ge.shmem, g.stream, g.d_pos, g.d_ivect,
                        g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, 0, ge.nsplit, ge.chunk);
+}
+
+template <int LAYOUT>
+static void launch_mv()
+{
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_move_energy<true, LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget); attr = true; }
+    const size_t iv_bytes = kMoveScratch + mw::lds_vec_bytes((size_t)g.ivcap);
+    hipLaunchKernelGGL((mw::k_move_energy<true, LAYOUT>), dim3(g.mwork_n), dim3(1024),
+                       iv_bytes + mw::lds_vec_bytes((size_t)g.N) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
+                       g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
+                       g.d_meold, g.d_menew, g.d_mcnt, g.N, g.ivcap, 3);
 }
 
 int main(int argc, char** argv)
@@ -89,6 +102,71 @@ int main(int argc, char** argv)
     vs.push_back({"k_model_energy<SoA,BATCH4>", [&] { launch_me<mw::kLayoutSoA, true>(W); }, {}});
     }
 
+    // ---- the drop-in single call: host wall time per synchronous mw_local_energy_patched through the C ABI ------------
+    if (!only || std::string(only) == "latency") {
+        std::vector<double> p1(pos.begin(), pos.begin() + (size_t)N * 3);
+        auto run = [&](int ncalls) {
+            double acc = 0.0, e = 0.0;
+            int prev = 0;
+            unsigned s = 12345u;
+            for (int k = 0; k < ncalls; ++k) {
+                s = s * 1664525u + 1013904223u;
+                const int im = (int)(s % (unsigned)N) + 1;
+                if (mw_local_energy_patched(1, im, &p1[3 * (size_t)(im - 1)], prev, prev ? &p1[3 * (size_t)(prev - 1)] : nullptr, &e)) { fprintf(stderr, "%s\n", mw_last_error()); break; }
+                acc += e; prev = im;
+            }
+            return acc;
+        };
+        run(2000);
+        {   // device-side stamps of one call each (100 MHz clock): poll -> decoded, evaluation
+            double tp = 0.0, te = 0.0; double e;
+            for (int k = 0; k < 1000; ++k) {
+                const int im = 1 + (k * 37) % N;
+                mw_local_energy_patched(1, im, &p1[3 * (size_t)(im - 1)], 0, nullptr, &e);
+                tp += (double)g.h_slots[0].pad_c[0] * 0.01; te += (double)g.h_slots[0].pad_c[1] * 0.01;
+            }
+            printf("time  server: poll read %.2f us, evaluation %.2f us (device clock, mean of 1000)\n", tp / 1000, te / 1000);
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        const double acc = run(20000);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 20000.0;
+        printf("time  mw_local_energy_patched, one call (server %s)   %8.2f us   (sum %.6f)\n", g.srv_enabled ? "resident" : "off: one launch per call", us, acc);
+        double em = 0.0;
+        const auto t1 = std::chrono::steady_clock::now();
+        for (int k = 0; k < 200; ++k) CK(mw_model_energy(1, &em));
+        printf("time  mw_model_energy, one box, one call               %8.2f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count() / 200.0);
+        // alternating: the server is stopped by every exclusive entry point and restarted by the next single call
+        const auto t2 = std::chrono::steady_clock::now();
+        for (int k = 0; k < 200; ++k) { double e; CK(mw_local_energy_patched(1, 1 + k, &p1[3 * (size_t)k], 0, nullptr, &e)); CK(mw_sync()); }
+        printf("time  single call + mw_sync (server stop/start)         %8.2f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t2).count() / 200.0);
+    }
+
+    // ---- single-move kernel: layouts of the staged vectors ------------------------------------------------------
+    std::vector<Variant> mv;
+    if (M > 0 && lds_fits_move(g.N, g.ivcap)) {
+        std::vector<int> ils((size_t)W * M);
+        for (int w = 0; w < W; ++w) for (int m = 0; m < M; ++m) ils[(size_t)w * M + m] = w + 1;
+        CK(mw_moves_upload(W * M, ils.data(), imol.data(), trial.data()));
+        if (g.mlds) {
+            CK(mw_moves_launch());
+            std::vector<double> eo((size_t)W * M), en((size_t)W * M), eo2((size_t)W * M), en2((size_t)W * M);
+            CK(mw_moves_fetch(eo.data(), en.data()));
+            mv.push_back({"k_move_energy product", [&] { (void)launch_moves(3); }, {}});
+            mv.push_back({"k_move_energy<AoS>", [&] { launch_mv<mw::kLayoutAoS>(); }, {}});
+            mv.push_back({"k_move_energy<Pair>", [&] { launch_mv<mw::kLayoutPair>(); }, {}});
+            mv.push_back({"k_move_energy<SoA>", [&] { launch_mv<mw::kLayoutSoA>(); }, {}});
+            for (auto& v : mv) {
+                if (only && v.name.find(only) == std::string::npos) continue;
+                v.launch();
+                HK(hipGetLastError());
+                CK(mw_moves_fetch(eo2.data(), en2.data()));
+                double worst = 0.0;
+                for (size_t k = 0; k < eo.size(); ++k) worst = std::max(worst, std::max(fabs(eo2[k] - eo[k]), fabs(en2[k] - en[k])));
+                printf("check %-44s max |diff| %.2e Ha\n", v.name.c_str(), worst);
+            }
+        }
+    }
+
     hipEvent_t e0, e1;
     HK(hipEventCreate(&e0)); HK(hipEventCreate(&e1));
     // correctness of every variant first (energies of all boxes against the product kernel)
@@ -124,7 +202,22 @@ int main(int argc, char** argv)
             }
         }
     }
-    for (auto& v : vs) {
+    for (int r = 0; r < rounds; ++r) {
+        for (auto& v : mv) {
+            if (only && v.name.find(only) == std::string::npos) continue;
+            for (int k = 0; k < 3; ++k) {
+                HK(hipEventRecord(e0, g.stream));
+                v.launch();
+                HK(hipEventRecord(e1, g.stream));
+                HK(hipEventSynchronize(e1));
+                float ms = 0.f;
+                HK(hipEventElapsedTime(&ms, e0, e1));
+                if (r > 0 || k > 0) v.us.push_back(ms * 1e3f);
+            }
+        }
+    }
+    for (auto* grp : {&vs, &mv})
+    for (auto& v : *grp) {
         if (v.us.empty()) continue;
         std::sort(v.us.begin(), v.us.end());
         printf("time  %-44s median %8.1f us   min %8.1f us   (n=%zu)\n", v.name.c_str(), v.us[v.us.size() / 2], v.us[0], v.us.size());
