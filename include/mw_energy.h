@@ -169,6 +169,23 @@ int mw_sweep_options(int record, int samplerun, int always_switch, int npt,
  * device; pressure and ensemble come from mw_sweep_options.  Default: translations only.  After sweeps with volume
  * moves call mw_sweep_sync_cells before rebuilding lists: it reads the cells back (h_out, count x 9, may be NULL)
  * and refreshes the host-side image vectors / neighbour-grid descriptors exactly as mw_set_cell does. */
+/* leshift (userparams.f90:41; main.f90:146-150,173): the reference enthalpies of the two lattices enter the order
+ * parameter (mc_moves.F90:1371,1526,1584) and the lattice-switch acceptance (:1567,1572).  (0, 0) = off. */
+int mw_sweep_leshift(double ref_enthalpy_1, double ref_enthalpy_2);
+/* wl_swetnam (mc_moves.F90:1636-1653): after every recorded move the walker's increment becomes
+ * min(orig_wl_factor, wl_alpha nbins log(rms deviation of its histogram from flat)); mu_min / mu_max of the whole grid. */
+int mw_sweep_swetnam(int on, double wl_alpha, double orig_wl_factor, double mu_min, double mu_max);
+/* parallel_strategy = 'dd' (mc_moves.F90:181-210,243-248,659-709): every walker samples its own window of the overlap
+ * parameter (mw_sweep_windows; NULL arrays: back to the window of mw_sweep_configure for everybody).  Until cycle
+ * eq_mc_cycles a walker outside its window carries no weight and no lattice switch is attempted; a walker still outside
+ * at eq_mc_cycles raises the flag mw_sweep_check_flags reports.  Cycle numbers follow from move0 (nwater moves per cycle). */
+int mw_sweep_dd(int on, int eq_mc_cycles);
+int mw_sweep_windows(int first_walker, int count, const int *start_bin, const int *end_bin,
+                     const double *mu_lo, const double *mu_hi);
+/* Per-walker Wang-Landau increment and Swetnam visit total (every rank of the reference has its own; mw_sweep_options
+ * sets one increment for all walkers unless 'dd' or wl_swetnam is on).  NULL pointers are skipped. */
+int mw_sweep_set_factors(int first_walker, int count, const double *wl_factor, const double *sumhist);
+int mw_sweep_get_factors(int first_walker, int count, double *wl_factor, double *sumhist, int *in_window);
 int mw_sweep_moves(double transP, double dv_max_bohr);
 int mw_sweep_get_volume_moves(int walker, long long *attempted, long long *accepted);
 /* Nonzero (with the walker named in mw_last_error) if a volume move of any walker of the range needed more image

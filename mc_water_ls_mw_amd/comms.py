@@ -104,12 +104,15 @@ class WalkerComms:
     # serial Recv loop: one gather to rank 0 (gather_object of 808-byte arrays is latency, not bandwidth), the
     # stitching in rank order exactly as the reference does it, one broadcast.
     def _gather_to_root(self, arr):
+        """The windows' arrays in rank order.  A farm passes a 2-D array, one row per walker of this process: walker k
+        of process p is window p * nrows + k, so the rows of all processes are laid end to end."""
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
         if not dist.is_initialized():
-            return [np.array(arr, dtype=np.float64)]
-        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.device)
+            return [np.array(r) for r in np.atleast_2d(arr)]
+        t = torch.from_numpy(arr).to(self.device)
         out = [torch.empty_like(t) for _ in range(self.world_size)]
         dist.all_gather(out, t, group=self.group)
-        return [o.cpu().numpy() for o in out]
+        return [np.array(r) for o in out for r in np.atleast_2d(o.cpu().numpy())]
 
     def _bcast(self, arr):
         if not dist.is_initialized():
@@ -122,7 +125,7 @@ class WalkerComms:
         """comms_join_eta (comms_mpi.f90:381-459): rank r's window supplies the bins above r*bins_per_window,
         shifted so that the mean over the 2*overlap+1 bins around the seam agrees; the middle bin is set to 0."""
         parts = self._gather_to_root(weight)
-        length, size = len(weight), len(parts)
+        length, size = len(parts[0]), len(parts)
         bpw = length // size                                           # :399
         joined = parts[0].copy()                                       # :401
         for irank in range(1, size):
@@ -137,7 +140,7 @@ class WalkerComms:
     def join_uhist(self, uhist, overlap):
         """comms_join_uhist (comms_mpi.f90:299-379): the same stitching for the unbiased histogram, in log space."""
         parts = self._gather_to_root(uhist)
-        length, size = len(uhist), len(parts)
+        length, size = len(parts[0]), len(parts)
         bpw = length // size
         joined = parts[0].copy()
         for irank in range(1, size):

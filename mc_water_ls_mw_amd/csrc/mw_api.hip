@@ -104,7 +104,11 @@ struct Ctx {
     double* d_tabscratch = nullptr;  // [3 nbins last | 3 nbins out | chunks x nbins partial] for mw_sweep_reduce_tables
     size_t tabscratch_n = 0;      // per walker: sum of the minima mc_update_wl_bins subtracted since the last read-out
     unsigned long long* d_wvol = nullptr;        // [walker][2] volume moves attempted / accepted
-    int* d_wflag = nullptr;                      // [walker] a volume move needed more image vectors than ivcap
+    int* d_wflag = nullptr;                      // [walker] bit 0: a volume move needed more image vectors than ivcap; bit 1: 'dd' walker outside its window at eq_mc_cycles
+    double* d_wwin = nullptr;                    // [walker][4] start_bin, end_bin, mu_lo, mu_hi ('dd' windows); used when has_windows
+    double *d_wfac = nullptr, *d_wsum = nullptr; // [walker] Wang-Landau increment, Swetnam's visit total
+    int* d_winflag = nullptr;                    // [walker] walker_in_window
+    bool has_windows = false;
     double* d_volume = nullptr;                  // [box] |det hmatrix|
     int* d_wls = nullptr;
     double* d_wmu = nullptr;
@@ -447,7 +451,7 @@ void release_all()
     if (g.h_head) (void)hipHostFree(g.h_head);
     if (g.h_slots) (void)hipHostFree(g.h_slots);
     void* ptrs[] = {g.d_hmat, g.d_sw_mubin, g.d_sw_binwidth, g.d_wweight, g.d_whist, g.d_wuhist, g.d_wls, g.d_wmu, g.d_wacc,
-                    g.d_wswitch, g.d_wshift, g.d_wvol, g.d_wflag, g.d_volume, g.d_swlog, g.d_tabscratch, g.d_pos, g.d_ivect,
+                    g.d_wswitch, g.d_wshift, g.d_wvol, g.d_wflag, g.d_wwin, g.d_wfac, g.d_wsum, g.d_winflag, g.d_volume, g.d_swlog, g.d_tabscratch, g.d_pos, g.d_ivect,
                     g.d_nivect, g.d_list, g.d_listm, g.d_nn, g.d_stats, g.d_order, g.d_nns, g.d_cmax, g.d_cin, g.d_grid,
                     g.d_usegrid, g.d_cellid, g.d_shift, g.d_sorted, g.d_wrel, g.d_wpos, g.d_wsh, g.d_ccount, g.d_cstart, g.d_ccursor, g.d_partial,
                     g.d_cpartial, g.d_energy, g.d_counts, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.d_mperm,
@@ -1193,7 +1197,18 @@ int mw_sweep_configure(int nlat, double beta, double max_trans, int nbins, int e
         HIPCHK(hipMalloc(&g.d_wshift, sizeof(double) * g.nbox));
         HIPCHK(hipMalloc(&g.d_wvol, sizeof(unsigned long long) * 2 * g.nbox));
         HIPCHK(hipMalloc(&g.d_wflag, sizeof(int) * g.nbox));
+        HIPCHK(hipMalloc(&g.d_wwin, sizeof(double) * 4 * g.nbox));
+        HIPCHK(hipMalloc(&g.d_wfac, sizeof(double) * g.nbox));
+        HIPCHK(hipMalloc(&g.d_wsum, sizeof(double) * g.nbox));
+        HIPCHK(hipMalloc(&g.d_winflag, sizeof(int) * g.nbox));
     }
+    HIPCHK(hipMemset(g.d_wwin, 0, sizeof(double) * 4 * g.nbox));
+    HIPCHK(hipMemset(g.d_wfac, 0, sizeof(double) * g.nbox));
+    HIPCHK(hipMemset(g.d_wsum, 0, sizeof(double) * g.nbox));
+    HIPCHK(hipMemset(g.d_winflag, 0, sizeof(int) * g.nbox));
+    g.has_windows = false;
+    g.sp.dref = 0.0; g.sp.swetnam = 0; g.sp.dd = 0; g.sp.wl_alpha = 1.0; g.sp.orig_wl_factor = 0.0;
+    g.sp.mu_min = mu_lo; g.sp.mu_max = mu_hi; g.sp.eq_cycles = 0; g.sp.in_window = 1;
     HIPCHK(hipMemset(g.d_wvol, 0, sizeof(unsigned long long) * 2 * g.nbox));
     HIPCHK(hipMemset(g.d_wflag, 0, sizeof(int) * g.nbox));
     HIPCHK(hipMemset(g.d_wswitch, 0, sizeof(unsigned long long) * g.nbox));
@@ -1251,6 +1266,83 @@ int mw_sweep_options(int record, int samplerun, int always_switch, int npt,
     if ((record || always_switch) && g.sp.nlat != 2) return fail("mw_sweep_options: histograms and lattice switches need two lattices");
     g.sp.record = record ? 1 : 0; g.sp.samplerun = samplerun ? 1 : 0; g.sp.always_switch = always_switch ? 1 : 0; g.sp.npt = npt ? 1 : 0;
     g.sp.av_binwidth = av_binwidth; g.sp.wl_factor = wl_factor; g.sp.log_unbiased_norm = log_unbiased_norm; g.sp.pressure = pressure;
+    if (g.sp.nlat == 2 && !g.sp.swetnam && !g.sp.dd) {           // one increment for every walker ('mw'); per-walker values: mw_sweep_set_factors
+        std::vector<double> f((size_t)g.nwalkers, wl_factor);
+        HIPCHK(hipMemcpyAsync(g.d_wfac, f.data(), sizeof(double) * g.nwalkers, hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    return 0;
+}
+
+int mw_sweep_leshift(double ref_enthalpy_1, double ref_enthalpy_2)
+{
+    MW_LOCK;
+    if (check_live()) return 1;
+    if (!g.sweep_ready) return fail("mw_sweep_leshift: call mw_sweep_configure first");
+    g.sp.dref = ref_enthalpy_1 - ref_enthalpy_2;
+    return 0;
+}
+
+int mw_sweep_swetnam(int on, double wl_alpha, double orig_wl_factor, double mu_min, double mu_max)
+{
+    MW_LOCK;
+    if (check_live()) return 1;
+    if (!g.sweep_ready) return fail("mw_sweep_swetnam: call mw_sweep_configure first");
+    g.sp.swetnam = on ? 1 : 0; g.sp.wl_alpha = wl_alpha; g.sp.orig_wl_factor = orig_wl_factor;
+    g.sp.mu_min = mu_min; g.sp.mu_max = mu_max;
+    return 0;
+}
+
+int mw_sweep_dd(int on, int eq_mc_cycles)
+{
+    MW_LOCK;
+    if (check_live()) return 1;
+    if (!g.sweep_ready) return fail("mw_sweep_dd: call mw_sweep_configure first");
+    g.sp.dd = on ? 1 : 0; g.sp.eq_cycles = eq_mc_cycles;
+    return 0;
+}
+
+int mw_sweep_windows(int first_walker, int count, const int* start_bin, const int* end_bin, const double* mu_lo, const double* mu_hi)
+{
+    MW_LOCK;
+    if (check_live() || check_walker(first_walker, count)) return 1;
+    if (!start_bin || !end_bin || !mu_lo || !mu_hi) { g.has_windows = false; return 0; }
+    std::vector<double> w((size_t)count * 4);
+    for (int k = 0; k < count; ++k) {
+        if (start_bin[k] < 1 || end_bin[k] > g.sp.nbins || start_bin[k] >= end_bin[k])
+            return fail("mw_sweep_windows: walker %d has bins %d..%d outside 1..%d", first_walker + k, start_bin[k], end_bin[k], g.sp.nbins);
+        w[4 * (size_t)k] = start_bin[k]; w[4 * (size_t)k + 1] = end_bin[k]; w[4 * (size_t)k + 2] = mu_lo[k]; w[4 * (size_t)k + 3] = mu_hi[k];
+    }
+    if (!g.has_windows) {        // walkers outside the range given keep the window of mw_sweep_configure
+        std::vector<double> all((size_t)g.nwalkers * 4);
+        for (int k = 0; k < g.nwalkers; ++k) { all[4 * (size_t)k] = g.sp.start_bin; all[4 * (size_t)k + 1] = g.sp.end_bin; all[4 * (size_t)k + 2] = g.sp.mu_lo; all[4 * (size_t)k + 3] = g.sp.mu_hi; }
+        HIPCHK(hipMemcpyAsync(g.d_wwin, all.data(), sizeof(double) * all.size(), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    HIPCHK(hipMemcpyAsync(g.d_wwin + 4 * (size_t)(first_walker - 1), w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    g.has_windows = true;
+    return 0;
+}
+
+int mw_sweep_set_factors(int first_walker, int count, const double* wl_factor, const double* sumhist)
+{
+    MW_LOCK;
+    if (check_live() || check_walker(first_walker, count)) return 1;
+    if (wl_factor) HIPCHK(hipMemcpyAsync(g.d_wfac + (first_walker - 1), wl_factor, sizeof(double) * count, hipMemcpyHostToDevice, g.stream));
+    if (sumhist) HIPCHK(hipMemcpyAsync(g.d_wsum + (first_walker - 1), sumhist, sizeof(double) * count, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int mw_sweep_get_factors(int first_walker, int count, double* wl_factor, double* sumhist, int* in_window)
+{
+    MW_LOCK;
+    if (check_live() || check_walker(first_walker, count)) return 1;
+    if (wl_factor) HIPCHK(hipMemcpyAsync(wl_factor, g.d_wfac + (first_walker - 1), sizeof(double) * count, hipMemcpyDeviceToHost, g.stream));
+    if (sumhist) HIPCHK(hipMemcpyAsync(sumhist, g.d_wsum + (first_walker - 1), sizeof(double) * count, hipMemcpyDeviceToHost, g.stream));
+    if (in_window) HIPCHK(hipMemcpyAsync(in_window, g.d_winflag + (first_walker - 1), sizeof(int) * count, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
     return 0;
 }
 
@@ -1284,10 +1376,14 @@ int mw_sweep_check_flags(int first_walker, int count)
     std::vector<int> flags((size_t)count, 0);
     HIPCHK(hipMemcpyAsync(flags.data(), g.d_wflag + (first_walker - 1), sizeof(int) * count, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
-    for (int w = 0; w < count; ++w)
-        if (flags[(size_t)w])
+    for (int w = 0; w < count; ++w) {
+        if (flags[(size_t)w] & 1)
             return fail("mw_sweep: a volume move of walker %d shrank a cell below what %d image vectors cover (the move was rejected)",
                         first_walker + w, g.ivcap);
+        if (flags[(size_t)w] & 2)
+            return fail("Error : Not all walkers have reached their designated window after %d MC cycles (walker %d)",
+                        g.sp.eq_cycles, first_walker + w);
+    }
     return 0;
 }
 
@@ -1302,7 +1398,7 @@ int mw_sweep_get_volume_moves(int walker, long long* attempted, long long* accep
     HIPCHK(hipStreamSynchronize(g.stream));
     if (attempted) *attempted = (long long)v[0];
     if (accepted) *accepted = (long long)v[1];
-    if (flag) return fail("mw_sweep: a volume move of walker %d shrank a cell below what %d image vectors cover", walker, g.ivcap);
+    if (flag & 1) return fail("mw_sweep: a volume move of walker %d shrank a cell below what %d image vectors cover", walker, g.ivcap);
     return 0;
 }
 
@@ -1318,7 +1414,7 @@ int mw_sweep_sync_cells(int first_ils, int count, double* h_out)
     if (g.d_wflag) HIPCHK(hipMemcpyAsync(flags.data(), g.d_wflag, sizeof(int) * g.nbox, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     for (int w = 0; w < g.nbox; ++w)
-        if (flags[(size_t)w]) return fail("mw_sweep: a volume move of walker %d shrank a cell below what %d image vectors cover", w + 1, g.ivcap);
+        if (flags[(size_t)w] & 1) return fail("mw_sweep: a volume move of walker %d shrank a cell below what %d image vectors cover", w + 1, g.ivcap);
     // host mirrors for every box, then four bulk uploads (the device already holds these image vectors: same arithmetic)
     for (int b = 0; b < count; ++b) {
         const int box = first_ils - 1 + b;
@@ -1528,7 +1624,8 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
     hipLaunchKernelGGL(kern, dim3(count), dim3(64), shmem, g.stream, g.d_pos, g.d_hmat, g.d_ivect, g.d_nivect,
                        g.d_listm, g.d_list, g.d_nn, g.d_order, g.d_nns, g.d_cmax, g.d_energy, g.d_wls, g.d_wmu, g.d_wacc, g.d_wswitch, g.d_wshift, g.sp, g.d_wweight, g.d_whist, g.d_wuhist,
                        g.d_sw_mubin, g.d_sw_binwidth, g.d_volume, g.d_wvol, g.d_wflag, g.N, g.S, g.ivcap, nmoves, seed, move0,
-                       first_walker - 1, dlog, rstride);
+                       first_walker - 1, dlog, rstride, g.has_windows ? (const double*)g.d_wwin : (const double*)nullptr,
+                       g.d_wfac, g.d_wsum, g.d_winflag);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -30,6 +30,12 @@ struct SweepParams {
     int record, samplerun, always_switch, npt;      // mc_update_wl_bins active / fixed weights / switch after every move / ensemble
     double av_binwidth, wl_factor, log_unbiased_norm, pressure;
     double transP, dv_max;                          // move-type threshold (mc_moves.F90:157-166), max cell-element change
+    // leshift (userparams.f90:41): ref_enthalpy(1) - ref_enthalpy(2), 0 when off (main.f90:146-150,173; mc_moves.F90:1371,1567-1584)
+    double dref;
+    // wl_swetnam (mc_moves.F90:1636-1653): the increment follows the histogram's r.m.s. deviation from flat, move by move
+    int swetnam, dd;                                // dd: parallel_strategy = 'dd' (window per walker, mc_moves.F90:181-210,659-709)
+    double wl_alpha, orig_wl_factor, mu_min, mu_max;
+    int eq_cycles, in_window;                       // dd: equilibration length (cycles); in_window: this walker's flag (filled per walker)
 };
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
@@ -63,6 +69,9 @@ __device__ __forceinline__ double dev_eta_weight(const SweepParams& g, const dou
                                                  const double* __restrict__ mu_bin, const double* __restrict__ binwidth,
                                                  double mu)                                // mc_moves.F90:893-964
 {
+    // 'dd' walkers that have not reached their window yet carry no weight: the reference returns here without
+    // assigning the function result (:913); 0 is what its comment asks for ("don't want to penalise walkers")
+    if (!g.in_window) return 0.0;
     if (mu < g.mu_lo || mu > g.mu_hi) return 1.7976931348623157e308;                       // huge(1.0_dp)
     const int k = dev_mu_to_bin(g, mu);
     const double* w = weight - 1; const double* mb = mu_bin - 1; const double* bw = binwidth - 1;   // 1-based views
@@ -278,6 +287,7 @@ int volume_move_wave(const VolCtx& c, const SweepParams& sp, const double* weigh
         if (L == 2) {                                                                            // :1363-1371
             old_eta = dev_eta_weight(sp, weight, mu_bin, binwidth, ls_mu);
             double mu = (men[0] + sp.pressure * c.svol[0]) - (men[1] + sp.pressure * c.svol[1]);
+            mu = mu - sp.dref;                                                                   // :1371 (leshift)
             mu = mu * sp.beta - (double)N * log(c.svol[0] / c.svol[1]);
             ls_mu = mu;
             new_eta = dev_eta_weight(sp, weight, mu_bin, binwidth, ls_mu);
@@ -313,6 +323,7 @@ int volume_move_wave(const VolCtx& c, const SweepParams& sp, const double* weigh
         men[0] = backup_e[0]; men[1] = backup_e[1];                                              // :1514
         if (L == 2) {                                                                            // :1516-1520
             double mu = (men[0] + sp.pressure * c.svol[0]) - (men[1] + sp.pressure * c.svol[1]);
+            mu = mu - sp.dref;                                                                   // :1526 (leshift)
             mu = mu * sp.beta - (double)N * log(c.svol[0] / c.svol[1]);
             ls_mu = mu;
         }
@@ -344,7 +355,9 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
                          const double* __restrict__ mu_bin_g, const double* __restrict__ binwidth_g,
                          double* volume, unsigned long long* __restrict__ wvol, int* __restrict__ wflag,
                          int N, int S, int ivcap, int nmoves, unsigned long long seed, unsigned long long move0,
-                         int walker0, double* __restrict__ mvlog, int rstride)
+                         int walker0, double* __restrict__ mvlog, int rstride,
+                         const double* __restrict__ wwin, double* __restrict__ wfac, double* __restrict__ wsum,
+                         int* __restrict__ winflag)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ WaveScratch ws;
@@ -355,6 +368,15 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
     const int wlk = walker0 + blockIdx.x;
     const int L = sp.nlat;
     const int box0 = wlk * L;
+    // per-walker pieces of the parameter block: its window of the overlap parameter ('dd': mc_moves.F90:659-709; else
+    // the whole range), whether it has reached that window, its Wang-Landau increment and Swetnam's visit total
+    if (wwin) {
+        sp.start_bin = (int)wwin[4 * (size_t)wlk]; sp.end_bin = (int)wwin[4 * (size_t)wlk + 1];
+        sp.mu_lo = wwin[4 * (size_t)wlk + 2]; sp.mu_hi = wwin[4 * (size_t)wlk + 3];
+    }
+    sp.in_window = sp.dd ? winflag[wlk] : 1;                              // mc_moves.F90:112,872
+    double wlf = L == 2 ? wfac[wlk] : 0.0;                                // wl_factor of this walker (:1615,1677)
+    double sumh = L == 2 ? wsum[wlk] : 0.0;                               // sumhist (:94,1638)
     const double invPi = 1.0 / 3.141592653589793238462643383279502884197;
 
     // image vectors of the walker's lattices in LDS: siv[l][ivcap][3]; with LDSPOS (small systems) the walker's
@@ -442,6 +464,16 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
         const double u3 = readlane_f64(ub, 1), u4 = readlane_f64(ua, 2), u5 = readlane_f64(ub, 2);
         const double u6 = readlane_f64(ua, 3);          // lattice-switch variate (mc_moves.F90:1576)
         const double u7 = readlane_f64(ub, 3);          // move type (mc_moves.F90:226)
+        int cyc = 0;                                                   // mc_cycle_num of this move ('dd' only)
+        if (sp.dd) {
+            const unsigned long long mg = move0 + (unsigned long long)mv;
+            cyc = (int)(mg / (unsigned long long)N) + 1;
+            if (mg % (unsigned long long)N == 0ull) {                  // top of a cycle: the equilibration check of mc_cycle (:181-210)
+                if (cyc < sp.eq_cycles) sp.in_window = (ls_mu > sp.mu_lo && ls_mu < sp.mu_hi) ? 1 : 0;
+                else if (cyc == sp.eq_cycles) { if (!sp.in_window) flag |= 2; }     // "Not all walkers have reached their designated window"
+                else sp.in_window = 1;                                 // a restart
+            }
+        }
         const bool is_volume = WITHVOL && !(u7 < sp.transP);    // WITHVOL = false: translation-only build, no call, lean registers
         bool ok = false;
         double eo[2] = {0.0, 0.0}, en[2] = {0.0, 0.0}, diffkT = 0.0;
@@ -451,7 +483,7 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
             if constexpr (WITHVOL) rv = volume_move_wave(vc, sp, weight, mu_bin, binwidth, u0, u1, u2, u3, ls, ls_mu, men, lane);
             ++nvol_try;
             if (rv == 1) ++nvol_acc;
-            if (rv < 0) flag = 1;
+            if (rv < 0) flag |= 1;
             ok = rv == 1;
         } else {
         const int lsn = L == 2 ? 3 - ls : 1;
@@ -552,9 +584,23 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
                         uhist[k - 1] = uhist[k - 1] + (sp.av_binwidth / bwk) * exp(etaw - sp.log_unbiased_norm);   // :1627-1629
                     }
                 } else {
+                    if (sp.swetnam) {                                             // :1636-1653
+                        sumh = sumh + 1.0;
+                        double acc = 0.0;
+                        const double span = sp.mu_max - sp.mu_min - 1.0;
+                        for (int b = lane; b < sp.nbins; b += 64) {
+                            const double hb = hist[b] + (b == k - 1 ? sp.av_binwidth / bwk : 0.0);    // this move's visit is already counted (:1621)
+                            const double dev = hb * binwidth[b] / sumh - binwidth[b] / span;
+                            acc += dev * dev;
+                        }
+                        acc = readlane_f64(dpp_wave_sum(acc), 63);
+                        double f = sqrt(acc / (double)sp.nbins);
+                        f = log(f) * sp.wl_alpha * (double)sp.nbins;
+                        wlf = f < sp.orig_wl_factor ? f : sp.orig_wl_factor;
+                    }
                     // weight(k) += av_binwidth*wl_factor/binwidth(k) -- whichever bin k is (:1680); then the minimum over the
                     // walker's window is subtracted inside the window (:1682-1685; with 'dd' windows k may lie outside)
-                    const double inc = sp.av_binwidth * sp.wl_factor / bwk;
+                    const double inc = sp.av_binwidth * wlf / bwk;
                     double mn = 1.7976931348623157e308;
                     for (int b = sp.start_bin - 1 + lane; b < sp.end_bin; b += 64) {
                         double w = weight[b];
@@ -576,7 +622,7 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
         }
-        if (L == 2 && sp.always_switch) {                                         // mc_lattice_switch, :1536-1594
+        if (L == 2 && sp.always_switch && !(sp.dd && cyc < sp.eq_cycles)) {      // mc_lattice_switch, :1536-1594 (:243-248: not while a 'dd' run equilibrates)
             const int lsw = 3 - ls;
             const double eta_w = dev_eta_weight(sp, weight, mu_bin, binwidth, ls_mu);
             const double deta = eta_w - eta_w;                                    // new_eta - old_eta, :1557-1558
@@ -586,10 +632,12 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
             double dk;
             if (sp.npt) dk = sp.beta * Elsn - sp.beta * Els + sp.beta * sp.pressure * (Vlsn - Vls) - (double)N * log(Vlsn / Vls) + deta;
             else        dk = sp.beta * Elsn - sp.beta * Els + deta;
+            dk = dk + (ls == 1 ? sp.beta * sp.dref : -(sp.beta * sp.dref));       // leshift: - beta ref(lsn) + beta ref(ls), :1567,1572
             double cmp = exp(-dk);
             cmp = cmp > 1.0 ? 1.0 : cmp;
             if (u6 < cmp) {
                 double mu = (men[0] + sp.pressure * V1) - (men[1] + sp.pressure * V2);          // :1581-1583
+                mu = mu - sp.dref;                                                              // :1584 (leshift)
                 mu = mu * sp.beta - (double)N * log(V1 / V2);
                 ls_mu = mu; ls = lsw; sw = 1; ++nsw;
             }
@@ -609,7 +657,9 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
     if (lane == 0) {
         wls[wlk] = ls; wmu[wlk] = ls_mu; wacc[wlk] += acc; wswitch[wlk] += nsw; wshift[wlk] += gauge;
         wvol[2 * wlk] += nvol_try; wvol[2 * wlk + 1] += nvol_acc;
-        if (flag) wflag[wlk] = 1;
+        if (flag) wflag[wlk] |= flag;                       // bit 0: image-vector table outgrown, bit 1: 'dd' walker not in its window at eq_mc_cycles
+        if (L == 2) { wfac[wlk] = wlf; wsum[wlk] = sumh; }
+        if (sp.dd) winflag[wlk] = sp.in_window;
         energy[box0] = men[0];
         if (L == 2) energy[box0 + 1] = men[1];
     }

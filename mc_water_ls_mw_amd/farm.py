@@ -23,7 +23,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         list_update_int=10, mpi_sync_int=250, sigma_ang=0.05, seed=2025, device=0, comms=None, rank=0,
         samplerun=False, weight=None, npt=False, pressure_atm=1.0,
         flat_chk_int=10000, wl_schedule=0, wl_flattol=0.05, wl_minhist=20, wl_useinvt=False, file_wl_factor=None,
-        deltaG_int=100000, max_mc_cycles=None, eq_mc_cycles=0, outdir=None, thermalise=True, regauge=False):
+        deltaG_int=100000, max_mc_cycles=None, eq_mc_cycles=0, outdir=None, thermalise=True, regauge=False,
+        parallel_strategy="mw", window_overlap=2, leshift=False, input_ref_enthalpy=None, wl_swetnam=False, wl_alpha=1.0):
     """Run `cycles` MC cycles of `walkers` two-lattice walkers on this GPU.  Returns a dict of results.
 
     ``flat_chk_int`` ... ``file_wl_factor``: the Wang-Landau schedule (mc_check_flatness, :291-294;
@@ -32,12 +33,20 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
     ``regauge``: False (default) is the reference's exchange arithmetic to the letter (comms_mpi.f90:256-270: every
     rank's increment carries the window minimum it subtracted); True sums the increments proper and subtracts the
     minimum once (WalkerFarm.synchronise) -- the mode for farms of hundreds of walkers per GPU, where the reference's
-    scheme loses the weights' precision within a few synchronisations (tests/test_sweep.py shows the growth)."""
+    scheme loses the weights' precision within a few synchronisations (tests/test_sweep.py shows the growth).
+    ``parallel_strategy``: 'mw' (every walker samples the whole range, tables synchronised every mpi_sync_int cycles) or
+    'dd' (mc_moves.F90:659-709: every walker of every GPU is one window of ``world x walkers``, overlapping its
+    neighbours by ``window_overlap`` bins, with its own increment and flatness check and no exchange; the windows are
+    stitched at the end as mc_monitor_stats does, :1851-1925).  ``leshift`` / ``input_ref_enthalpy``: userparams.f90:41,57;
+    ``wl_swetnam`` / ``wl_alpha``: mc_moves.F90:1636-1653."""
     from . import lattice as lat
     from .energy import EnergyModule
-    from .schedule import WangLandauSchedule, delta_g_from_hist, log_unbiased_norm
+    from .schedule import WangLandauSchedule, WindowSchedules, delta_g_from_hist, log_unbiased_norm
     from .sweep import MuGrid, WalkerFarm
 
+    if parallel_strategy not in ("mw", "dd"):
+        raise ValueError("Unknown parallel_strategy")                      # mc_moves.F90:720
+    dd = parallel_strategy == "dd"
     n = len(x_pair[0])
     em = EnergyModule(n, 2 * walkers, device=device)
     for w in range(walkers):
@@ -57,9 +66,29 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         grid = MuGrid(nbins, -mu_range, mu_range)
         farm = WalkerFarm(em, 2, temperature, 1.1, grid=grid, weight=weight, pressure_au=pressure_atm / 2.90363081e8)
         comms = farm.local_comms() if comms is None else comms             # one exchange object throughout
-        sched = WangLandauSchedule(grid.nbins, wl_factor, wl_schedule=wl_schedule, wl_flattol=wl_flattol,
-                                   wl_minhist=wl_minhist, wl_useinvt=wl_useinvt, samplerun=samplerun, outdir=outdir)
+        skw = dict(wl_schedule=wl_schedule, wl_flattol=wl_flattol, wl_minhist=wl_minhist, wl_useinvt=wl_useinvt,
+                   wl_swetnam=wl_swetnam, samplerun=samplerun, outdir=outdir)
+        if dd:                                                             # :659-709: one window per walker
+            sched = WindowSchedules(grid, comms.world_size * walkers, window_overlap, comms.rank * walkers, walkers,
+                                    wl_factor, **skw)
+            farm.set_windows(sched.windows)
+            farm.dd(True, eq_mc_cycles)
+            wrow = np.tile(farm.weight, (walkers, 1))                      # :808-812: only the window's part of the weights
+            for k, w_ in enumerate(sched.windows):
+                wrow[k, :w_["start_bin"] - 1] = 0.0
+                wrow[k, w_["end_bin"]:] = 0.0
+            farm.set_tables_range(1, weight=wrow)
+        else:
+            sched = WangLandauSchedule(grid.nbins, wl_factor, **skw)
         sched.adopt_file_factor(file_wl_factor)                            # mc_moves.F90:751-760,816-821
+        if leshift:                                                        # main.f90:146-150
+            ref = input_ref_enthalpy
+            if ref is None or not np.any(np.abs(ref) > np.finfo(np.float64).tiny):
+                ref = farm.starting_enthalpy(1, npt)
+            farm.leshift(ref)
+        if wl_swetnam:
+            farm.swetnam(True, wl_alpha, wl_factor)
+            farm.set_factors(wl_factor=np.full(walkers, sched.wl_factors[0] if dd else sched.wl_factor))
         lun = 0.0
         if samplerun:                                                      # :778-806
             lun = log_unbiased_norm(np.zeros(grid.nbins) if weight is None else weight, grid.av_binwidth,
@@ -67,13 +96,19 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                                     comms.world_size * walkers, n)
 
         def set_options(cyc):
-            farm.options(record=cyc >= eq_mc_cycles, samplerun=samplerun, always_switch=True, npt=npt,
-                         wl_factor=sched.move_factor(cyc, n), log_unbiased_norm=lun)        # :1615,1655-1657
+            if dd:                                                 # per-window increments (Swetnam's live on the device)
+                farm.options(record=cyc >= eq_mc_cycles, samplerun=samplerun, always_switch=True, npt=npt,
+                             wl_factor=0.0, log_unbiased_norm=lun)
+                if not wl_swetnam:
+                    farm.set_factors(wl_factor=sched.move_factors(cyc, n))
+            else:
+                farm.options(record=cyc >= eq_mc_cycles, samplerun=samplerun, always_switch=True, npt=npt,
+                             wl_factor=sched.move_factor(cyc, n), log_unbiased_norm=lun)    # :1615,1655-1657
 
         if npt:                                                    # io.f90:171-172: vol 1/N against trans 0.5
             farm.moves(trans_prob=0.5, vol_prob=1.0 / n, dv_max_ang=0.924)
-        for w in range(1, walkers + 1):
-            farm.set_state(w, 1, farm.initial_mu(w))
+        for w in range(1, walkers + 1):                            # :703-704: a window on one side of mu = 0 fixes the lattice
+            farm.set_state(w, (sched.windows[w - 1]["ls"] or 1) if dd else 1, farm.initial_mu(w))
         t0 = time.perf_counter()
         synced, events, delta_g = None, [], None
         def ends_a_stretch(c):
@@ -98,27 +133,43 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             farm.sweep_launch(n * (cyc - first + 1), seed=seed + rank, move0=(first - 1) * n)
             if cyc % mpi_sync_int == 0:                            # mc_moves.F90:258-276
                 em.sync()
-                if npt:
+                if npt or dd:
                     farm.check_flags()
-                synced = farm.synchronise(comms, regauge=regauge)
+                if not dd:                                         # (:270-272: the windows exchange nothing)
+                    synced = farm.synchronise(comms, regauge=regauge)
             if cyc % flat_chk_int == 0:                            # :291-294
                 em.sync()
-                ev = sched.check_flatness(cyc, n, farm, comms)
-                if ev["action"] != "none":
-                    events.append(ev)
+                if dd:
+                    events += [dict(action=what, cycle=cyc, walker=comms.rank * walkers + k - 1)   # 'walker' = the window's rank
+                               for k, what in sched.check_flatness(cyc, n, farm)]
+                else:
+                    ev = sched.check_flatness(cyc, n, farm, comms)
+                    if ev["action"] != "none":
+                        events.append(ev)
             if samplerun and cyc % deltaG_int == 0:                # :302-306
                 em.sync()
-                synced = farm.synchronise(comms, regauge=regauge)  # comms_allreduce_uhist (:2532) with the rest
-                dg, per, normp = delta_g_from_hist(synced[2], grid.binwidth, n, temperature)
+                if dd:                                             # comms_join_uhist (:2535)
+                    joined_u = comms.join_uhist(farm.tables_range()[2], window_overlap)
+                else:
+                    synced = farm.synchronise(comms, regauge=regauge)  # comms_allreduce_uhist (:2532) with the rest
+                    joined_u = synced[2]
+                dg, per, normp = delta_g_from_hist(joined_u, grid.binwidth, n, temperature, beta_dh=farm.beta_dh())
                 delta_g = dict(cycle=cyc, kT=dg, **{"per_molecule_" + k: v for k, v in per.items()})
                 if outdir is not None and comms.rank == 0:         # :2590-2613
                     with open(os.path.join(outdir, "unbiased_histogram_%010d.dat" % cyc), "w") as fh:
                         for m_, p_ in zip(grid.mu_bin, normp):
                             fh.write(f"  {float(m_)!r}        {float(p_)!r}\n")
         em.sync()
-        if npt:
+        if npt or dd:
             farm.check_flags()                                     # every walker, not only the ones read out below
         wall = time.perf_counter() - t0
+        joined = None
+        if dd:                                                     # mc_monitor_stats, :1883-1886
+            facs = farm.factors()[0] if wl_swetnam else sched.wl_factors
+            joined = dict(weight=comms.join_eta(farm.tables_range()[0], window_overlap),
+                          wl_factor=comms.get_max(float(np.max(facs))))
+            if samplerun:
+                joined["unbiased_hist"] = comms.join_uhist(farm.tables_range()[2], window_overlap)
         states = [farm.state(w) for w in range(1, min(walkers, 32) + 1)]
         fresh = em.model_energy_batch(1, 2)
         out = dict(walkers=walkers, cycles=cycles, molecules=n, moves=walkers * cycles * n, wall_s=wall,
@@ -129,9 +180,14 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                    volume_moves_walker1=farm.volume_moves(1) if npt else None,
                    histogram_total=None if synced is None else float(synced[1].sum()),
                    weight_max=None if synced is None else float(synced[0].max()),
-                   wl_factor=sched.wl_factor, wl_invt_active=sched.invt_active, flatness_events=events,
-                   delta_g=delta_g)
+                   wl_factor=(joined["wl_factor"] if dd else float(farm.factors(1, 1)[0][0]) if wl_swetnam else sched.wl_factor),
+                   wl_invt_active=sched.invt_active, flatness_events=events, delta_g=delta_g,
+                   ref_enthalpy=farm.ref_enthalpy)
         out["tables"] = synced
+        out["joined"] = joined
+        if dd:
+            out["windows"] = sched.windows
+            out["in_window"] = farm.factors()[2].tolist()
         out["walker1_tables"] = farm.tables(1)
         out["walker1_positions"] = [farm.positions(1), farm.positions(2)]
         return out
@@ -154,6 +210,12 @@ def main():
     ap.add_argument("--wl-minhist", type=int, default=20)
     ap.add_argument("--wl-useinvt", action="store_true")
     ap.add_argument("--outdir", default=None, help="directory for wlf.dat / eta_weights.dat_* / histogram.dat_*")
+    ap.add_argument("--strategy", default="mw", choices=["mw", "dd"], help="parallel_strategy")
+    ap.add_argument("--window-overlap", type=int, default=2)
+    ap.add_argument("--eq-cycles", type=int, default=0, help="eq_mc_cycles")
+    ap.add_argument("--leshift", action="store_true")
+    ap.add_argument("--wl-swetnam", action="store_true")
+    ap.add_argument("--wl-alpha", type=float, default=1.0)
     ap.add_argument("--regauge", action="store_true",
                     help="exchange step sums the weight increments proper and subtracts the window minimum once "
                          "(default: the reference's arithmetic, comms_mpi.f90:256-270)")
@@ -177,9 +239,16 @@ def main():
     res = run([z1["h"], z2["h"]], [z1["xyz"], z2["xyz"]], args.walkers, args.cycles, mpi_sync_int=args.sync,
               device=local, comms=comms, rank=rank, npt=args.npt, wl_factor=args.wl_factor, flat_chk_int=args.flat_chk,
               wl_schedule=args.wl_schedule, wl_flattol=args.wl_flattol, wl_minhist=args.wl_minhist,
-              wl_useinvt=args.wl_useinvt, outdir=args.outdir, regauge=args.regauge)
+              wl_useinvt=args.wl_useinvt, outdir=args.outdir, regauge=args.regauge, parallel_strategy=args.strategy,
+              window_overlap=args.window_overlap, eq_mc_cycles=args.eq_cycles, leshift=args.leshift,
+              wl_swetnam=args.wl_swetnam, wl_alpha=args.wl_alpha)
     tabs = res.pop("tables")
     res.pop("walker1_tables"), res.pop("walker1_positions")
+    joined = res.pop("joined")
+    if joined is not None:
+        tabs = (joined["weight"], joined["weight"])
+        res["joined_weight_range"] = [float(joined["weight"].min()), float(joined["weight"].max())]
+    res.pop("windows", None)
     if world > 1:
         t = torch.tensor(np.concatenate(tabs[:2]), dtype=torch.float64,
                          device=torch.device("cuda", local) if args.backend == "nccl" else "cpu")

@@ -8,12 +8,13 @@ between the device-resident move driver and the exchange step.
     mc_compute_deltaG_from_hist    mc_moves.F90:2498-2621   delta_g_from_hist
 
 All of it is O(nbins) arithmetic once every flat_chk_int (default 10^4) cycles: it stays on the host, on the tables the
-farm already brings over for the exchange step.  Parallel strategy 'mw' (every walker samples the whole range); the
-window decomposition ('dd') of the flatness check differs only in that nothing is exchanged and each rank looks at its
-own window -- pass ``comms=None`` and the window through ``start_bin`` / ``end_bin``.
+farm already brings over for the exchange step.  Parallel strategy 'mw' (every walker samples the whole range):
+:class:`WangLandauSchedule`, one for the whole job.  Window decomposition ('dd'): every walker is a rank of the
+reference with its own window, histogram, increment and first-cycle state, nothing is exchanged
+(:class:`WindowSchedules`, mc_moves.F90:2002-2016,2114-2126).
 
-Adam Swetnam's per-move increment (wl_swetnam, mc_moves.F90:1636-1653; off by default and in every shipped example)
-is not implemented: asking for it raises.
+Adam Swetnam's per-move increment (wl_swetnam, mc_moves.F90:1636-1653) lives on the device (mw_sweep_swetnam); here it
+only switches the flatness test off, as wl_invt_active does (:2018).
 """
 from __future__ import annotations
 
@@ -32,8 +33,7 @@ class WangLandauSchedule:
 
     def __init__(self, nbins, wl_factor, wl_schedule=0, wl_flattol=0.05, wl_minhist=20, wl_useinvt=False,
                  wl_swetnam=False, samplerun=False, start_bin=1, end_bin=None, invt_dump_int=500000, outdir=None):
-        if wl_swetnam:
-            raise NotImplementedError("wl_swetnam (per-move increment from the histogram's r.m.s. deviation) is not built")
+        self.wl_swetnam = bool(wl_swetnam)
         if wl_schedule not in (0, 1, 2):
             raise ValueError("Error - unknown wl_schedule value")          # mc_moves.F90:2051
         self.nbins = int(nbins)
@@ -82,13 +82,8 @@ class WangLandauSchedule:
         win = hist[self.start_bin - 1:self.end_bin]
         av = _seqsum(win) / float(len(win))                                # :1983-1989
         out["most_pct"], out["least_pct"] = 100.0 * hist.max() / av, 100.0 * hist.min() / av   # :1997-1998
-        if not self.invt_active:                                           # :2018 (wl_swetnam is never set here)
-            if self.wl_schedule == 0:                                      # within wl_flattol of the mean
-                flat = not bool(np.any(np.abs(win - av) / av > self.wl_flattol))
-            elif self.wl_schedule == 1:                                    # every bin visited wl_minhist times
-                flat = not (_nint(win.min()) < self.wl_minhist)
-            else:                                                          # every bin above (1 - wl_flattol) of the mean
-                flat = not bool(np.any(win < (1.0 - self.wl_flattol) * av))
+        if not (self.invt_active or self.wl_swetnam):                      # :2018
+            flat = self._is_flat(win, av)
             if comms is not None:                                          # :2055
                 flat = comms.bcast_flag(flat)
             out["flat"] = flat
@@ -109,13 +104,88 @@ class WangLandauSchedule:
                 self.wl_factor = wl_invt
                 out["invt"] = True
         else:                                                              # :2145-2181: periodic dumps only
+            if self.wl_swetnam:                                            # rank 0's own increment lives on the device
+                self.wl_factor = float(farm.factors(1, 1)[0][0])
             if self.outdir is not None and (comms is None or comms.rank == 0) and cycle % self.invt_dump_int == 0:
                 w, _, _ = farm.tables(1)
                 mwio.append_wlf(self.outdir, [(cycle, self.wl_factor)], replace=False)
                 mwio.write_tagged_tables(self.outdir, "%020d" % cycle, self.wl_factor, farm.grid.mu_bin, w, hist)
-            out["action"] = "invt"
+            out["action"] = "invt" if self.invt_active else "swetnam"
         out["wl_factor"] = self.wl_factor
         return out
+
+
+    def _is_flat(self, win, av):
+        if self.wl_schedule == 0:                                          # within wl_flattol of the mean, :2024-2031
+            return not bool(np.any(np.abs(win - av) / av > self.wl_flattol))
+        if self.wl_schedule == 1:                                          # every bin visited wl_minhist times, :2033-2039
+            return not (_nint(win.min()) < self.wl_minhist)
+        return not bool(np.any(win < (1.0 - self.wl_flattol) * av))        # above (1 - wl_flattol) of the mean, :2041-2048
+
+    def check_window(self, cycle, nwater, hist):
+        """mc_check_flatness as ONE rank of a 'dd' run sees it (no exchange, its own histogram, the window
+        start_bin..end_bin; flat: histogram reset and increment halved, but no weight shift and no wlf.dat,
+        :2114-2126).  Returns (what happened, whether the rank's histogram is to be zeroed)."""
+        if self.samplerun or _seqsum(hist) < np.finfo(np.float64).tiny:    # :1962
+            return "none", False
+        if self.firstcycle and not self.histogram_reset and _nint(hist.min()) > self.wl_minhist:   # :1972-1980
+            self.histogram_reset = True
+            return "first reset", True
+        win = hist[self.start_bin - 1:self.end_bin]
+        av = _seqsum(win) / float(len(win))
+        if self.invt_active or self.wl_swetnam:
+            return "invt" if self.invt_active else "swetnam", False
+        what, zero = "checked", False
+        if self._is_flat(win, av):
+            self.wl_factor *= 0.5
+            self.firstcycle = False
+            what, zero = "halved", True
+        wl_invt = float(self.nbins) / float(cycle * nwater)                # :2136-2143
+        if self.wl_factor < wl_invt and self.wl_factor > np.finfo(np.float64).tiny and self.wl_useinvt:
+            self.invt_active = True
+            self.wl_factor = wl_invt
+        return what, zero
+
+
+class WindowSchedules:
+    """parallel_strategy = 'dd' for a farm: walker k of this process is rank ``rank0 + k`` of ``size`` windows, each with
+    its own WangLandauSchedule state (mc_moves.F90:80-85 are per-rank variables)."""
+
+    def __init__(self, grid, size, overlap, rank0, count, wl_factor, **kw):
+        self.windows = [grid.window(rank0 + k, size, overlap) for k in range(count)]
+        self.scheds = [WangLandauSchedule(grid.nbins, wl_factor, start_bin=w["start_bin"], end_bin=w["end_bin"], **kw)
+                       for w in self.windows]
+        self.overlap, self.size = int(overlap), int(size)
+
+    @property
+    def wl_factors(self):
+        return np.array([s.wl_factor for s in self.scheds])
+
+    @property
+    def invt_active(self):
+        return any(s.invt_active for s in self.scheds)
+
+    def adopt_file_factor(self, f):
+        for s in self.scheds:
+            s.adopt_file_factor(f)
+
+    def move_factors(self, cycle, nwater):
+        return np.array([s.move_factor(cycle, nwater) for s in self.scheds])
+
+    def check_flatness(self, cycle, nwater, farm):
+        """Every walker looks at its own histogram over its own window; returns the list of (walker, what)."""
+        _, hist, _ = farm.tables_range(1, len(self.scheds))
+        events, dirty = [], False
+        for k, s in enumerate(self.scheds):
+            what, zero = s.check_window(cycle, nwater, hist[k])
+            if zero:
+                hist[k] = 0.0
+                dirty = True
+            if what not in ("none", "checked"):
+                events.append((k + 1, what))
+        if dirty:
+            farm.set_tables_range(1, histogram=hist)
+        return events
 
 
 def _nint(x):

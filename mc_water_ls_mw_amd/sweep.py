@@ -16,6 +16,14 @@ KB = 1.0 / 3.1577465e5          # constants.f90:39, Hartree / Kelvin
 _dp = ctypes.POINTER(ctypes.c_double)
 
 
+def _seqsum(a):
+    """Left-to-right sum, as Fortran's sum() over a short array forms it here (flang: sequential)."""
+    t = 0.0
+    for v in a:
+        t += float(v)
+    return t
+
+
 def _ipow(r, n):
     acc, b = 1.0, r
     while n > 0:
@@ -58,6 +66,32 @@ class MuGrid:
         self.start_bin, self.end_bin = 1, nbins
         self.my_mu_min, self.my_mu_max = self.mu_min, self.mu_max
 
+    def window(self, rank, size, overlap):
+        """parallel_strategy = 'dd' (mc_moves.F90:659-709): the window of rank `rank` of `size` -- bins (1-based,
+        inclusive), limits of mu, and the lattice that has to be active there (None: either)."""
+        bpw = self.nbins // size                                           # :663
+        bw = self.binwidth
+        if rank == 0:                                                      # :665-673
+            s, e = 1, bpw + overlap
+            lo, hi = self.mu_min, self.mu_min + _seqsum(bw[:e])
+        elif rank < size - 1:                                              # :677-688
+            s, e = rank * bpw - overlap, (rank + 1) * bpw + overlap
+            lo, hi = self.mu_min + _seqsum(bw[:s - 1]), self.mu_min + _seqsum(bw[:e])
+        else:                                                              # :690-698
+            s, e = rank * bpw - overlap, self.nbins
+            lo, hi = self.mu_min + _seqsum(bw[:s - 1]), self.mu_max
+        if size == 1:
+            e, hi = bpw + overlap, self.mu_min + _seqsum(bw[:bpw + overlap])   # (rank 0's branch is the only one taken)
+        ls = 1 if hi < 0.0 else (2 if lo > 0.0 else None)                  # :703-704
+        return dict(start_bin=s, end_bin=e, mu_min=lo, mu_max=hi, ls=ls)
+
+    def restricted(self, w):
+        """A copy of the grid whose walker is confined to window `w` (my_start_bin .. my_mu_max of that rank)."""
+        import copy
+        g = copy.copy(self)
+        g.start_bin, g.end_bin, g.my_mu_min, g.my_mu_max = w["start_bin"], w["end_bin"], w["mu_min"], w["mu_max"]
+        return g
+
     @staticmethod
     def _ratio(a, s, ns):                                  # :583-596
         r = 1.1
@@ -85,6 +119,8 @@ class WalkerFarm:
         g = self.grid
         self.weight = np.zeros(g.nbins) if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
         self.eta_interp = bool(eta_interp)
+        self.dref = 0.0                                      # ref_enthalpy(1) - ref_enthalpy(2) when leshift is on
+        self.ref_enthalpy = None
         mb, bw = np.ascontiguousarray(g.mu_bin), np.ascontiguousarray(g.binwidth)
         em._chk(self.L.mw_sweep_configure(
             self.nlat, ctypes.c_double(self.beta), ctypes.c_double(self.max_trans), g.nbins, int(self.eta_interp),
@@ -100,6 +136,79 @@ class WalkerFarm:
         self.em._chk(self.L.mw_sweep_options(int(record), int(samplerun), int(always_switch), int(npt),
                                              ctypes.c_double(self.grid.av_binwidth), ctypes.c_double(wl_factor),
                                              ctypes.c_double(log_unbiased_norm), ctypes.c_double(self.pressure)))
+
+    # -- the run-control options beyond the 'mw' defaults ---------------------------------
+    def leshift(self, ref_enthalpy=None):
+        """leshift (userparams.f90:41): the lattices' reference enthalpies are taken out of the order parameter
+        (mc_moves.F90:860,1371,1526,1584,2256,2401) and of the switch acceptance (:1567,1572).  ``ref_enthalpy``:
+        the pair (Hartree), e.g. input_ref_enthalpy; None switches it off.  main.f90:146-150 takes the starting
+        configuration's model_energy (+ pressure*volume under npt): :meth:`starting_enthalpy`."""
+        self.ref_enthalpy = None if ref_enthalpy is None else (float(ref_enthalpy[0]), float(ref_enthalpy[1]))
+        r1, r2 = (0.0, 0.0) if self.ref_enthalpy is None else self.ref_enthalpy
+        self.dref = r1 - r2
+        self.em._chk(self.L.mw_sweep_leshift(ctypes.c_double(r1), ctypes.c_double(r2)))
+
+    def starting_enthalpy(self, walker=1, npt=False):
+        """ref_enthalpy as main.f90:146-147 forms it from a walker's current full-box energies."""
+        b = (walker - 1) * 2
+        e, v = self.em.model_energy, self.em.volume
+        return tuple(float(e[b + l] + (self.pressure * v[b + l] if npt else 0.0)) for l in range(2))
+
+    def beta_dh(self):
+        """beta (H_ref(2) - H_ref(1)), the correction mc_compute_deltaG_from_hist adds back (mc_moves.F90:2586)."""
+        return -self.beta * self.dref
+
+    def swetnam(self, on, wl_alpha=1.0, orig_wl_factor=0.0):
+        """wl_swetnam (mc_moves.F90:1636-1653): every walker recomputes its own increment after each recorded move from
+        the r.m.s. deviation of its histogram from flat; per-walker increments and visit totals: :meth:`factors`."""
+        g = self.grid
+        self.em._chk(self.L.mw_sweep_swetnam(int(bool(on)), ctypes.c_double(wl_alpha), ctypes.c_double(orig_wl_factor),
+                                             ctypes.c_double(g.mu_min), ctypes.c_double(g.mu_max)))
+
+    def dd(self, on, eq_mc_cycles=0):
+        """parallel_strategy = 'dd' (mc_moves.F90:181-210,243-248): until cycle eq_mc_cycles a walker outside its window
+        carries no weight and attempts no lattice switch; one still outside at eq_mc_cycles raises the flag
+        :meth:`check_flags` reports.  Windows: :meth:`set_windows`; increments are per walker (:meth:`set_factors`)."""
+        self.em._chk(self.L.mw_sweep_dd(int(bool(on)), int(eq_mc_cycles)))
+
+    def set_windows(self, windows, first_walker=1):
+        """One window (MuGrid.window) per walker from ``first_walker`` on; None: everybody back on the grid's own."""
+        _ip = ctypes.POINTER(ctypes.c_int)
+        if windows is None:
+            self.em._chk(self.L.mw_sweep_windows(1, self.nwalkers, None, None, None, None))
+            return
+        sb = np.ascontiguousarray([w["start_bin"] for w in windows], dtype=np.int32)
+        eb = np.ascontiguousarray([w["end_bin"] for w in windows], dtype=np.int32)
+        lo = np.ascontiguousarray([w["mu_min"] for w in windows], dtype=np.float64)
+        hi = np.ascontiguousarray([w["mu_max"] for w in windows], dtype=np.float64)
+        self.em._chk(self.L.mw_sweep_windows(first_walker, len(windows), sb.ctypes.data_as(_ip), eb.ctypes.data_as(_ip),
+                                             lo.ctypes.data_as(_dp), hi.ctypes.data_as(_dp)))
+
+    def set_factors(self, wl_factor=None, sumhist=None, first_walker=1):
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (wl_factor, sumhist)]
+        count = len(next(a for a in arrs if a is not None))
+        self.em._chk(self.L.mw_sweep_set_factors(first_walker, count, *[None if a is None else a.ctypes.data_as(_dp) for a in arrs]))
+
+    def factors(self, first_walker=1, count=None):
+        """(wl_factor, Swetnam visit total, walker_in_window) per walker."""
+        count = self.nwalkers - first_walker + 1 if count is None else count
+        f, sh, iw = np.zeros(count), np.zeros(count), np.zeros(count, dtype=np.int32)
+        self.em._chk(self.L.mw_sweep_get_factors(first_walker, count, f.ctypes.data_as(_dp), sh.ctypes.data_as(_dp),
+                                                 iw.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return f, sh, iw.astype(bool)
+
+    def tables_range(self, first_walker=1, count=None):
+        """(weight, histogram, unbiased_hist), each count x nbins."""
+        count = self.nwalkers - first_walker + 1 if count is None else count
+        nb = self.grid.nbins
+        w, h, u = np.zeros((count, nb)), np.zeros((count, nb)), np.zeros((count, nb))
+        self.em._chk(self.L.mw_sweep_get_tables_range(first_walker, count, w.ctypes.data_as(_dp), h.ctypes.data_as(_dp), u.ctypes.data_as(_dp)))
+        return w, h, u
+
+    def set_tables_range(self, first_walker, weight=None, histogram=None, unbiased_hist=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (weight, histogram, unbiased_hist)]
+        count = len(next(a for a in arrs if a is not None))
+        self.em._chk(self.L.mw_sweep_set_tables_range(first_walker, count, *[None if a is None else a.ctypes.data_as(_dp) for a in arrs]))
 
     def moves(self, trans_prob=0.5, vol_prob=0.0, dv_max_ang=0.924):
         """Move mix of mc_cycle (mc_moves.F90:157-166): transP = trans/(trans + vol); volume moves change one
@@ -117,7 +226,8 @@ class WalkerFarm:
     def check_flags(self):
         """Fail loudly if a volume move of ANY walker outgrew the image-vector table since the last call (such a
         move is rejected and undone on the device, so the walker's state is consistent, but its chain has left
-        mc_volume's)."""
+        mc_volume's), or if a 'dd' walker was still outside its window at eq_mc_cycles (the reference stops there,
+        mc_moves.F90:187-201)."""
         self.em._chk(self.L.mw_sweep_check_flags(1, self.nwalkers))
 
     def sync_cells(self):
@@ -172,6 +282,7 @@ class WalkerFarm:
         v = em.volume
         for w in range(self.nwalkers):                                     # :2398-2400
             mu = e[2 * w] + self.pressure * v[2 * w] - e[2 * w + 1] - self.pressure * v[2 * w + 1]
+            mu = mu - self.dref                                            # leshift, :2401
             mu = mu * self.beta - n * math.log(v[2 * w] / v[2 * w + 1])
             self.set_state(w + 1, self.state(w + 1)["ls"], mu)
 
@@ -262,12 +373,13 @@ class WalkerFarm:
         self.em._chk(self.L.mw_sweep_set_tables_range(1, nw, np.ascontiguousarray(w).ctypes.data_as(_dp), None, None))
 
     def initial_mu(self, walker):
-        """ls_mu as mc_init / mc_lattice_switch form it (mc_moves.F90:1581-1583), without leshift."""
+        """ls_mu as main.f90:170-174 / mc_init (mc_moves.F90:857-862) form it."""
         if self.nlat == 1:
             return 0.0
         b = (walker - 1) * 2
         e, v, n = self.em.model_energy, self.em.volume, self.em.nwater
         mu = (e[b] + self.pressure * v[b]) - (e[b + 1] + self.pressure * v[b + 1])
+        mu = mu - self.dref                                                # leshift, :860
         return mu * self.beta - n * math.log(v[b] / v[b + 1])
 
     def set_state(self, walker, ls=1, ls_mu=None):

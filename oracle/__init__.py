@@ -229,6 +229,27 @@ class SweepOracle:
         assert rc == 0
         st.ls_mu = mu.value
 
+    # run options the reference keeps in module variables (they apply to every later call until changed)
+    def set_leshift(self, ref1=0.0, ref2=0.0):
+        self.L.mwo_set_leshift(ctypes.c_double(ref1), ctypes.c_double(ref2))
+
+    def set_swetnam(self, on, alpha=1.0, orig_wl_factor=0.0, mu_min=0.0, mu_max=0.0, sumhist=0.0):
+        self.L.mwo_set_swetnam(int(on), ctypes.c_double(alpha), ctypes.c_double(orig_wl_factor), ctypes.c_double(mu_min),
+                               ctypes.c_double(mu_max), ctypes.c_double(sumhist))
+
+    def get_swetnam(self):
+        a, b = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self.L.mwo_get_swetnam(ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    def set_dd(self, on, eq_cycles=0, in_window=False):
+        self.L.mwo_set_dd(int(on), int(eq_cycles), int(in_window))
+
+    def get_dd(self):
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        self.L.mwo_get_dd(ctypes.byref(a), ctypes.byref(b))
+        return bool(a.value), bool(b.value)
+
     def cycle(self, nmoves, seed, walker, move0, hs, xs, beta, max_trans, grid, weight, histogram, unbiased_hist,
               eta_interp=True, ls=1, ls_mu=0.0, model_energy=None, lists=None, record=True, samplerun=True,
               always_switch=True, npt=False, wl_factor=0.0, log_unbiased_norm=0.0, pressure=0.0, maxneigh=MAXNEIGH):

@@ -414,7 +414,29 @@ void mwo_recipmatrix(const double h[9], double rc[9])                        /* 
     for (int i = 0; i < 9; ++i) rc[i] = rc[i] * 2.0 * Pi / vol;
 }
 
-/* mc_update_wl_bins, mc_moves.F90:1597-1689 (default schedule) */
+/* ---- run options the reference keeps in module variables (userparams / mc_moves), set by the tests ------------------
+ * leshift (userparams.f90:41; main.f90:146-150,173): g_dref = ref_enthalpy(1) - ref_enthalpy(2), 0 = off.
+ * wl_swetnam (mc_moves.F90:1636-1653): increment recomputed from the histogram after every recorded move.
+ * parallel_strategy = 'dd' (mc_moves.F90:181-210,243-248,872,913): walker_in_window and the equilibration rules. */
+static double g_dref = 0.0;
+static int g_swetnam = 0;
+static double g_wl_alpha = 1.0, g_orig_wl_factor = 0.0, g_mu_min = 0.0, g_mu_max = 0.0, g_sumhist = 0.0, g_wl_factor_now = 0.0;
+static int g_dd = 0, g_eq_cycles = 0, g_in_window = 1, g_not_in_window_at_eq = 0;
+
+void mwo_set_leshift(double ref1, double ref2) { g_dref = ref1 - ref2; }
+void mwo_set_swetnam(int on, double alpha, double orig_wl_factor, double mu_min, double mu_max, double sumhist)
+{
+    g_swetnam = on; g_wl_alpha = alpha; g_orig_wl_factor = orig_wl_factor; g_mu_min = mu_min; g_mu_max = mu_max; g_sumhist = sumhist;
+}
+void mwo_get_swetnam(double *sumhist, double *wl_factor) { *sumhist = g_sumhist; *wl_factor = g_wl_factor_now; }
+void mwo_set_dd(int on, int eq_cycles, int in_window) { g_dd = on; g_eq_cycles = eq_cycles; g_in_window = on ? in_window : 1; g_not_in_window_at_eq = 0; }
+void mwo_get_dd(int *in_window, int *failed) { *in_window = g_in_window; *failed = g_not_in_window_at_eq; }
+
+/* eta_weight with the 'dd' rule of :913 in front: a walker that has not reached its window carries no weight (the
+ * reference returns there WITHOUT assigning the function result; 0 is what its comment asks for) */
+static double eta_w(const mwo_eta *g, double mu) { return g_in_window ? mwo_eta_weight(g, mu) : 0.0; }
+
+/* mc_update_wl_bins, mc_moves.F90:1597-1689 */
 static void update_wl_bins(const mwo_eta *eta, const mwo_cycle_opts *o, double ls_mu,
                            double *histogram, double *unbiased_hist, double *weight)
 {
@@ -424,22 +446,37 @@ static void update_wl_bins(const mwo_eta *eta, const mwo_cycle_opts *o, double l
     histogram[k - 1] = histogram[k - 1] + o->av_binwidth / eta->binwidth[k - 1];          /* :1621 */
     if (o->samplerun) {                                                       /* :1625-1631 */
         const double incr = o->av_binwidth / eta->binwidth[k - 1];
-        unbiased_hist[k - 1] = unbiased_hist[k - 1] + incr * exp(mwo_eta_weight(eta, ls_mu) - o->log_unbiased_norm);
+        unbiased_hist[k - 1] = unbiased_hist[k - 1] + incr * exp(eta_w(eta, ls_mu) - o->log_unbiased_norm);
         return;
     }
-    const double incr = o->wl_factor;                                         /* :1677 */
+    double wl_factor = o->wl_factor;
+    if (g_swetnam) {                                                          /* :1636-1653 */
+        g_sumhist = g_sumhist + 1.0;
+        wl_factor = 0.0;
+        for (int i = 1; i <= eta->nbins; ++i) {
+            const double binfrac = eta->binwidth[i - 1] / (g_mu_max - g_mu_min - 1.0);
+            const double dev = histogram[i - 1] * eta->binwidth[i - 1] / g_sumhist - binfrac;
+            wl_factor = wl_factor + dev * dev;
+        }
+        wl_factor = sqrt(wl_factor / (double)eta->nbins);
+        wl_factor = log(wl_factor);
+        wl_factor = wl_factor * g_wl_alpha * (double)eta->nbins;
+        wl_factor = wl_factor < g_orig_wl_factor ? wl_factor : g_orig_wl_factor;
+        g_wl_factor_now = wl_factor;
+    }
+    const double incr = wl_factor;                                            /* :1677 */
     weight[k - 1] = weight[k - 1] + o->av_binwidth * incr / eta->binwidth[k - 1];           /* :1680 */
     double minbin = weight[eta->start_bin - 1];                               /* :1682-1685 */
     for (int i = eta->start_bin; i <= eta->end_bin; ++i) if (weight[i - 1] < minbin) minbin = weight[i - 1];
     for (int i = eta->start_bin; i <= eta->end_bin; ++i) weight[i - 1] = weight[i - 1] - minbin;
 }
 
-/* mc_lattice_switch, mc_moves.F90:1536-1594 (leshift off); returns 1 if accepted */
+/* mc_lattice_switch, mc_moves.F90:1536-1594; returns 1 if accepted */
 static int lattice_switch(const mwo_eta *eta, const mwo_cycle_opts *o, double beta, int n, double x,
                           const double *model_energy, int *ls, double *ls_mu)
 {
     const int lsn = 3 - *ls;                                                  /* :1555 */
-    const double old_eta = mwo_eta_weight(eta, *ls_mu), new_eta = mwo_eta_weight(eta, *ls_mu);   /* :1557-1558 */
+    const double old_eta = eta_w(eta, *ls_mu), new_eta = eta_w(eta, *ls_mu);                     /* :1557-1558 */
     const double *E = model_energy - 1, *V = o->volume - 1;                   /* 1-based views */
     double diffkT;
     if (o->npt)                                                               /* :1561-1563 */
@@ -447,10 +484,12 @@ static int lattice_switch(const mwo_eta *eta, const mwo_cycle_opts *o, double be
                  - (double)n * log(V[lsn] / V[*ls]) + new_eta - old_eta;
     else                                                                      /* :1568 */
         diffkT = beta * E[lsn] - beta * E[*ls] + new_eta - old_eta;
+    diffkT = diffkT + (*ls == 1 ? beta * g_dref : -(beta * g_dref));          /* leshift: - beta ref(lsn) + beta ref(ls), :1567,1572 */
     double compare = exp(-diffkT);
     if (compare > 1.0) compare = 1.0;
     if (x < compare) {                                                        /* :1576-1590 */
         double mu = (E[1] + o->pressure * V[1]) - (E[2] + o->pressure * V[2]);
+        mu = mu - g_dref;                                                     /* :1584 */
         mu = mu * beta - (double)n * log(V[1] / V[2]);
         *ls_mu = mu;
         *ls = lsn;
@@ -512,6 +551,16 @@ static void sweep_impl(int nmoves, uint64_t seed, uint32_t walker, uint64_t move
     for (int mv = 0; mv < nmoves; ++mv) {
         double u[8];
         mwo_move_uniforms8(seed, walker, move0 + (uint64_t)mv, u);            /* u[0..5] as mwo_move_uniforms */
+        int cyc = 0;
+        if (g_dd) {                                                           /* top of mc_cycle, :181-210 */
+            const uint64_t mg = move0 + (uint64_t)mv;
+            cyc = (int)(mg / (uint64_t)n) + 1;
+            if (mg % (uint64_t)n == 0) {
+                if (cyc < g_eq_cycles) g_in_window = (ls_mu > eta->mu_lo && ls_mu < eta->mu_hi) ? 1 : 0;
+                else if (cyc == g_eq_cycles) { if (!g_in_window) g_not_in_window_at_eq = 1; }
+                else g_in_window = 1;
+            }
+        }
         const int lsn = nlat == 2 ? 3 - ls : 1;                               /* partner_lattice, :866-868 */
         int imol = (int)(u[0] * (double)n) + 1;                               /* :1001-1002 */
         if (imol > n) imol = n;
@@ -551,9 +600,9 @@ static void sweep_impl(int nmoves, uint64_t seed, uint32_t walker, uint64_t move
         if (nlat == 1) {
             diffkT = beta * deltaE[0];                                        /* :1106 */
         } else {
-            const double eta_old = mwo_eta_weight(eta, ls_mu);                /* :1112-1116 */
+            const double eta_old = eta_w(eta, ls_mu);                         /* :1112-1116 */
             ls_mu = ls_mu + (deltaE[0] - deltaE[1]) * beta;
-            const double eta_new = mwo_eta_weight(eta, ls_mu);
+            const double eta_new = eta_w(eta, ls_mu);
             diffkT = deltaE[ls - 1] * beta + eta_new - eta_old;
         }
         const double zeta = u[5];                                             /* :1145 */
@@ -573,7 +622,7 @@ static void sweep_impl(int nmoves, uint64_t seed, uint32_t walker, uint64_t move
         int sw = 0;
         if (opt && nlat == 2) {
             update_wl_bins(eta, opt, ls_mu, histogram, unbiased_hist, weight);                 /* mc_moves.F90:230 */
-            if (opt->always_switch) {                                                          /* :243-248 */
+            if (opt->always_switch && !(g_dd && cyc < g_eq_cycles)) {                         /* :243-248 */
                 sw = lattice_switch(eta, opt, beta, n, u[6], model_energy, &ls, &ls_mu);
                 if (sw && switches) ++*switches;
             }
@@ -589,7 +638,7 @@ static void sweep_impl(int nmoves, uint64_t seed, uint32_t walker, uint64_t move
 
 
 /* ------------------------------------------------------------------------------------------------
- * mc_volume, mc_moves.F90:1216-1534 (MINU and leshift off; ref_ljr, which only chain synchronisation
+ * mc_volume, mc_moves.F90:1216-1534 (MINU off; ref_ljr, which only chain synchronisation
  * reads, is not carried).
  * ------------------------------------------------------------------------------------------------ */
 static double det3(const double *m)                                           /* util.f90:16-41 */
@@ -655,11 +704,12 @@ int mwo_volume_move(const double u[4], int nlat, int n, double *xyz, double *h, 
     for (int l = 0; l < nlat; ++l) deltaE[l] = new_e[l] - old_e[l];           /* :1361 */
     double old_eta = 0.0, new_eta = 0.0;
     if (nlat == 2) {                                                          /* :1363-1371 */
-        old_eta = mwo_eta_weight(eta, *ls_mu);
+        old_eta = eta_w(eta, *ls_mu);
         double mu = (model_energy[0] + pressure * volume[0]) - (model_energy[1] + pressure * volume[1]);
+        mu = mu - g_dref;                                                     /* :1371 */
         mu = mu * beta - (double)n * log(volume[0] / volume[1]);
         *ls_mu = mu;
-        new_eta = mwo_eta_weight(eta, *ls_mu);
+        new_eta = eta_w(eta, *ls_mu);
     }
     const double x = u[3];                                                    /* :1378 */
     const double diffkT = beta * deltaE[ls - 1] + new_eta - old_eta + beta * pressure * (volume[ls - 1] - old_vol[ls - 1])
@@ -684,6 +734,7 @@ int mwo_volume_move(const double u[4], int nlat, int n, double *xyz, double *h, 
     }
     if (nlat == 2) {                                                          /* :1516-1520 */
         double mu = (model_energy[0] + pressure * volume[0]) - (model_energy[1] + pressure * volume[1]);
+        mu = mu - g_dref;                                                     /* :1526 */
         mu = mu * beta - (double)n * log(volume[0] / volume[1]);
         *ls_mu = mu;
     }
@@ -747,7 +798,7 @@ void mwo_sweep_full_ref(int nmoves, uint64_t seed, uint32_t walker, uint64_t mov
     g_ref_xyz = NULL;
 }
 
-/* mc_check_chain_synchronisation, mc_moves.F90:2217-2416 (leshift off) */
+/* mc_check_chain_synchronisation, mc_moves.F90:2217-2416 */
 int mwo_chain_sync(int n, double *xyz, const double *ref_xyz, double *h, const double *ref_h, double *volume,
                    double *ivect, int ivstride, int *nivect, int maxneigh,
                    const int *nn, const int *jn, const int *vn,
@@ -791,7 +842,8 @@ int mwo_chain_sync(int n, double *xyz, const double *ref_xyz, double *h, const d
     for (int l = 0; l < 2; ++l)                                                                                   /* :2395-2396 */
         model_energy[l] = mwo_model_energy(n, xyz + (size_t)3 * n * l, ivect + (size_t)3 * ivstride * l, maxneigh,
                                            nn + (size_t)n * l, jn + (size_t)n * maxneigh * l, vn + (size_t)n * maxneigh * l, NULL);
-    double mu = model_energy[0] + pressure * volume[0] - model_energy[1] - pressure * volume[1];                  /* :2398-2400 */
+    double mu = model_energy[0] + pressure * volume[0] - model_energy[1] - pressure * volume[1];                  /* :2398-2401 */
+    mu = mu - g_dref;
     *ls_mu = mu * beta - (double)n * log(volume[0] / volume[1]);
     return 0;
 }

@@ -135,6 +135,16 @@ typedef struct {
  * (nbins each; `eta->weight` must point at the same `weight` array) and, with always_switch, one
  * mc_lattice_switch attempt (mc_moves.F90:1536-1594).  Uniforms per move: mwo_move_uniforms8. */
 void mwo_move_uniforms8(uint64_t seed, uint32_t walker, uint64_t move, double u[8]);
+/* Run options the reference keeps in module variables; they apply to every later mwo_sweep_* / mwo_volume_move /
+ * mwo_chain_sync call until changed.  leshift: reference enthalpies (0, 0 = off; main.f90:146-150).  wl_swetnam
+ * (mc_moves.F90:1636-1653): `sumhist` is the visit total so far; mwo_get_swetnam returns it and the last increment.
+ * 'dd' (mc_moves.F90:181-210,243-248,913): in_window = walker_in_window at entry; mwo_get_dd returns it and whether the
+ * walker was outside its window at cycle eq_cycles (the reference stops there). */
+void mwo_set_leshift(double ref1, double ref2);
+void mwo_set_swetnam(int on, double alpha, double orig_wl_factor, double mu_min, double mu_max, double sumhist);
+void mwo_get_swetnam(double *sumhist, double *wl_factor);
+void mwo_set_dd(int on, int eq_cycles, int in_window);
+void mwo_get_dd(int *in_window, int *failed);
 void mwo_sweep_cycle(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0,
                      int nlat, int n, double *xyz, const double *h,
                      const double *ivect, int ivstride, int maxneigh,

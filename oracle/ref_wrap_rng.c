@@ -29,6 +29,8 @@
 static unsigned long long mw_move = 0;
 static int mw_phase = -1;           /* -1: not configured; 0: expect xi; 1..: index into the move's draws */
 static int mw_ndraws = 0, mw_switch = 0;
+static unsigned long long mw_switch_from = 0;   /* MW_WRAP_SWITCH_FROM_MOVE: first move that is followed by a switch attempt
+                                                   ('dd' runs attempt none while mc_cycle_num < eq_mc_cycles, mc_moves.F90:243-248) */
 static double mw_transp = 1.0, mw_u[8];
 
 double __wrap__QMrandomPrandom_uniform_random(void)
@@ -40,6 +42,8 @@ double __wrap__QMrandomPrandom_uniform_random(void)
         if (e && atoi(e) == 1) mw_switch = 1;
         e = getenv("MW_WRAP_CALLS_PER_MOVE");
         if (e && atoi(e) == 8) mw_switch = 1;
+        e = getenv("MW_WRAP_SWITCH_FROM_MOVE");
+        if (e) mw_switch_from = strtoull(e, 0, 10);
         mw_phase = 0;
     }
     if (mw_phase == 0) {
@@ -51,7 +55,7 @@ double __wrap__QMrandomPrandom_uniform_random(void)
     double v;
     if (mw_phase <= mw_ndraws) v = mw_u[mw_phase - 1];
     else v = mw_u[6];                                   /* the lattice-switch variate */
-    if (mw_phase == mw_ndraws + mw_switch) { mw_phase = 0; ++mw_move; }
+    if (mw_phase == mw_ndraws + ((mw_switch && mw_move >= mw_switch_from) ? 1 : 0)) { mw_phase = 0; ++mw_move; }
     else ++mw_phase;
     return v;
 }
@@ -63,8 +67,23 @@ double __wrap__QMrandomPrandom_uniform_random(void)
  * tests/test_schedule_pin.py to pin log_unbiased_norm and mc_compute_deltaG_from_hist); unset, the
  * reference's own serial behaviour is left alone. */
 extern int _QMcommsEsize;
+extern int _QMcommsEmyrank;
 __attribute__((constructor)) static void mw_wrap_comms_size(void)
 {
     const char *e = getenv("MW_WRAP_SIZE");
     if (e && atoi(e) > 0) _QMcommsEsize = atoi(e);
+}
+
+/* MW_WRAP_RANK=r (with MW_WRAP_SIZE=R): from mc_init on the serial program behaves as rank r of an R-rank run wherever
+ * it only consults comms::myrank / comms::size -- the 'dd' window assignment, the choice of the active lattice, the
+ * equilibration guard and the per-window flatness check (mc_moves.F90:181-210,659-709,2002-2016).  The input files are
+ * read by rank 0 only and "broadcast" (io.f90:106-145, init.f90:70-98), so the rank is poked AFTER that: energy_init
+ * (main.f90:115) is the last call before mc_init, and it is interposed here just to carry the poke.  The collectives
+ * stay the serial stubs, so nothing that needs another rank's data (the window joins) is pinned this way. */
+void __real__QMenergyPenergy_init(void);
+void __wrap__QMenergyPenergy_init(void)
+{
+    __real__QMenergyPenergy_init();
+    const char *e = getenv("MW_WRAP_RANK");
+    if (e && atoi(e) >= 0) _QMcommsEmyrank = atoi(e);
 }

@@ -25,8 +25,9 @@ def cycle_factor(st, cycle, nwater, nbins):
     return st["wl_factor"]
 
 
-def flatness_step(st, cycle, nwater, histogram, weight, start_bin=1, end_bin=None):
-    """In place on the lists/arrays `histogram` and `weight` (one rank).  Returns what happened."""
+def flatness_step(st, cycle, nwater, histogram, weight, start_bin=1, end_bin=None, dd=False):
+    """In place on the lists/arrays `histogram` and `weight` (one rank).  Returns what happened.  dd: the window
+    decomposition's branch of a flat histogram (:2114-2126): no weight shift, no wlf.dat, only reset + halving."""
     nbins = len(histogram)
     end_bin = nbins if end_bin is None else end_bin
     if sum(float(h) for h in histogram) < TINY:                                               # :1962
@@ -57,10 +58,11 @@ def flatness_step(st, cycle, nwater, histogram, weight, start_bin=1, end_bin=Non
                 if float(histogram[k]) < (1.0 - st["flattol"]) * av:
                     flat = False
         if flat:
-            mid = float(weight[nbins // 2])                                                   # :2063  weight(nbins/2+1)
-            for k in range(nbins):
-                weight[k] = float(weight[k]) - mid
-            st["wlf"] += [(cycle, st["wl_factor"]), (cycle, 0.5 * st["wl_factor"])]           # :2080-2081
+            if not dd:
+                mid = float(weight[nbins // 2])                                               # :2063  weight(nbins/2+1)
+                for k in range(nbins):
+                    weight[k] = float(weight[k]) - mid
+                st["wlf"] += [(cycle, st["wl_factor"]), (cycle, 0.5 * st["wl_factor"])]       # :2080-2081
             for k in range(nbins):
                 histogram[k] = 0.0                                                            # :2105
             st["wl_factor"] *= 0.5                                                            # :2107

@@ -137,3 +137,38 @@ def test_window_join_three_ranks(tmp_path):
     for k in range(1, world):
         end = k * bpw
         assert abs(np.diff(jw)[end - 1]) < 5.0
+
+
+def _dd_rows_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mc_water_ls_mw_amd.comms import WalkerComms
+    c = WalkerComms(NBINS)
+    rows = np.load(os.path.join(tmp, "rows.npz"))
+    np.savez(os.path.join(tmp, f"ddrows{rank}.npz"), jw=c.join_eta(rows["w"][2 * rank:2 * rank + 2], 2),
+             ju=c.join_uhist(rows["u"][2 * rank:2 * rank + 2], 2))
+    dist.destroy_process_group()
+
+
+def test_window_join_of_a_farm_two_processes_two_walkers_each(tmp_path):
+    """A farm hands the join one row per walker: walker k of process p is window 2p + k, so two processes of two
+    walkers stitch exactly what four single-window ranks would (done here without a process group)."""
+    from mc_water_ls_mw_amd.comms import WalkerComms
+    rng = np.random.default_rng(11)
+    w = np.cumsum(rng.random((4, NBINS)), axis=1) + 7.0 * np.arange(4)[:, None]
+    u = np.exp(rng.normal(0, 1, (4, NBINS)))
+    np.savez(tmp_path / "rows.npz", w=w, u=u)
+    mp.spawn(_dd_rows_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    single = WalkerComms(NBINS)
+    jw, ju = single.join_eta(w, 2), single.join_uhist(u, 2)
+    bpw = NBINS // 4
+    ref = w[0].copy()
+    for k in range(1, 4):
+        end = k * bpw
+        ref[end:] = w[k][end:] + (ref[end - 3:end + 2].mean() - w[k][end - 3:end + 2].mean())
+    ref -= ref[NBINS // 2]
+    assert np.allclose(jw, ref, rtol=1e-13, atol=1e-12)
+    for k in range(2):
+        r = np.load(tmp_path / f"ddrows{k}.npz")
+        assert np.array_equal(r["jw"], jw) and np.array_equal(r["ju"], ju)

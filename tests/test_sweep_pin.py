@@ -26,7 +26,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(RNG), reason="oracle/_ref/mc_
 
 
 def namelist(num_lattices, temperature, cycles, samplerun, always_switch=False, npt=False, vol_prob=None, latt_sync=None,
-             mc_extra="", book_extra=""):
+             mc_extra="", book_extra="", par_extra=""):
     volume_lines = "allow_vol        = .false." if not npt else f"mc_vol_prob      = {vol_prob}"
     return f"""&potential
 model_type = "mW"
@@ -68,6 +68,7 @@ chkpt_dump_int   = {cycles}
 timer_qtime      = 172800
 timer_closetime  = 1800
 /
+{'' if not par_extra else '&parallelisation' + chr(10) + par_extra + chr(10) + '/'}
 """
 
 
@@ -82,11 +83,12 @@ def read_records(path):
 
 
 def run_reference(d, num_lattices, temperature, cycles, weight=None, grid=None, samplerun=None, always_switch=False,
-                  tables=False, npt=False, vol_prob=None, transP=1.0, latt_sync=None, mc_extra="", book_extra="", run_env={}):
+                  tables=False, npt=False, vol_prob=None, transP=1.0, latt_sync=None, mc_extra="", book_extra="", run_env={},
+                  par_extra=""):
     from mc_water_ls_mw_amd import lattice as lat
     os.makedirs(d)
     samplerun = (weight is not None) if samplerun is None else samplerun
-    open(os.path.join(d, "ice.input"), "w").write(namelist(num_lattices, temperature, cycles, samplerun, always_switch, npt, vol_prob, latt_sync, mc_extra, book_extra))
+    open(os.path.join(d, "ice.input"), "w").write(namelist(num_lattices, temperature, cycles, samplerun, always_switch, npt, vol_prob, latt_sync, mc_extra, book_extra, par_extra))
     z1 = load_golden("ic48_t015")
     h1, x1 = lat.read_xmol(_write(d, "input001.xmol", z1))
     boxes = [(h1, x1)]
