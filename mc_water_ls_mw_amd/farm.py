@@ -190,6 +190,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             out["in_window"] = farm.factors()[2].tolist()
         out["walker1_tables"] = farm.tables(1)
         out["walker1_positions"] = [farm.positions(1), farm.positions(2)]
+        out["first_walkers"] = [dict(positions=[farm.positions(2 * w - 1), farm.positions(2 * w)], tables=farm.tables(w),
+                                     **farm.state(w)) for w in range(1, min(walkers, 4) + 1)]
         return out
     finally:
         em.energy_deinit()
@@ -243,7 +245,7 @@ def main():
               window_overlap=args.window_overlap, eq_mc_cycles=args.eq_cycles, leshift=args.leshift,
               wl_swetnam=args.wl_swetnam, wl_alpha=args.wl_alpha)
     tabs = res.pop("tables")
-    res.pop("walker1_tables"), res.pop("walker1_positions")
+    res.pop("walker1_tables"), res.pop("walker1_positions"), res.pop("first_walkers")
     joined = res.pop("joined")
     if joined is not None:
         tabs = (joined["weight"], joined["weight"])

@@ -498,6 +498,20 @@ static int lattice_switch(const mwo_eta *eta, const mwo_cycle_opts *o, double be
     return 0;
 }
 
+/* Top of mc_cycle for the move with global index mg (n moves per cycle; cycles count from 1), mc_moves.F90:181-210:
+ * the first move of a cycle re-evaluates walker_in_window.  Returns the cycle number (0 when 'dd' is off). */
+static int dd_cycle_top(uint64_t mg, int n, double ls_mu, const mwo_eta *eta)
+{
+    if (!g_dd) return 0;
+    const int cyc = (int)(mg / (uint64_t)n) + 1;
+    if (mg % (uint64_t)n == 0) {
+        if (cyc < g_eq_cycles) g_in_window = (ls_mu > eta->mu_lo && ls_mu < eta->mu_hi) ? 1 : 0;
+        else if (cyc == g_eq_cycles) { if (!g_in_window) g_not_in_window_at_eq = 1; }
+        else g_in_window = 1;
+    }
+    return cyc;
+}
+
 static void sweep_impl(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0,
                        int nlat, int n, double *xyz, const double *h,
                        const double *ivect, int ivstride, int maxneigh,
@@ -551,16 +565,7 @@ static void sweep_impl(int nmoves, uint64_t seed, uint32_t walker, uint64_t move
     for (int mv = 0; mv < nmoves; ++mv) {
         double u[8];
         mwo_move_uniforms8(seed, walker, move0 + (uint64_t)mv, u);            /* u[0..5] as mwo_move_uniforms */
-        int cyc = 0;
-        if (g_dd) {                                                           /* top of mc_cycle, :181-210 */
-            const uint64_t mg = move0 + (uint64_t)mv;
-            cyc = (int)(mg / (uint64_t)n) + 1;
-            if (mg % (uint64_t)n == 0) {
-                if (cyc < g_eq_cycles) g_in_window = (ls_mu > eta->mu_lo && ls_mu < eta->mu_hi) ? 1 : 0;
-                else if (cyc == g_eq_cycles) { if (!g_in_window) g_not_in_window_at_eq = 1; }
-                else g_in_window = 1;
-            }
-        }
+        const int cyc = dd_cycle_top(move0 + (uint64_t)mv, n, ls_mu, eta);
         const int lsn = nlat == 2 ? 3 - ls : 1;                               /* partner_lattice, :866-868 */
         int imol = (int)(u[0] * (double)n) + 1;                               /* :1001-1002 */
         if (imol > n) imol = n;
@@ -760,6 +765,7 @@ void mwo_sweep_full(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0, 
                        beta, max_trans, eta, opt, histogram, unbiased_hist, weight, ls, ls_mu, model_energy,
                        accepted, switches, log ? log + 8 * (size_t)mv : NULL);
         } else {                                                              /* :232-235 */
+            const int cyc = dd_cycle_top(move0 + (uint64_t)mv, n, *ls_mu, eta);
             const int ok = mwo_volume_move(u, nlat, n, xyz, h, volume, ivect, ivstride, nivect, maxneigh, nn, jn, vn,
                                            beta, dv_max, opt->pressure, eta, *ls, ls_mu, model_energy);
             if (nvol) { ++nvol[0]; if (ok == 1) ++nvol[1]; }
@@ -767,7 +773,7 @@ void mwo_sweep_full(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0, 
             if (nlat == 2) {
                 opt->volume[0] = volume[0]; opt->volume[1] = volume[1];
                 update_wl_bins(eta, opt, *ls_mu, histogram, unbiased_hist, weight);                    /* :234 */
-                if (opt->always_switch) {                                                              /* :243-248 */
+                if (opt->always_switch && !(g_dd && cyc < g_eq_cycles)) {                              /* :243-248 */
                     sw = lattice_switch(eta, opt, beta, n, u[6], model_energy, ls, ls_mu);
                     if (sw && switches) ++*switches;
                 }

@@ -12,6 +12,8 @@ model_energy, every local energy, old/new local energies of trial moves).
 
 The two 48-molecule inputs are the reference's own example data files
 (examples/*/input001.xmol = cubic Ic, input002.xmol = hexagonal Ih).
+ice1_sample_dd_eta_weights.dat is the weights table shipped with examples/ice1_sample_dd (a data file: 101 rows of
+mu_bin, weight under the increment header), kept verbatim for the 'dd' sampling test.
 """
 from __future__ import annotations
 

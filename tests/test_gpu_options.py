@@ -142,3 +142,102 @@ def test_dd_walker_outside_its_window_after_equilibration_stops_the_run():
     reference stops with this message at cycle eq_mc_cycles (mc_moves.F90:187-201)."""
     with pytest.raises(RuntimeError, match="Not all walkers have reached their designated window"):
         run_farm(12, walkers=2, parallel_strategy="dd", window_overlap=2, eq_mc_cycles=2)
+
+
+# ---- the reference's own 'dd' examples in miniature (examples/ice1_gen_weights_dd, examples/ice1_sample_dd): the shipped
+# inputs (ideal Ic / Ih of 48 molecules = tests/golden/ic48, ih48), NPT at 200 K and 1 atm, volume moves at 1/N against
+# translations at 0.5, a switch attempt after every move, two windows overlapping by two bins.  max_mc_cycles /
+# eq_mc_cycles / flat_chk_int are cut from 5 10^6 / 10^4 / 10^4 to 24 (48) / 4 / 8 so that the oracle replays them in seconds.
+
+def ideal48():
+    z1, z2 = load_golden("ic48"), load_golden("ih48")
+    return [(z1["h"], z1["xyz"]), (z2["h"], z2["xyz"])]
+
+
+def replay_npt_window(so, c_oracle, k, size, cycles, eq, wl_factor0, samplerun=False, weight=None, lun=0.0, flat_int=8,
+                      flattol=0.05):
+    """Rank k of `size` of an NPT 'dd' run, cycle by cycle on the oracle (mwo_sweep_full: the restatement
+    tests/test_sweep_pin.py pins to the reference program under NPT, with the 'dd' rules of tests/test_options_pin.py)."""
+    from mc_water_ls_mw_amd.lattice import ANG_TO_BOHR
+    from mc_water_ls_mw_amd.sweep import KB, MuGrid
+    from oracle import FullSweepState
+    from oracle import schedule as osch
+    grid = MuGrid(101, -400.0, 400.0)
+    w0 = grid.window(k, size, 2)
+    g = grid.restricted(w0)
+    b = ideal48()
+    beta, p, transP = 1.0 / (KB * 200.0), 1.0 / pin.AUP_TO_ATM, 0.5 / (0.5 + 1.0 / 48)
+    st = FullSweepState(c_oracle, [b[0][0], b[1][0]], [b[0][1], b[1][1]])
+    mu = st.model_energy[0] + p * st.volume[0] - st.model_energy[1] - p * st.volume[1]
+    st.ls_mu = mu * beta - 48.0 * np.log(st.volume[0] / st.volume[1])
+    st.ls = w0["ls"] or 1
+    w = np.zeros(101) if weight is None else np.array(weight, dtype=float)
+    w[:w0["start_bin"] - 1] = 0.0                                          # mc_moves.F90:808-812
+    w[w0["end_bin"]:] = 0.0
+    hi, uh = np.zeros(101), np.zeros(101)
+    sched = osch.new_state(wl_factor0, schedule=0, flattol=flattol)
+    events = []
+    so.set_dd(True, eq, False)
+    try:
+        for cyc in range(1, cycles + 1):
+            if cyc % 10 == 0:
+                st.rebuild_lists(c_oracle)
+            so.full(st, 48, pin.SEED, k, (cyc - 1) * 48, transP, 0.924 * ANG_TO_BOHR, beta, 1.1 * ANG_TO_BOHR, g, w, hi, uh,
+                    record=cyc >= eq, samplerun=samplerun, always_switch=True, npt=True,
+                    wl_factor=0.0 if samplerun else sched["wl_factor"], log_unbiased_norm=lun, pressure=p)
+            if not samplerun and cyc % flat_int == 0:
+                what = osch.flatness_step(sched, cyc, 48, hi, w, start_bin=w0["start_bin"], end_bin=w0["end_bin"], dd=True)
+                if what not in ("none", "checked"):
+                    events.append((cyc, k, what))
+        in_window, failed = so.get_dd()
+    finally:
+        so.set_dd(False)
+    assert in_window and not failed
+    return dict(st=st, weight=w, hist=hi, uhist=uh, factor=sched["wl_factor"], events=events, window=w0)
+
+
+def run_example(cycles, **kw):
+    from mc_water_ls_mw_amd.farm import run
+    b = ideal48()
+    return run([b[0][0], b[1][0]], [b[0][1], b[1][1]], walkers=2, cycles=cycles, temperature=200.0, seed=pin.SEED,
+               thermalise=False, list_update_int=10, mpi_sync_int=250, npt=True, pressure_atm=1.0, parallel_strategy="dd",
+               window_overlap=2, eq_mc_cycles=4, flat_chk_int=8, **kw)
+
+
+def test_ice1_gen_weights_dd_example_in_miniature(so, c_oracle):
+    from mc_water_ls_mw_amd.comms import WalkerComms
+    res = run_example(24, wl_factor=0.005, wl_flattol=0.05)
+    ranks = [replay_npt_window(so, c_oracle, k, 2, 24, 4, 0.005) for k in range(2)]
+    assert res["in_window"] == [True, True] and res["volume_moves_walker1"][0] == ranks[0]["st"].nvol[0] > 0
+    assert sorted((e["cycle"], e["walker"], e["action"]) for e in res["flatness_events"]) == sorted(ranks[0]["events"] + ranks[1]["events"])
+    wt_d, hi_d, _ = res["walker1_tables"]
+    assert hi_d.sum() > 0 and np.allclose(hi_d, ranks[0]["hist"], rtol=1e-12, atol=1e-12)
+    assert np.allclose(wt_d, ranks[0]["weight"], rtol=1e-9, atol=1e-11)
+    assert np.abs(np.array(res["walker1_positions"]) - ranks[0]["st"].xyz).max() < 1e-8
+    joined = WalkerComms(101).join_eta(np.array([ranks[0]["weight"], ranks[1]["weight"]]), 2)
+    assert np.abs(joined).max() > 0 and np.allclose(res["joined"]["weight"], joined, rtol=1e-9, atol=1e-10)
+    assert res["wl_factor"] == max(r["factor"] for r in ranks)
+
+
+def test_ice1_sample_dd_example_in_miniature(so, c_oracle):
+    """Fixed weights from the example's own eta_weights.dat, each walker keeping its window's part; the unbiased
+    histograms of the two windows stitched (comms_join_uhist) and turned into a free-energy difference."""
+    import os
+    from conftest import GOLDEN
+    from mc_water_ls_mw_amd import io as mwio
+    from mc_water_ls_mw_amd.comms import WalkerComms
+    from mc_water_ls_mw_amd.sweep import MuGrid
+    from oracle import schedule as osch
+    grid = MuGrid(101, -400.0, 400.0)
+    factor, mu_bin, weight = mwio.read_table(os.path.join(GOLDEN, "ice1_sample_dd_eta_weights.dat"))
+    assert np.allclose(mu_bin, grid.mu_bin, rtol=1e-12, atol=1e-12) and factor == pytest.approx(0.05, rel=1e-6)
+    res = run_example(48, samplerun=True, weight=weight, deltaG_int=48, max_mc_cycles=48)     # (48: every seam bin visited)
+    lun = osch.unbiased_norm(weight, grid.av_binwidth, 48, 4, 2, 48)
+    ranks = [replay_npt_window(so, c_oracle, k, 2, 48, 4, 0.0, samplerun=True, weight=weight, lun=lun) for k in range(2)]
+    assert all(r["uhist"][47:52].min() > 0 for r in ranks)
+    _, hi_d, uh_d = res["walker1_tables"]
+    assert np.allclose(hi_d, ranks[0]["hist"], rtol=1e-12, atol=1e-12) and np.allclose(uh_d, ranks[0]["uhist"], rtol=1e-8, atol=0)
+    ju = WalkerComms(101).join_uhist(np.array([r["uhist"] for r in ranks]), 2)
+    assert np.allclose(res["joined"]["unbiased_hist"], ju, rtol=1e-8, atol=0)
+    assert ju[:50].sum() > 0 and ju[50:].sum() > 0
+    assert res["delta_g"]["kT"] == pytest.approx(osch.delta_g(ju, grid.binwidth), rel=1e-7)

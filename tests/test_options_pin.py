@@ -173,3 +173,39 @@ def test_dd_run_in_its_window_matches_the_reference_program(tmp_path, so, c_orac
     assert np.allclose(hi, hist, rtol=0, atol=1e-12) and np.allclose(w, wgt, rtol=1e-11, atol=1e-12)
     assert wgt[w0["end_bin"]:].max() == 0.0 and wgt[:w0["end_bin"]].max() > 0      # nothing outside the window
     assert not os.path.exists(os.path.join(d, "wlf.dat"))
+
+
+
+def test_dd_npt_run_in_its_window_matches_the_reference_program(tmp_path, so, c_oracle):
+    """Rank 0 of two under NPT (~1 move in 6 a volume move): during the two equilibration cycles no switch attempt follows
+    a volume move either (mc_moves.F90:243-248 sits below both branches), and mc_volume sees the window's walls."""
+    from mc_water_ls_mw_amd.lattice import ANG_TO_BOHR
+    from mc_water_ls_mw_amd.sweep import KB, MuGrid
+    from oracle import FullSweepState
+    grid = MuGrid(101, -400.0, 400.0)
+    w0 = grid.window(0, 2, 2)
+    vol_prob = 0.1
+    transP = 0.5 / (0.5 + vol_prob)
+    boxes, e_ref, ljr, ls, hist, wgt = pin.run_reference(str(tmp_path / "run"), 2, 200, 12, samplerun=False, always_switch=True,
+                                                         tables=True, npt=True, vol_prob=vol_prob, transP=transP, par_extra=PAR,
+                                                         book_extra="eq_mc_cycles = 3",
+                                                         run_env=dict(MW_WRAP_SIZE="2", MW_WRAP_RANK="0", MW_WRAP_SWITCH_FROM_MOVE=str(2 * 48)))
+    beta, p = 1.0 / (KB * 200.0), 1.0 / pin.AUP_TO_ATM
+    st = FullSweepState(c_oracle, [b[0] for b in boxes], [b[1] for b in boxes])
+    mu = st.model_energy[0] + p * st.volume[0] - st.model_energy[1] - p * st.volume[1]
+    st.ls_mu = mu * beta - 48.0 * np.log(st.volume[0] / st.volume[1])
+    w, hi, uh = np.zeros(101), np.zeros(101), np.zeros(101)
+    so.set_dd(True, 3, False)
+    try:
+        for cyc in range(1, 13):
+            if cyc % 10 == 0:
+                st.rebuild_lists(c_oracle)
+            so.full(st, 48, pin.SEED, 0, (cyc - 1) * 48, transP, 0.924 * ANG_TO_BOHR, beta, 1.1 * ANG_TO_BOHR, grid.restricted(w0),
+                    w, hi, uh, record=cyc >= 3, samplerun=False, always_switch=True, npt=True, wl_factor=F0, pressure=p)
+        in_window, failed = so.get_dd()
+    finally:
+        so.set_dd(False)
+    assert in_window and not failed and st.nvol[0] > 40 and 0 < st.nvol[1]
+    assert np.abs(st.h - pin.run_reference.hmatrix).max() < 1e-10
+    assert np.abs(st.xyz - ljr).max() < 1e-9 and st.ls == ls
+    assert hist.sum() > 0 and np.allclose(hi, hist, rtol=1e-12, atol=1e-12) and np.allclose(w, wgt, rtol=1e-10, atol=1e-11)
