@@ -1,4 +1,5 @@
-"""Build libmw_hip.so (the C-ABI engine) in-tree with hipcc for gfx950.
+"""Build libmw_hip.so (the C-ABI engine) and libmw_comms.so (the RCCL exchange layer for a Fortran host, include/mw_comms.h)
+in-tree with hipcc for gfx950.
 
     python -m mc_water_ls_mw_amd.build [--force]
 
@@ -21,6 +22,11 @@ DEPS = SOURCES + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.end
     [os.path.join(os.path.dirname(PKG), "include", "mw_energy.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+COMMS_LIB = os.path.join(PKG, "libmw_comms.so")
+COMMS_SRC = os.path.join(CSRC, "mw_comms.hip")
+COMMS_DEPS = [COMMS_SRC, os.path.join(os.path.dirname(PKG), "include", "mw_comms.h")]
 
 
 def hipcc_path():
@@ -47,6 +53,19 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+def build_comms(force=False, verbose=False):
+    """libmw_comms.so: host code only (no kernels), linked against RCCL."""
+    if not force and os.path.exists(COMMS_LIB) and all(os.path.getmtime(p) <= os.path.getmtime(COMMS_LIB) for p in COMMS_DEPS):
+        return COMMS_LIB
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", COMMS_LIB, COMMS_SRC,
+           "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return COMMS_LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
     print(LIB)
+    print(build_comms(force="--force" in sys.argv, verbose=True))

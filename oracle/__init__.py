@@ -39,7 +39,7 @@ def _i(a):
 def build(ref=True):
     """Compile the C restatement and, when /root/reference is present (build container only), everything
     oracle/Makefile derives from the reference: libmw_ref.so, the drop-in driver pair and the whole-program
-    builds (mc_water_ref, _ref_scrub, _ref_rng, _hip).  The last two link libmw_hip.so: build that first."""
+    builds (mc_water_ref, _ref_scrub, _ref_rng, _hip, _hip_rccl).  The last two link libmw_hip.so / libmw_comms.so: build those first."""
     subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
     if ref and os.path.isdir("/root/reference"):
         with open(os.devnull, "w") as null:     # flang prints literal-widening warnings for the reference sources

@@ -82,3 +82,18 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "mw_oracle" not in text and "libmw_ref" not in text, f
+
+
+def test_comms_library_exports_every_declared_symbol():
+    """libmw_comms.so (include/mw_comms.h): loads without a GPU, exports the whole interface, and refuses to work
+    before mw_comms_init."""
+    from mc_water_ls_mw_amd import build
+    L = ctypes.CDLL(build.build_comms())
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mw_comms.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(mw_comms_[a-z_0-9]+)\s*\(", text)))
+    assert len(names) == 12
+    for name in names:
+        assert hasattr(L, name), f"libmw_comms.so does not export {name}"
+    L.mw_comms_last_error.restype = ctypes.c_char_p
+    assert L.mw_comms_barrier() != 0 and b"mw_comms_init first" in L.mw_comms_last_error()
+    assert L.mw_comms_finalize() == 0                       # nothing to tear down is not an error
