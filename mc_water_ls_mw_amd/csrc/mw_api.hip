@@ -82,6 +82,7 @@ struct Ctx {
     float4 *d_wrel = nullptr, *d_wpos = nullptr;   // wrapped cell-relative positions (single precision) by molecule / by cell-sorted slot
     int* d_wsh = nullptr;                          // packed shifts by cell-sorted slot
     bool legacy_search = false;                    // MW_CELL_SEARCH=legacy: the one-thread-per-molecule search (cross-check)
+    bool sort_in_lds = false;                      // bin + scan + scatter of a box in one workgroup (k_cell_sort_box); MW_CELL_SORT=global: the three kernels
     int *d_ccount = nullptr, *d_cstart = nullptr, *d_ccursor = nullptr;
     int cstride = 0;
     std::vector<mw::GridDesc> h_grid;
@@ -89,6 +90,7 @@ struct Ctx {
     bool force_brute = false;
     double* d_partial = nullptr;
     unsigned long long* d_cpartial = nullptr;
+    unsigned int* d_done = nullptr;          // per box: workgroups of the running k_model_energy launch that have published their partial
     double* d_energy = nullptr;
     unsigned long long* d_counts = nullptr;
     // device-resident translation driver (walker = nlat consecutive boxes)
@@ -353,17 +355,15 @@ int launch_model_energy(int first, int count)
     const int box0 = first - 1;
     if (ge.lds)
         hipLaunchKernelGGL((mw::k_model_energy<true, 1024, kFullLayout>), grid, dim3(1024), ge.shmem, g.stream, g.d_pos, g.d_ivect,
-                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
+                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.d_done, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
     else
         hipLaunchKernelGGL((mw::k_model_energy<false, 256, kFullLayout, true>), grid, dim3(256), ge.shmem, g.stream, g.d_pos, g.d_ivect,
-                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
-    HIPCHK(hipGetLastError());
-    // the partials of box b live at [b*nsplit .. b*nsplit+nsplit): same nsplit in both kernels
-    hipLaunchKernelGGL(mw::k_sum_partials, dim3((count + 255) / 256), dim3(256), 0, g.stream, g.d_partial, g.d_cpartial,
-                       g.d_energy, g.d_counts, box0, count, ge.nsplit);
-    HIPCHK(hipGetLastError());
+                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.d_done, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
+    HIPCHK(hipGetLastError());     // (the workgroup of a box that finishes last sums the box's partials: one launch)
     return 0;
 }
+
+size_t sort_box_lds_bytes() { return (size_t)g.N * 24 + ((size_t)g.cstride + 1) * 4; }
 
 int launch_build(int first, int count)
 {
@@ -375,6 +375,12 @@ int launch_build(int first, int count)
     for (int b = box0; b < box0 + count; ++b) ngrid += g.h_usegrid[b] ? 1 : 0;
     dim3 grid((g.N + 255) / 256, count);
     if (ngrid > 0) {
+        if (g.sort_in_lds && !g.legacy_search) {
+            // boxes whose cell-ordered records fit LDS: bin + scan + scatter in one workgroup per box
+            hipLaunchKernelGGL(mw::k_cell_sort_box, dim3(count), dim3(1024), sort_box_lds_bytes(), g.stream, g.d_pos, g.d_grid,
+                               g.d_cstart, g.d_wpos, g.d_wsh, g.N, g.cstride, box0);
+            HIPCHK(hipGetLastError());
+        } else {
         HIPCHK(hipMemsetAsync(g.d_ccount + (size_t)box0 * g.cstride, 0, sizeof(int) * (size_t)count * g.cstride, g.stream));
         hipLaunchKernelGGL(mw::k_cell_bin, grid, dim3(256), 0, g.stream, g.d_pos, g.d_grid, g.d_cellid, g.d_shift, g.d_wrel, g.d_ccount,
                            g.N, g.cstride, box0);
@@ -385,6 +391,7 @@ int launch_build(int first, int count)
         hipLaunchKernelGGL(mw::k_cell_scatter, grid, dim3(256), 0, g.stream, g.d_grid, g.d_cellid, g.d_shift, g.d_wrel, g.d_ccursor,
                            g.d_sorted, g.d_wpos, g.d_wsh, g.N, g.cstride, box0);
         HIPCHK(hipGetLastError());
+        }
         if (g.legacy_search) {
             hipLaunchKernelGGL(mw::k_cell_search, grid, dim3(256), (size_t)g.S * 256 * sizeof(uint32_t), g.stream, g.d_pos, g.d_ivect,
                                g.d_grid, g.d_cellid, g.d_shift, g.d_cstart, g.d_sorted, g.d_listm, g.d_nn, g.d_cin, g.d_stats,
@@ -454,7 +461,7 @@ void release_all()
                     g.d_wswitch, g.d_wshift, g.d_wvol, g.d_wflag, g.d_wwin, g.d_wfac, g.d_wsum, g.d_winflag, g.d_volume, g.d_swlog, g.d_tabscratch, g.d_pos, g.d_ivect,
                     g.d_nivect, g.d_list, g.d_listm, g.d_nn, g.d_stats, g.d_order, g.d_nns, g.d_cmax, g.d_cin, g.d_grid,
                     g.d_usegrid, g.d_cellid, g.d_shift, g.d_sorted, g.d_wrel, g.d_wpos, g.d_wsh, g.d_ccount, g.d_cstart, g.d_ccursor, g.d_partial,
-                    g.d_cpartial, g.d_energy, g.d_counts, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.d_mperm,
+                    g.d_cpartial, g.d_done, g.d_energy, g.d_counts, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.d_mperm,
                     g.d_mwork};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g.h_pin) (void)hipHostFree(g.h_pin);
@@ -577,6 +584,13 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
     HIPCHK(hipMalloc(&g.d_wpos, nb * N * sizeof(float4)));
     HIPCHK(hipMalloc(&g.d_wsh, nb * N * sizeof(int)));
     { const char* cs = std::getenv("MW_CELL_SEARCH"); g.legacy_search = cs && std::strcmp(cs, "legacy") == 0; }
+    {
+        const char* cs = std::getenv("MW_CELL_SORT");
+        g.sort_in_lds = nwater <= mw::kSortBoxMax && !(cs && std::strcmp(cs, "global") == 0);
+        if (g.sort_in_lds)
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_cell_sort_box), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sort_box_lds_bytes()));
+    }
     HIPCHK(hipMalloc(&g.d_ccount, nb * (size_t)g.cstride * sizeof(int)));
     HIPCHK(hipMalloc(&g.d_cstart, nb * ((size_t)g.cstride + 1) * sizeof(int)));
     HIPCHK(hipMalloc(&g.d_ccursor, nb * (size_t)g.cstride * sizeof(int)));
@@ -588,6 +602,8 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
     { const char* fb = std::getenv("MW_FORCE_BRUTE_NEIGHBOURS"); g.force_brute = fb && *fb && *fb != '0'; }
     HIPCHK(hipMalloc(&g.d_partial, nb * g.nsplit_max * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_cpartial, nb * g.nsplit_max * 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&g.d_done, nb * sizeof(unsigned int)));
+    HIPCHK(hipMemset(g.d_done, 0, nb * sizeof(unsigned int)));
     HIPCHK(hipMalloc(&g.d_energy, nb * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_counts, nb * 2 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(g.d_pos, 0, nb * N * 3 * sizeof(double)));

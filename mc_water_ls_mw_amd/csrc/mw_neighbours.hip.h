@@ -183,6 +183,108 @@ void k_cell_scatter(const GridDesc* __restrict__ grid, const int* __restrict__ c
     wsh[(size_t)b * N + slot] = shift[(size_t)b * N + i];
 }
 
+// Bin + scan + scatter of one box in ONE workgroup, for boxes whose cell-ordered records fit LDS (N <= kSortBoxMax):
+// the three kernels above move every molecule's record through HBM twice (cell id, shift and cell-relative position
+// out of k_cell_bin, back into k_cell_scatter, out again in cell order) and pay two grid-wide launches for ~100 KB of
+// data per box.  Here a box's positions are read once (and once more from L2), the per-cell counters and the scan
+// live in LDS, the cell-ordered records are assembled in LDS and leave in one coalesced stream:
+//   HBM traffic per box = 24 N in + 20 N + 4 (ncell + 1) out   (k_cell_pairs reads exactly these 20 N + 4 ncell bytes).
+// Order inside a cell = arrival order of the LDS atomics (arbitrary, as in k_cell_scatter: the rows are sorted later).
+//   grid = boxes, block = 1024; dynamic LDS = N * 24 + (cstride + 1) * 4 bytes
+constexpr int kSortBoxMax = 5120;
+
+struct CellRec { int c[3]; int sh; float4 w; };
+
+__device__ __forceinline__ CellRec cell_record(const GridDesc& G, const double* __restrict__ p, int i)
+{
+    const double x = p[0], y = p[1], z = p[2];
+    CellRec r;
+    int f[3];
+    double u[3];           // position inside the grid cell, in units of the cell vectors / nc
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double sd = G.hinv[3 * d] * x + G.hinv[3 * d + 1] * y + G.hinv[3 * d + 2] * z;
+        const double fl = floor(sd);
+        int ci = (int)((sd - fl) * (double)G.nc[d]);
+        ci = ci < 0 ? 0 : (ci >= G.nc[d] ? G.nc[d] - 1 : ci);
+        r.c[d] = ci;
+        u[d] = ((sd - fl) * (double)G.nc[d] - (double)ci) / (double)G.nc[d];
+        int sh = (int)fl;
+        f[d] = sh < -511 ? -511 : (sh > 511 ? 511 : sh);   // farther out than the image table reaches anyway
+    }
+    r.sh = pack_shift(f[0], f[1], f[2]);
+    // the wrapped position relative to its grid cell's origin: small numbers, so single precision keeps ~1e-6 bohr
+    // (k_cell_pairs' pre-filter); .w carries the molecule index
+    r.w = make_float4((float)(u[0] * G.h[0] + u[1] * G.h[3] + u[2] * G.h[6]),
+                      (float)(u[0] * G.h[1] + u[1] * G.h[4] + u[2] * G.h[7]),
+                      (float)(u[0] * G.h[2] + u[1] * G.h[5] + u[2] * G.h[8]), __int_as_float(i));
+    return r;
+}
+
+__global__ __launch_bounds__(1024)
+void k_cell_sort_box(const double* __restrict__ pos, const GridDesc* __restrict__ grid,
+                     int* __restrict__ start, float4* __restrict__ wpos, int* __restrict__ wsh,
+                     int N, int cstride, int box0)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sortbox_lds[];
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int b = box0 + blockIdx.x;
+    const GridDesc& G = grid[b];
+    if (G.nc[0] == 0) return;                                             // this box keeps the brute-force kernel
+    float4* s_w = reinterpret_cast<float4*>(sortbox_lds);                 // [N] records in cell order
+    int* s_sh = reinterpret_cast<int*>(s_w + N);                          // [N]
+    unsigned int* s_rc = reinterpret_cast<unsigned int*>(s_sh + N);       // [N] rank inside the cell << 16 | ... (cell id kept apart)
+    int* s_cnt = reinterpret_cast<int*>(s_rc + N);                        // [cstride + 1] counts, then starts
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ncell = G.ncell;
+    const double* P = pos + (size_t)b * N * 3;
+    for (int c = tid; c <= ncell; c += 1024) s_cnt[c] = 0;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    // ---- pass 1: cell of every molecule, its rank among the cell's molecules ----------------------------------------
+    for (int i = tid; i < N; i += 1024) {
+        const CellRec r = cell_record(G, P + 3 * (size_t)i, i);
+        const int cid = (r.c[0] * G.nc[1] + r.c[1]) * G.nc[2] + r.c[2];
+        const int rank = atomicAdd(&s_cnt[cid], 1);
+        s_rc[i] = ((unsigned int)rank << 16) | (unsigned int)cid;         // (ncell <= cstride < 65536, a cell never holds 65536 molecules)
+    }
+    __syncthreads();
+    // ---- exclusive scan of the counts, in place --------------------------------------------------------------------
+    for (int base = 0; base < ncell; base += 1024) {
+        const int idx = base + tid;
+        const int v = idx < ncell ? s_cnt[idx] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        const int excl = carry + woff + incl - v;
+        if (idx < ncell) s_cnt[idx] = excl;
+        __syncthreads();
+        if (tid == 1023) carry = excl + v;
+        __syncthreads();
+    }
+    if (tid == 0) s_cnt[ncell] = carry;
+    __syncthreads();
+    // ---- pass 2: records into their cell-ordered slots (LDS), then out in one coalesced stream -----------------------
+    for (int i = tid; i < N; i += 1024) {
+        const CellRec r = cell_record(G, P + 3 * (size_t)i, i);
+        const unsigned int rc = s_rc[i];
+        const int slot = s_cnt[rc & 0xffffu] + (int)(rc >> 16);
+        s_w[slot] = r.w;
+        s_sh[slot] = r.sh;
+    }
+    __syncthreads();
+    float4* WP = wpos + (size_t)b * N;
+    int* WS = wsh + (size_t)b * N;
+    int* ST = start + (size_t)b * (cstride + 1);
+    for (int t = tid; t < N; t += 1024) { WP[t] = s_w[t]; WS[t] = s_sh[t]; }
+    for (int c = tid; c <= ncell; c += 1024) ST[c] = s_cnt[c];
+}
+
 // One thread per molecule, taken in grid order so that a wavefront walks the same cells.
 __global__ __launch_bounds__(256)
 void k_cell_search(const double* __restrict__ pos, const double* __restrict__ ivect,
