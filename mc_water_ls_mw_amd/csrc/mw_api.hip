@@ -398,10 +398,12 @@ int launch_build(int first, int count)
                                g.N, g.S, g.ivcap, g.cstride, box0);
         } else {
             // one wavefront per block of grid cells along the third axis, four per workgroup; cells per block: enough
-            // for ~13 molecules per wavefront (MW_PAIR_BCELLS overrides)
+            // for ~17 molecules per wavefront -- one block of kPairIB rows, and the block's candidates still fit one
+            // register batch (measured on 512 x 4096 ice: 3 cells 1.35 ms, 4 cells 1.18 ms, 5 cells 1.19 ms;
+            // MW_PAIR_BCELLS overrides)
             int bcells = 1, maxblocks = 0;
             for (int b = box0; b < box0 + count; ++b)
-                if (g.h_usegrid[b]) { bcells = std::max(bcells, (int)(13.0 * g.h_grid[(size_t)b].ncell / g.N + 0.5)); }
+                if (g.h_usegrid[b]) { bcells = std::max(bcells, (int)(17.5 * g.h_grid[(size_t)b].ncell / g.N + 0.5)); }
             if (const char* ev = std::getenv("MW_PAIR_BCELLS")) bcells = std::atoi(ev);
             bcells = std::max(1, std::min(bcells, mw::kPairMaxB));
             for (int b = box0; b < box0 + count; ++b) {
