@@ -208,7 +208,15 @@ def secondary_measurements(device):
     out = []
 
     def timed(em, slot, fn, reps):
-        fn(); em.sync()
+        """Average of a HIP-event bracket over enough launches to last >= 30 ms, after >= 100 ms of the same launches
+        (a few sub-millisecond launches on an idle GPU are timed at its idle clock)."""
+        t0 = time.perf_counter()
+        n_warm = 0
+        while time.perf_counter() - t0 < 0.1 or n_warm < 2:
+            fn(); em.sync()
+            n_warm += 1
+        per = (time.perf_counter() - t0) / n_warm
+        reps = max(reps, min(2000, int(0.03 / max(per, 1e-6)) + 1))
         em.timer_start(slot)
         for _ in range(reps):
             fn()
