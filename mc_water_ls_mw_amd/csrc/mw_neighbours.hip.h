@@ -2,6 +2,7 @@
 // compute_neighbours (molint.F90:501-559): brute-force builder and the cell-grid builder, both
 // bit-identical to the reference's list.
 #pragma once
+#include <type_traits>
 
 #include "mw_common.hip.h"
 
@@ -384,10 +385,11 @@ void k_cell_search(const double* __restrict__ pos, const double* __restrict__ iv
 //     cell shifts (m = wrap + floor(s_i) - floor(s_j): positions are never wrapped, G8); a candidate whose image is
 //     not in the reference's image table is dropped here, exactly as the reference never tests it.  Every molecule
 //     of a block normally has the same shift; if not, the candidates are re-staged when the shift changes.
-//   * The enumeration is ordered by slab along the third axis, so a molecule only meets the chunks that overlap
-//     the three slabs around its own cell.  For each molecule i of the block (wave-uniform) the 64 lanes test 64
-//     candidates per step in single precision against rn^2 + eps: 6 instructions per 64 tests and nothing to wait
-//     for; the ~20 hits go straight into the molecule's row in LDS as finished entries (ballot + mbcnt).
+//   * For each molecule i of the block (wave-uniform) the 64 lanes test 64 candidates per step in single precision
+//     against rn^2 + eps, ALL chunks of the batch in straight-line code (4 or 5 chunks; the compiler interleaves
+//     their dependency chains -- skipping the chunks outside the molecule's three slabs, as an earlier version did,
+//     put a branch in front of every chunk and cost more than it saved); the ~20 hits go straight into the molecule's
+//     row in LDS as finished entries (ballot + mbcnt).
 //   * A hit whose single-precision distance lies within eps of rn^2 -- about one molecule in 2000 -- flags its row:
 //     such a row is re-decided entry by entry with the reference's own double-precision expression on the
 //     unwrapped positions, unfused (molint.F90:529-537).  eps bounds the pre-filter's rounding error (make_grid),
@@ -396,28 +398,32 @@ void k_cell_search(const double* __restrict__ pos, const double* __restrict__ iv
 //     molecule-major list; k_list_order derives the slot-major layout.
 // Needs >= 3 grid cells along every cell vector and bcells <= nc[2] (each (cell, wrap) pair, hence each image of a
 // molecule, is a candidate at most once).
-//   grid = (ceil(max blocks of cells / 4), boxes), block = 256 (wavefront w of workgroup x takes cell block 4x + w)
+//   grid = (ceil(max blocks of cells / 4), boxes), block = 256 (wavefront w of workgroup x takes cell block 4x + w);
+//   64 VGPRs and 25.5 KB of LDS per workgroup: six workgroups = 24 wavefronts per CU
 // =====================================================================================
-constexpr int kPairChunks = 6;      // candidate chunks (of 64) held in registers per batch (more candidates: more batches)
+constexpr int kPairChunks = 5;      // candidate chunks (of 64) held in registers per batch (more candidates: more batches)
 constexpr int kPairIB = 16;         // molecules of the cell block per block of rows (more molecules: more passes)
 constexpr int kPairRowCap = 64;     // single-precision hits kept per molecule
 constexpr int kPairMaxB = 5;        // grid cells per wavefront at most
 constexpr int kPairPieces = 9 * (kPairMaxB + 2);
-constexpr int kPairLookup = 512;    // enumeration positions with a one-read piece lookup (beyond: binary search)
+constexpr int kPairLookup = 320;    // enumeration positions with a one-read piece lookup (beyond: binary search)
 constexpr uint32_t kNoEntry = 0xffffffffu;
 
+// (sized so that six workgroups of four wavefronts fit a CU's 160 KiB: the kernel is latency bound -- 13 % slower with
+// four workgroups per CU than with five, 10 % faster with six)
 struct PairsLds {
     __attribute__((aligned(16))) uint32_t rows[kPairIB][kPairRowCap];   // hits as sort keys: j << 10 | image
     float4 own[kPairIB];                         // the block's molecules (position relative to the block origin, index)
     int ownsh[kPairIB];                          // their packed shifts
-    int ownrange[kPairIB];                       // enumeration positions each has to meet: first | last + 1 << 16
     int cnt[kPairIB];                            // hits per molecule (bit 30: an ambiguous hit, re-decide in double precision)
     int ncin[kPairIB];                           // hits already inside the energy cutoff (single precision: a sort key only)
-    int pstart[kPairPieces + 1], pq[kPairPieces], po[kPairPieces];   // pieces of the enumeration (one grid cell each): first position, first sorted slot, wrap offsets
-    int pk[kPairPieces];                         // image number of the piece's molecules for equal shifts (m = wrap offsets); -1: not in the table
+    int pstart[kPairPieces + 1], pq[kPairPieces];   // pieces of the enumeration (one grid cell each): first position, first sorted slot
+    int pk[kPairPieces];                         // image number of the piece's molecules for equal shifts (m = wrap offsets) | wrap offsets (2 bits each, biased by 1) << 10
     float poff[kPairPieces][3];                  // origin of the piece's grid cell relative to the block's
     unsigned char tpiece[kPairLookup];           // piece of enumeration position t (t < kPairLookup)
 };
+
+static_assert(4 * sizeof(PairsLds) <= 26 * 1024, "six workgroups of k_cell_pairs per CU");
 
 __device__ __forceinline__ int piece_of(const PairsLds& W, int t, int npieces)
 {
@@ -474,13 +480,13 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
         const int q0 = ST[ncl];
         pcnt = ST[ncl + 1] - q0;
         W.pq[lane] = q0;
-        W.po[lane] = (o0 + 1) | ((o1 + 1) << 2) | ((o2 + 1) << 4);
+        const int po_ = (o0 + 1) | ((o1 + 1) << 2) | ((o2 + 1) << 4);
         {
             const int im0_ = G.im[0], im1_ = G.im[1], im2_ = G.im[2];            // (>= 1: the wrap offsets are always in the table)
             const int w1_ = 2 * im1_ + 1, w2_ = 2 * im2_ + 1;
             const int central_ = (im0_ * w1_ + im1_) * w2_ + im2_;
             const int lin = ((o0 + im0_) * w1_ + (o1 + im1_)) * w2_ + (o2 + im2_);
-            W.pk[lane] = lin == central_ ? 0 : (lin < central_ ? lin + 1 : lin);                                    // molint.F90:197-213
+            W.pk[lane] = (lin == central_ ? 0 : (lin < central_ ? lin + 1 : lin)) | (po_ << 10);                     // molint.F90:197-213; wrap offsets above the image number
         }
         const double f0 = (double)d0 / (double)nc0, f1 = (double)d1 / (double)nc1, f2 = (double)d2 / (double)nc2;
         W.poff[lane][0] = (float)(f0 * G.h[0] + f1 * G.h[3] + f2 * G.h[6]);
@@ -499,7 +505,9 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int T = W.pstart[npieces];
-    const float rn2_hi = (float)kRnSq + G.eps, rn2_lo = (float)kRnSq - G.eps;
+    const float rn2_hi = (float)kRnSq + G.eps;
+    const float eps_ = G.eps + 8.0f * (float)kRnSq * 1.1920929e-7f;      // band of the ambiguity test: (rn^2 - eps, rn^2 + eps) and a few ulps, so that
+                                                                          // every single-precision hit above rn^2 - eps is inside it whatever the rounding
     const int im0 = G.im[0], im1 = G.im[1], im2 = G.im[2];
     const int w1 = 2 * im1 + 1, w2 = 2 * im2 + 1;
     const int central = (im0 * w1 + im1) * w2 + im2;
@@ -517,7 +525,6 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
             v.x += W.poff[r][0]; v.y += W.poff[r][1]; v.z += W.poff[r][2];
             W.own[lane] = v;
             W.ownsh[lane] = WS[q];
-            W.ownrange[lane] = W.pstart[cell * 9] | (W.pstart[(cell + 3) * 9] << 16);   // slabs cell .. cell + 2 (T < 65536 checked below)
             W.cnt[lane] = 0; W.ncin[lane] = 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -528,8 +535,10 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
         for (int t0 = 0; t0 < T; t0 += kPairChunks * 64) {
             float cx[kPairChunks], cy[kPairChunks], cz[kPairChunks];
             uint32_t ck[kPairChunks];                                      // the entry (j << 10 | image) each candidate would become
+            int staged_t0 = -1, shcur = 0;                                 // (kept in registers only inside a batch: holding them across the
+                                                                           //  sort of a block of rows costs 46 VGPRs, i.e. two wavefronts per SIMD)
             // ---- a batch of candidates into registers, for molecules of shift `sh` -------------------------------
-            auto stage = [&](int sh) {
+            auto stage = [&](int sh) __attribute__((always_inline)) {
                 const int s0 = (sh & 1023) - 512, s1 = ((sh >> 10) & 1023) - 512, s2 = ((sh >> 20) & 1023) - 512;
 #pragma unroll
                 for (int ch = 0; ch < kPairChunks; ++ch) {
@@ -540,10 +549,11 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
                         const int q = W.pq[r] + (t - W.pstart[r]);
                         const float4 v = WP[q];
                         const int shj = WS[q];
-                        int k = W.pk[r];                                                         // same shift (the rule): the piece's image
+                        const int pkr = W.pk[r];
+                        int k = pkr & 1023;                                                      // same shift (the rule): the piece's image
                         if (__builtin_amdgcn_ballot_w64(shj != sh) != 0ull) {                    // wave-uniform
                             if (shj != sh) {
-                                const int po = W.po[r];
+                                const int po = pkr >> 10;
                                 const int m0 = ((po & 3) - 1) + s0 - ((shj & 1023) - 512);
                                 const int m1 = (((po >> 2) & 3) - 1) + s1 - (((shj >> 10) & 1023) - 512);
                                 const int m2 = (((po >> 4) & 3) - 1) + s2 - (((shj >> 20) & 1023) - 512);
@@ -561,41 +571,47 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
                     }
                 }
             };
-            int shcur = 0;
+            const int nch = min(kPairChunks, (T - t0 + 63) >> 6);          // chunks of this batch that hold candidates
             // ---- every molecule of the block against the batch -------------------------------------------------
-            for (int il = 0; il < nib; ++il) {
-                const int shi = __builtin_amdgcn_readfirstlane(W.ownsh[il]);
-                if (il == 0 || shi != shcur) { shcur = shi; stage(shcur); }   // (again only for a molecule that left the box unwrapped)
-                const float4 o = W.own[il];
-                const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.x)));
-                const float yi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.y)));
-                const float zi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.z)));
-                const int rg = __builtin_amdgcn_readfirstlane(W.ownrange[il]);
-                const int ta = rg & 0xffff, tb = rg >> 16;
-                int cnt = __builtin_amdgcn_readfirstlane(W.cnt[il]);
-                int ninner = 0;
-                unsigned long long amb = 0ull;
+            // The chunk loop is compiled once per chunk count with NO branch inside: the chunks of a molecule are
+            // independent dependency chains (subtract, square, compare, ballot, mbcnt, store), and only straight-line
+            // code lets the compiler interleave them -- with a branch per chunk (the earlier "skip the chunks outside the
+            // molecule's three slabs") every chain ran exposed, which cost more than the tests it saved (1.35 -> 1.25 ms
+            // for the whole list build with all chunks tested).  What is needed once per molecule -- "some hit was too
+            // close to call", "how many hits are inside the energy cutoff" -- is kept per lane and reduced once.
+            auto run_batch = [&](auto nch_c) __attribute__((always_inline)) {
+                constexpr int NCH = decltype(nch_c)::value;
+                for (int il = 0; il < nib; ++il) {
+                    const int shi = __builtin_amdgcn_readfirstlane(W.ownsh[il]);
+                    if (staged_t0 != t0 || shi != shcur) { shcur = shi; staged_t0 = t0; stage(shcur); }   // (again only for a molecule that left the box unwrapped)
+                    const float4 o = W.own[il];
+                    const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.x)));
+                    const float yi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.y)));
+                    const float zi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.z)));
+                    int cnt = __builtin_amdgcn_readfirstlane(W.cnt[il]);
+                    int inner_l = 0, amb_l = 0;
 #pragma unroll
-                for (int ch = 0; ch < kPairChunks; ++ch) {
-                    const int tc = t0 + ch * 64;
-                    if (tc < tb && tc + 64 > ta) {                                     // wave-uniform: the chunk overlaps the molecule's slabs
+                    for (int ch = 0; ch < NCH; ++ch) {
                         const float dx = cx[ch] - xi, dy = cy[ch] - yi, dz = cz[ch] - zi;
                         const float r2 = dx * dx + dy * dy + dz * dz;
                         // (one compare per ballot: the molecule itself, r2 = 0, is let in here and dropped when its row is sorted)
                         const bool hit = r2 < rn2_hi;
-                        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);         // (no branch on it: most chunks hold a hit)
-                        const int p = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                        int p = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
                         if (hit && p < kPairRowCap) W.rows[il][p] = ck[ch];
                         cnt += __popcll(m);
-                        amb |= m & __builtin_amdgcn_ballot_w64(r2 > rn2_lo);
-                        ninner += __popcll(__builtin_amdgcn_ballot_w64(r2 < (float)kRcSq));
+                        inner_l += r2 < (float)kRcSq ? 1 : 0;
+                        amb_l = __builtin_fabsf(r2 - (float)kRnSq) < eps_ ? 1 : amb_l;  // inside the band: a hit, and ambiguous
+                    }
+                    const int ninner = __builtin_amdgcn_readlane(dpp_wave_sum_i32(inner_l), 63);
+                    const unsigned long long amb = __builtin_amdgcn_ballot_w64(amb_l != 0);
+                    if (lane == 0) {
+                        W.cnt[il] = (cnt & 0x3fffffff) | (amb != 0ull ? 0x40000000 : (W.cnt[il] & 0x40000000));
+                        W.ncin[il] += ninner;                              // (counts the molecule itself once: taken off below)
                     }
                 }
-                if (lane == 0) {
-                    W.cnt[il] = (cnt & 0x3fffffff) | (amb != 0ull ? 0x40000000 : (W.cnt[il] & 0x40000000));
-                    W.ncin[il] += ninner;                                  // (counts the molecule itself once: taken off below)
-                }
-            }
+            };
+            if (nch <= 4) run_batch(std::integral_constant<int, 4>{}); else run_batch(std::integral_constant<int, kPairChunks>{});
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
