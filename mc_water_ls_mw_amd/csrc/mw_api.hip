@@ -369,16 +369,19 @@ int launch_build(int first, int count)
 {
     const int box0 = first - 1;
     ++g.list_version;
-    hipLaunchKernelGGL(mw::k_init_stats, dim3((count + 255) / 256), dim3(256), 0, g.stream, g.d_stats, box0, count);   // {min, max} per box
-    HIPCHK(hipGetLastError());
     int ngrid = 0;
     for (int b = box0; b < box0 + count; ++b) ngrid += g.h_usegrid[b] ? 1 : 0;
+    const bool fused_sort = ngrid > 0 && g.sort_in_lds && !g.legacy_search;       // k_cell_sort_box resets the statistics itself
+    if (!fused_sort) {
+        hipLaunchKernelGGL(mw::k_init_stats, dim3((count + 255) / 256), dim3(256), 0, g.stream, g.d_stats, box0, count);   // {min, max} per box
+        HIPCHK(hipGetLastError());
+    }
     dim3 grid((g.N + 255) / 256, count);
     if (ngrid > 0) {
-        if (g.sort_in_lds && !g.legacy_search) {
+        if (fused_sort) {
             // boxes whose cell-ordered records fit LDS: bin + scan + scatter in one workgroup per box
             hipLaunchKernelGGL(mw::k_cell_sort_box, dim3(count), dim3(1024), sort_box_lds_bytes(), g.stream, g.d_pos, g.d_grid,
-                               g.d_cstart, g.d_wpos, g.d_wsh, g.N, g.cstride, box0);
+                               g.d_cstart, g.d_wpos, g.d_wsh, g.d_stats, g.N, g.cstride, box0);
             HIPCHK(hipGetLastError());
         } else {
         HIPCHK(hipMemsetAsync(g.d_ccount + (size_t)box0 * g.cstride, 0, sizeof(int) * (size_t)count * g.cstride, g.stream));
@@ -412,8 +415,10 @@ int launch_build(int first, int count)
                 const int B = std::min(bcells, G.nc[2]);
                 maxblocks = std::max(maxblocks, G.nc[0] * G.nc[1] * ((G.nc[2] + B - 1) / B));
             }
-            hipLaunchKernelGGL(mw::k_cell_pairs, dim3((maxblocks + 3) / 4, count), dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_grid,
-                               g.d_cstart, g.d_wpos, g.d_wsh, g.d_listm, g.d_nn, g.d_cin, g.d_stats, g.N, g.S, g.ivcap, g.cstride, box0, bcells);
+            const int nwg = (maxblocks + 3) / 4, count8 = (count + 7) & ~7;       // a 1-D grid: the kernel maps workgroup -> (box, cell blocks) by XCD
+            hipLaunchKernelGGL(mw::k_cell_pairs, dim3((unsigned)nwg * (unsigned)count8), dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_grid,
+                               g.d_cstart, g.d_wpos, g.d_wsh, g.d_listm, g.d_nn, g.d_cin, g.d_stats, g.N, g.S, g.ivcap, g.cstride, box0, bcells,
+                               nwg, count);
         }
         HIPCHK(hipGetLastError());
     }

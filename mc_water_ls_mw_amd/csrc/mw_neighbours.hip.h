@@ -224,7 +224,7 @@ __device__ __forceinline__ CellRec cell_record(const GridDesc& G, const double* 
 
 __global__ __launch_bounds__(1024)
 void k_cell_sort_box(const double* __restrict__ pos, const GridDesc* __restrict__ grid,
-                     int* __restrict__ start, float4* __restrict__ wpos, int* __restrict__ wsh,
+                     int* __restrict__ start, float4* __restrict__ wpos, int* __restrict__ wsh, int* __restrict__ stats,
                      int N, int cstride, int box0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sortbox_lds[];
@@ -232,6 +232,7 @@ void k_cell_sort_box(const double* __restrict__ pos, const GridDesc* __restrict_
     __shared__ int carry;
     const int b = box0 + blockIdx.x;
     const GridDesc& G = grid[b];
+    if (threadIdx.x == 0) { stats[2 * b] = 0x7fffffff; stats[2 * b + 1] = 0; }   // {min, max} row length of this build (k_init_stats' job)
     if (G.nc[0] == 0) return;                                             // this box keeps the brute-force kernel
     float4* s_w = reinterpret_cast<float4*>(sortbox_lds);                 // [N] records in cell order
     int* s_sh = reinterpret_cast<int*>(s_w + N);                          // [N]
@@ -398,12 +399,14 @@ void k_cell_search(const double* __restrict__ pos, const double* __restrict__ iv
 //     molecule-major list; k_list_order derives the slot-major layout.
 // Needs >= 3 grid cells along every cell vector and bcells <= nc[2] (each (cell, wrap) pair, hence each image of a
 // molecule, is a candidate at most once).
-//   grid = (ceil(max blocks of cells / 4), boxes), block = 256 (wavefront w of workgroup x takes cell block 4x + w);
+//   grid = ceil(max blocks of cells / 4) * (boxes rounded up to 8), block = 256 (wavefront w of a box's workgroup x takes
+//   cell block 4x + w);
 //   64 VGPRs and 25.5 KB of LDS per workgroup: six workgroups = 24 wavefronts per CU
 // =====================================================================================
 constexpr int kPairChunks = 5;      // candidate chunks (of 64) held in registers per batch (more candidates: more batches)
-constexpr int kPairIB = 16;         // molecules of the cell block per block of rows (more molecules: more passes)
-constexpr int kPairRowCap = 64;     // single-precision hits kept per molecule
+constexpr int kPairIB = 20;         // molecules of the cell block per block of rows at most (more molecules: another block of rows)
+constexpr int kPairRowWords = 1040;  // LDS words for a block of rows: rows of `rowcap` = maxneigh + 2 (rounded up to 4) entries, i.e.
+                                     // 20 rows at maxneigh = 50, 15 at 64 (a wavefront's ~18 molecules then need one block, not two)
 constexpr int kPairMaxB = 5;        // grid cells per wavefront at most
 constexpr int kPairPieces = 9 * (kPairMaxB + 2);
 constexpr int kPairLookup = 320;    // enumeration positions with a one-read piece lookup (beyond: binary search)
@@ -412,7 +415,7 @@ constexpr uint32_t kNoEntry = 0xffffffffu;
 // (sized so that six workgroups of four wavefronts fit a CU's 160 KiB: the kernel is latency bound -- 13 % slower with
 // four workgroups per CU than with five, 10 % faster with six)
 struct PairsLds {
-    __attribute__((aligned(16))) uint32_t rows[kPairIB][kPairRowCap];   // hits as sort keys: j << 10 | image
+    __attribute__((aligned(16))) uint32_t rows[kPairRowWords];          // [rows][rowcap] hits as sort keys: j << 10 | image
     float4 own[kPairIB];                         // the block's molecules (position relative to the block origin, index)
     int ownsh[kPairIB];                          // their packed shifts
     int cnt[kPairIB];                            // hits per molecule (bit 30: an ambiguous hit, re-decide in double precision)
@@ -439,10 +442,21 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
                   const GridDesc* __restrict__ grid, const int* __restrict__ start,
                   const float4* __restrict__ wpos, const int* __restrict__ wsh,
                   uint32_t* __restrict__ listm, int* __restrict__ nn, unsigned char* __restrict__ cin,
-                  int* __restrict__ stats, int N, int S, int ivcap, int cstride, int box0, int bcells_max)
+                  int* __restrict__ stats, int N, int S, int ivcap, int cstride, int box0, int bcells_max,
+                  int nwg_per_box, int count)
 {
     __shared__ PairsLds lds[4];
-    const int b = box0 + blockIdx.y;
+    const int rowcap = (S + 2 + 3) & ~3;                                  // hits kept per molecule: maxneigh, itself, one to tell an overflow
+    const int ibmax = min(kPairIB, kPairRowWords / rowcap);               // rows per block of rows
+    // XCD-aware placement: the hardware deals consecutive workgroups to the 8 XCDs in turn, and each XCD has its own L2.
+    // A box's cell-ordered records (80 KB) are read ~27 times over by the wavefronts around each cell, so all workgroups of
+    // a box go to ONE XCD (box mod 8): workgroup L -> XCD L mod 8, the (L / 8)-th workgroup that XCD receives.
+    const int L = (int)blockIdx.x;                                         // 1-D grid of nwg_per_box * (count rounded up to 8) workgroups
+    const int xcd = L & 7, kq = L >> 3;
+    const int bl = (kq / nwg_per_box) * 8 + xcd;                          // box of this launch
+    const int wg = kq % nwg_per_box;                                      // its workgroup
+    if (bl >= count) return;
+    const int b = box0 + bl;
     const GridDesc& G = grid[b];
     if (G.nc[0] == 0) return;                                             // this box keeps the brute-force kernel
     const int lane = threadIdx.x & 63;
@@ -450,7 +464,7 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
     const int nc0 = G.nc[0], nc1 = G.nc[1], nc2 = G.nc[2];
     const int B = bcells_max < nc2 ? bcells_max : nc2;                    // cells per wavefront
     const int nb2 = (nc2 + B - 1) / B;                                    // blocks along the third axis
-    const int blk = blockIdx.x * 4 + wave;
+    const int blk = wg * 4 + wave;
     if (blk >= nc0 * nc1 * nb2) return;
     PairsLds& W = lds[wave];
     const int* ST = start + (size_t)b * (cstride + 1);
@@ -513,8 +527,8 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
     const int central = (im0 * w1 + im1) * w2 + im2;
     int wmin = 0x7fffffff, wmax = 0;                                      // row lengths seen by this wavefront
 
-    for (int ib0 = 0; ib0 < nmol; ib0 += kPairIB) {
-        const int nib = min(kPairIB, nmol - ib0);
+    for (int ib0 = 0; ib0 < nmol; ib0 += ibmax) {
+        const int nib = min(ibmax, nmol - ib0);
         // ---- the block's molecules: cell (hence slab range), position relative to the block origin, shift ----------
         if (lane < nib) {
             const int q = qc0 + ib0 + lane;
@@ -588,7 +602,7 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
                     const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.x)));
                     const float yi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.y)));
                     const float zi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.z)));
-                    int cnt = __builtin_amdgcn_readfirstlane(W.cnt[il]);
+                    int cnt = t0 == 0 ? 0 : __builtin_amdgcn_readfirstlane(W.cnt[il]);       // (first batch: the rows are empty)
                     int inner_l = 0, amb_l = 0;
 #pragma unroll
                     for (int ch = 0; ch < NCH; ++ch) {
@@ -598,7 +612,7 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
                         const bool hit = r2 < rn2_hi;
                         const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
                         int p = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-                        if (hit && p < kPairRowCap) W.rows[il][p] = ck[ch];
+                        if (hit && p < rowcap) W.rows[il * rowcap + p] = ck[ch];
                         cnt += __popcll(m);
                         inner_l += r2 < (float)kRcSq ? 1 : 0;
                         amb_l = __builtin_fabsf(r2 - (float)kRnSq) < eps_ ? 1 : amb_l;  // inside the band: a hit, and ambiguous
@@ -627,9 +641,9 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
             const bool rowok = il < nib;
             const int craw = rowok ? W.cnt[il] : 0;
             const int nraw = craw & 0x3fffffff;
-            const int nrow = nraw < kPairRowCap ? nraw : kPairRowCap;
+            const int nrow = nraw < rowcap ? nraw : rowcap;
             const bool active = sl < nrow;
-            uint32_t key = active ? W.rows[il][sl] : kNoEntry;
+            uint32_t key = active ? W.rows[il * rowcap + sl] : kNoEntry;
             int i = 0;
             if (rowok) i = __builtin_bit_cast(int, W.own[il].w);
             if (key == ((uint32_t)i << 10)) key = kNoEntry;                   // (i, central image) is not an entry (molint.F90:532)
@@ -646,7 +660,7 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (rowok) W.rows[il][sl] = key;                                   // the rank loop reads the rows from LDS: dropped entries and the
+            if (rowok && sl < rowcap) W.rows[il * rowcap + sl] = key;                                   // the rank loop reads the rows from LDS: dropped entries and the
                                                                                // lanes past the row's end as kNoEntry (never smaller than a key)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -654,7 +668,7 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
             const bool valid = key != kNoEntry;
             const int nloop = __builtin_amdgcn_readfirstlane(wave_max_i(nrow));
             int rank = 0;                                                     // keys are unique; dropped ones sort last
-            const uint4* k4 = reinterpret_cast<const uint4*>(&W.rows[rowok ? il : 0][0]);
+            const uint4* k4 = reinterpret_cast<const uint4*>(&W.rows[(rowok ? il : 0) * rowcap]);
             for (int e = 0; e < nloop; e += 4) {
                 const uint4 kk = k4[e >> 2];
                 rank += (kk.x < key ? 1 : 0) + (kk.y < key ? 1 : 0) + (kk.z < key ? 1 : 0) + (kk.w < key ? 1 : 0);
@@ -665,7 +679,7 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
             const int ncin = rowok ? max(W.ncin[il] - 1, 0) : 0;
             if (valid && rank < S) LM[(size_t)i * kRow + rank] = pack_entry((int)(key >> 10), (int)(key & 1023u));
             if (rowok && sl == 0) {
-                const int total = nraw > kPairRowCap ? nraw : nvalid;        // more single-precision hits than a row holds: reported as an overflow
+                const int total = nraw > rowcap ? nraw : nvalid;        // more single-precision hits than a row holds: reported as an overflow
                 nn[(size_t)b * N + i] = nvalid < S ? nvalid : S;
                 cin[(size_t)b * N + i] = (unsigned char)((ncin < 127 ? ncin : 127) | (nbnd ? 0x80 : 0));
                 wmin = total < wmin ? total : wmin;
@@ -788,6 +802,24 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
         if (fastrow) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) rv[u] = (4 * u < n) ? row[u] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        // a wavefront of interior molecules (the sort key groups them): every entry is of the central image, the column
+        // is the row as it stands -- one coalesced store per slot, no second pass
+        const bool interior = __ballot(valid && (CI[i] >> 7) != 0) == 0ull;
+        if (fastrow && interior) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (4 * u < nmax) {
+                    const uint32_t e[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (4 * u + v < nmax && valid) L[(size_t)(4 * u + v) * N + t] = 4 * u + v < n ? e[v] : 0u;
+                }
+            }
+            if (valid) NNS[t] = n | (n << 8);
+            const int c0min = __builtin_amdgcn_readfirstlane(wave_min_i(valid ? n : 0x7fff));
+            if (lane == 0 && valid) CM[t >> 6] = nmax | ((c0min > 255 ? 255 : c0min) << 8);
+            continue;
         }
         for (int pass = 0; pass < 2; ++pass) {
             if (fastrow) {
