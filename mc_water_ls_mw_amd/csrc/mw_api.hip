@@ -90,7 +90,6 @@ struct Ctx {
     bool force_brute = false;
     double* d_partial = nullptr;
     unsigned long long* d_cpartial = nullptr;
-    unsigned int* d_done = nullptr;          // per box: workgroups of the running k_model_energy launch that have published their partial
     double* d_energy = nullptr;
     unsigned long long* d_counts = nullptr;
     // device-resident translation driver (walker = nlat consecutive boxes)
@@ -355,11 +354,16 @@ int launch_model_energy(int first, int count)
     const int box0 = first - 1;
     if (ge.lds)
         hipLaunchKernelGGL((mw::k_model_energy<true, 1024, kFullLayout>), grid, dim3(1024), ge.shmem, g.stream, g.d_pos, g.d_ivect,
-                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.d_done, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
+                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
     else
         hipLaunchKernelGGL((mw::k_model_energy<false, 256, kFullLayout, true>), grid, dim3(256), ge.shmem, g.stream, g.d_pos, g.d_ivect,
-                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.d_done, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
-    HIPCHK(hipGetLastError());     // (the workgroup of a box that finishes last sums the box's partials: one launch)
+                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
+    HIPCHK(hipGetLastError());
+    if (ge.nsplit > 1) {           // split boxes: the partials of box b live at [b*nsplit .. b*nsplit+nsplit); unsplit boxes wrote their energy themselves
+        hipLaunchKernelGGL(mw::k_sum_partials, dim3((count + 255) / 256), dim3(256), 0, g.stream, g.d_partial, g.d_cpartial,
+                           g.d_energy, g.d_counts, box0, count, ge.nsplit);
+        HIPCHK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -468,7 +472,7 @@ void release_all()
                     g.d_wswitch, g.d_wshift, g.d_wvol, g.d_wflag, g.d_wwin, g.d_wfac, g.d_wsum, g.d_winflag, g.d_volume, g.d_swlog, g.d_tabscratch, g.d_pos, g.d_ivect,
                     g.d_nivect, g.d_list, g.d_listm, g.d_nn, g.d_stats, g.d_order, g.d_nns, g.d_cmax, g.d_cin, g.d_grid,
                     g.d_usegrid, g.d_cellid, g.d_shift, g.d_sorted, g.d_wrel, g.d_wpos, g.d_wsh, g.d_ccount, g.d_cstart, g.d_ccursor, g.d_partial,
-                    g.d_cpartial, g.d_done, g.d_energy, g.d_counts, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.d_mperm,
+                    g.d_cpartial, g.d_energy, g.d_counts, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.d_mperm,
                     g.d_mwork};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g.h_pin) (void)hipHostFree(g.h_pin);
@@ -609,8 +613,6 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
     { const char* fb = std::getenv("MW_FORCE_BRUTE_NEIGHBOURS"); g.force_brute = fb && *fb && *fb != '0'; }
     HIPCHK(hipMalloc(&g.d_partial, nb * g.nsplit_max * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_cpartial, nb * g.nsplit_max * 2 * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc(&g.d_done, nb * sizeof(unsigned int)));
-    HIPCHK(hipMemset(g.d_done, 0, nb * sizeof(unsigned int)));
     HIPCHK(hipMalloc(&g.d_energy, nb * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_counts, nb * 2 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(g.d_pos, 0, nb * N * 3 * sizeof(double)));

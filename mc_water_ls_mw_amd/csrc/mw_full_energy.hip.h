@@ -1,5 +1,5 @@
 // mw_full_energy.hip.h -- gfx950 (MI355X, CDNA4) device code of the mW energy engine:
-// compute_model_energy (molint.F90:407-499): k_model_energy.
+// compute_model_energy (molint.F90:407-499): k_model_energy, k_sum_partials.
 #pragma once
 
 #include "mw_common.hip.h"
@@ -213,7 +213,7 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
                     const int* __restrict__ nivect, const uint32_t* __restrict__ list,
                     const int* __restrict__ order, const int* __restrict__ nns, const int* __restrict__ cmax,
                     double* __restrict__ partial, unsigned long long* __restrict__ cpartial,
-                    double* __restrict__ energy, unsigned long long* __restrict__ counts, unsigned int* __restrict__ done,
+                    double* __restrict__ energy, unsigned long long* __restrict__ counts,
                     int N, int S, int ivcap, int box0, int nsplit, int chunk)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -297,27 +297,30 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
         for (int w = 0; w < BLOCK / 64; ++w) { p += red_p[w]; t += red_t[w]; }
         if (nsplit == 1) {                               // one workgroup per box: model_energy(ils) and its counts directly
             energy[b] = e; counts[2 * b] = p; counts[2 * b + 1] = t;
-        } else {
-            // several workgroups per box: each publishes its partial, the one that arrives last adds them up in split
-            // order (so the sum does not depend on arrival order) -- no second launch.  Agent scope: the workgroups of a
-            // box may sit on different XCDs, whose L2s are not coherent for plain accesses.
-            const size_t o = (size_t)(b) * nsplit;
-            __hip_atomic_store(partial + o + split, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(cpartial + 2 * (o + split), p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(cpartial + 2 * (o + split) + 1, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned int arrived = __hip_atomic_fetch_add(done + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if (arrived == (unsigned int)nsplit - 1u) {
-                double es = 0.0; unsigned long long ps = 0, ts = 0;
-                for (int s = 0; s < nsplit; ++s) {
-                    es += __hip_atomic_load(partial + o + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ps += __hip_atomic_load(cpartial + 2 * (o + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ts += __hip_atomic_load(cpartial + 2 * (o + s) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                energy[b] = es; counts[2 * b] = ps; counts[2 * b + 1] = ts;
-                __hip_atomic_store(done + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-            }
+        } else {                                         // a split box: k_sum_partials adds the partials in split order
+            const size_t o = (size_t)(b) * nsplit + split;
+            partial[o] = e; cpartial[2 * o] = p; cpartial[2 * o + 1] = t;
         }
     }
+}
+
+// Fixed-order sum of the per-workgroup partials of SPLIT boxes (nsplit > 1): model_energy(ils) and its counts.
+// (A "last workgroup sums" scheme inside k_model_energy needs agent-scope release/acquire around a counter -- on
+// gfx950 an L2 write-back and invalidate per workgroup -- which took the 64 x 32768 launch from 0.19 to 0.46 ms by
+// throwing away the L2 lines its position gathers live on; a second tiny launch is cheaper.)
+__global__ void k_sum_partials(const double* __restrict__ partial, const unsigned long long* __restrict__ cpartial,
+                               double* __restrict__ energy, unsigned long long* __restrict__ counts,
+                               int box0, int count, int nsplit)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int b = box0 + t;
+    double e = 0.0; unsigned long long p = 0, q = 0;
+    for (int s = 0; s < nsplit; ++s) {
+        const size_t o = (size_t)b * nsplit + s;
+        e += partial[o]; p += cpartial[2 * o]; q += cpartial[2 * o + 1];
+    }
+    energy[b] = e; counts[2 * b] = p; counts[2 * b + 1] = q;
 }
 
 }  // namespace mw
