@@ -343,8 +343,10 @@ int volume_move_wave(const VolCtx& c, const SweepParams& sp, const double* weigh
 // Per-walker tables (two lattices only): weight / histogram / unbiased_hist [walker][nbins]; every walker
 // reads its OWN weights in eta_weight, so Wang-Landau updates stay local until the host synchronises them
 // (comms_allreduce_eta/hist/uhist semantics, WalkerComms).
+// Two wavefronts per SIMD are the design point (one walker per wavefront, 512 VGPRs per SIMD lane): the build with volume
+// moves must stay within 256 VGPRs -- at 264 it ran ONE wavefront per SIMD and the NPT farm lost a third of its rate.
 template <bool LDSPOS, bool LDSLIST, bool WITHVOL>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_sweep_translation(double* pos, double* hmat, double* ivect,
                          int* nivect, const uint32_t* __restrict__ listm, const uint32_t* __restrict__ list,
                          const int* __restrict__ nn, const int* __restrict__ order, const int* __restrict__ nns,

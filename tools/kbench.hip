@@ -6,7 +6,6 @@
 // The whole engine is compiled into this program (the include below), so the variants run on the engine's own
 // device state: lists built by the product builder, energies checked against the product kernel.
 #include "../mc_water_ls_mw_amd/csrc/mw_api.hip"
-#include "kbench_variants.hip.h"
 
 #include <algorithm>
 #include <chrono>
