@@ -181,6 +181,22 @@ __device__ __forceinline__ double dpp_wave_sum(double v)
     v += dpp_mov_f64<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
     return v;
 }
+// Two wave sums for the price of one: v_permlane32_swap (gfx950) exchanges the upper 32 lanes of `a` with the lower 32 of
+// `b`, so one add folds both sums to 32 lanes each -- a's in lanes 0..31, b's in lanes 32..63 -- and a five-step DPP
+// reduction inside the halves finishes both.  Returns the sums through lanes 31 and 63.
+__device__ __forceinline__ void dpp_wave_sum2(double a, double b, double& sum_a, double& sum_b)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    double v = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    v += dpp_mov_f64<0x111, 0xf>(v);      // row_shr:1
+    v += dpp_mov_f64<0x112, 0xf>(v);      // row_shr:2
+    v += dpp_mov_f64<0x114, 0xf>(v);      // row_shr:4
+    v += dpp_mov_f64<0x118, 0xf>(v);      // row_shr:8
+    v += dpp_mov_f64<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    sum_a = readlane_f64(v, 31);
+    sum_b = readlane_f64(v, 63);
+}
 // Minimum over the 64 lanes, same network; lanes a step does not reach keep their own value.  Lane 63 ends up with it.
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_keep_f64(double v)

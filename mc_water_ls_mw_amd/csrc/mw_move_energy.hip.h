@@ -239,6 +239,7 @@ struct MoveRes { double eo, en; unsigned int io, so, in_, sn; };
 constexpr int kCap = 24;                       // more in-range neighbours than this: plain routine
 struct WaveScratch {
     double q[3][kCap];                         // position of j's image            (molint.F90:269)
+    double c[3][kCap];                         // j's image vector minus that position: takes r_k + ivect(k) into j's frame in ONE add
     double rinvo[kCap], rinvn[kCap];           // 1/r_ij at the old / trial position
     double go[kCap], gn[kCap];                 // exp(gamma sigma/(r_ij - a sigma)) old / trial
     int flag[kCap];                            // bit0 = in range of the old position, bit1 = of the trial position
@@ -330,6 +331,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     if (inu) {
         if (half == 0) {
             ws->q[0][rank] = qx; ws->q[1][rank] = qy; ws->q[2][rank] = qz;
+            ws->c[0][rank] = jvx - qx; ws->c[1][rank] = jvy - qy; ws->c[2][rank] = jvz - qz;
             ws->rinvo[rank] = rinv; ws->go[rank] = g;
             ws->flag[rank] = flg;
         } else {
@@ -403,17 +405,18 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         if (lane < nq) {
             const uint32_t e2 = ws->qe[lane];
             const int qw = ws->qown[lane];
-            const int own = qw & 31, kj = (qw >> 5) & 1023, fl = qw >> 25;
+            const int own = qw & 31, fl = qw >> 25;
             const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
-            double xk, yk, zk, kvx, kvy, kvz, sjx, sjy, sjz;
+            double xk, yk, zk, kvx, kvy, kvz;
             getpos(kk, xk, yk, zk);
             getiv(k2, kvx, kvy, kvz);
-            getiv(kj, sjx, sjy, sjz);
             const double pjx = ws->q[0][own], pjy = ws->q[1][own], pjz = ws->q[2][own];
             const double ro = ws->rinvo[own], rn = ws->rinvn[own], go_ = ws->go[own], gn_ = ws->gn[own];
-            const double bx = ((xk + kvx) + sjx) - pjx;                          // :332,334
-            const double by = ((yk + kvy) + sjy) - pjy;
-            const double bz = ((zk + kvz) + sjz) - pjz;
+            // r_jk = (r_k + ivect(k)) + (ivect(j) - q_j)   (:332,334, the last two terms taken together in pass 0: the very
+            // expression the scan used for the in-range decision)
+            const double bx = (xk + kvx) + ws->c[0][own];
+            const double by = (yk + kvy) + ws->c[1][own];
+            const double bz = (zk + kvz) + ws->c[2][own];
             const double s2 = bx * bx + by * by + bz * bz;                       // :335 (in range: tested at scan)
             double rk, gk, e1k;
             pair_terms(s2, rk, e1k, gk);
@@ -436,25 +439,24 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         const uint32_t e2 = ent_a;
         own_a = own_b; w_a = w_b; ent_a = ent_b;
         if (t0 + 128 < T) fetch(t + 128, own_b, w_b, ent_b);
-        const int kj = wj & 1023;
         const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
-        double xk, yk, zk, kvx, kvy, kvz, sjx, sjy, sjz;
+        double xk, yk, zk, kvx, kvy, kvz;
         getpos(kk, xk, yk, zk);
         getiv(k2, kvx, kvy, kvz);
-        getiv(kj, sjx, sjy, sjz);
-        const double pjx = ws->q[0][own], pjy = ws->q[1][own], pjz = ws->q[2][own];
+        const double cjx = ws->c[0][own], cjy = ws->c[1][own], cjz = ws->c[2][own];
         const bool self = valid && (kk == i);
         const bool selfimg = self && (k2 == ((wj >> 10) & 1023));   // the molecule itself, not an image: k's shift undoes j's
         const bool selfmove = self && !selfimg;
-        const double box_ = ((xk + kvx) + sjx) - pjx;                            // :332,334
-        const double boy_ = ((yk + kvy) + sjy) - pjy;
-        const double boz_ = ((zk + kvz) + sjz) - pjz;
+        const double box_ = (xk + kvx) + cjx;                                    // :332,334 (see the flush)
+        const double boy_ = (yk + kvy) + cjy;
+        const double boz_ = (zk + kvz) + cjz;
         const double s2o = box_ * box_ + boy_ * boy_ + boz_ * boz_;              // :335
         if (__ballot(selfmove) != 0ull) {
             // an image of the molecule itself as third body moves with it: both geometries, in line (rare)
             if (selfmove) {
                 const int fl = wj >> 20;
-                const double bnx = ((xn + kvx) + sjx) - pjx, bny = ((yn + kvy) + sjy) - pjy, bnz = ((zn + kvz) + sjz) - pjz;
+                const double pjx = ws->q[0][own], pjy = ws->q[1][own], pjz = ws->q[2][own];
+                const double bnx = (xn + kvx) + cjx, bny = (yn + kvy) + cjy, bnz = (zn + kvz) + cjz;
                 const double s2n = bnx * bnx + bny * bny + bnz * bnz;
                 double rk, gk, e1k;
                 if ((s2o < kRcSq) && (fl & 1)) {
@@ -483,8 +485,8 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     __builtin_amdgcn_wave_barrier();                          // scratch is reused by the wave's next request
 
     // Wave sums on the DPP network (no LDS round trips): afterwards lane 63 holds the totals.
-    const double eo = readlane_f64(dpp_wave_sum(kLamEps * t3o + (half == 0 ? accp : 0.0)), 63);   // :397
-    const double en = readlane_f64(dpp_wave_sum(kLamEps * t3n + (half == 1 ? accp : 0.0)), 63);
+    double eo, en;                                                                                 // :397
+    dpp_wave_sum2(kLamEps * t3o + (half == 0 ? accp : 0.0), kLamEps * t3n + (half == 1 ? accp : 0.0), eo, en);
     const unsigned int cs = (unsigned int)__builtin_amdgcn_readlane(dpp_wave_sum_i32((int)(nto | (ntn << 16))), 63);
     nto = cs & 0xffffu; ntn = cs >> 16;
     res.eo = eo; res.en = en;
