@@ -368,7 +368,8 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     const int npairs = cntU * (cntU - 1) / 2;
     for (int p0 = 0; p0 < npairs; p0 += 64) {
         const int p = p0 + lane;
-        int b = (int)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+        int b = (int)((1.0f + __builtin_amdgcn_sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);   // (v_sqrt_f32, 1 ulp: the two fix-ups below absorb it;
+                                                                                         //  the IEEE sqrtf expansion costs ~20 instructions)
         if (b * (b - 1) / 2 > p) --b;
         if ((b + 1) * b / 2 <= p) ++b;
         const int a = p - b * (b - 1) / 2;
