@@ -185,6 +185,12 @@ int mw_sweep_windows(int first_walker, int count, const int *start_bin, const in
 /* Per-walker Wang-Landau increment and Swetnam visit total (every rank of the reference has its own; mw_sweep_options
  * sets one increment for all walkers unless 'dd' or wl_swetnam is on).  NULL pointers are skipped. */
 int mw_sweep_set_factors(int first_walker, int count, const double *wl_factor, const double *sumhist);
+/* Per-walker step sizes (bohr): every rank of the reference tunes its own mc_max_trans / mc_dv_max during equilibration
+ * (eq_adjust_mc, mc_monitor_stats, mc_moves.F90:1724-1732).  NULL arrays: everybody back on the values of
+ * mw_sweep_configure / mw_sweep_moves.  mw_sweep_get_counters: accepted translations, attempted and accepted volume
+ * moves per walker since mw_sweep_configure (the host differences them per report interval). */
+int mw_sweep_steps(int first_walker, int count, const double *max_trans_bohr, const double *dv_max_bohr);
+int mw_sweep_get_counters(int first_walker, int count, long long *accepted, long long *vol_attempted, long long *vol_accepted);
 int mw_sweep_get_factors(int first_walker, int count, double *wl_factor, double *sumhist, int *in_window);
 int mw_sweep_moves(double transP, double dv_max_bohr);
 int mw_sweep_get_volume_moves(int walker, long long *attempted, long long *accepted);

@@ -109,6 +109,8 @@ struct Ctx {
     double* d_wwin = nullptr;                    // [walker][4] start_bin, end_bin, mu_lo, mu_hi ('dd' windows); used when has_windows
     double *d_wfac = nullptr, *d_wsum = nullptr; // [walker] Wang-Landau increment, Swetnam's visit total
     int* d_winflag = nullptr;                    // [walker] walker_in_window
+    double* d_wstep = nullptr;                   // [walker][2] max_trans, dv_max (bohr) when the walkers' step sizes differ (mw_sweep_steps)
+    bool has_steps = false;
     bool has_windows = false;
     double* d_volume = nullptr;                  // [box] |det hmatrix|
     int* d_wls = nullptr;
@@ -469,7 +471,7 @@ void release_all()
     if (g.h_head) (void)hipHostFree(g.h_head);
     if (g.h_slots) (void)hipHostFree(g.h_slots);
     void* ptrs[] = {g.d_hmat, g.d_sw_mubin, g.d_sw_binwidth, g.d_wweight, g.d_whist, g.d_wuhist, g.d_wls, g.d_wmu, g.d_wacc,
-                    g.d_wswitch, g.d_wshift, g.d_wvol, g.d_wflag, g.d_wwin, g.d_wfac, g.d_wsum, g.d_winflag, g.d_volume, g.d_swlog, g.d_tabscratch, g.d_pos, g.d_ivect,
+                    g.d_wswitch, g.d_wshift, g.d_wvol, g.d_wflag, g.d_wwin, g.d_wfac, g.d_wsum, g.d_winflag, g.d_wstep, g.d_volume, g.d_swlog, g.d_tabscratch, g.d_pos, g.d_ivect,
                     g.d_nivect, g.d_list, g.d_listm, g.d_nn, g.d_stats, g.d_order, g.d_nns, g.d_cmax, g.d_cin, g.d_grid,
                     g.d_usegrid, g.d_cellid, g.d_shift, g.d_sorted, g.d_wrel, g.d_wpos, g.d_wsh, g.d_ccount, g.d_cstart, g.d_ccursor, g.d_partial,
                     g.d_cpartial, g.d_energy, g.d_counts, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.d_mperm,
@@ -1226,12 +1228,13 @@ int mw_sweep_configure(int nlat, double beta, double max_trans, int nbins, int e
         HIPCHK(hipMalloc(&g.d_wfac, sizeof(double) * g.nbox));
         HIPCHK(hipMalloc(&g.d_wsum, sizeof(double) * g.nbox));
         HIPCHK(hipMalloc(&g.d_winflag, sizeof(int) * g.nbox));
+        HIPCHK(hipMalloc(&g.d_wstep, sizeof(double) * 2 * g.nbox));
     }
     HIPCHK(hipMemset(g.d_wwin, 0, sizeof(double) * 4 * g.nbox));
     HIPCHK(hipMemset(g.d_wfac, 0, sizeof(double) * g.nbox));
     HIPCHK(hipMemset(g.d_wsum, 0, sizeof(double) * g.nbox));
     HIPCHK(hipMemset(g.d_winflag, 0, sizeof(int) * g.nbox));
-    g.has_windows = false;
+    g.has_windows = false; g.has_steps = false;
     g.sp.dref = 0.0; g.sp.swetnam = 0; g.sp.dd = 0; g.sp.wl_alpha = 1.0; g.sp.orig_wl_factor = 0.0;
     g.sp.mu_min = mu_lo; g.sp.mu_max = mu_hi; g.sp.eq_cycles = 0; g.sp.in_window = 1;
     HIPCHK(hipMemset(g.d_wvol, 0, sizeof(unsigned long long) * 2 * g.nbox));
@@ -1368,6 +1371,44 @@ int mw_sweep_get_factors(int first_walker, int count, double* wl_factor, double*
     if (sumhist) HIPCHK(hipMemcpyAsync(sumhist, g.d_wsum + (first_walker - 1), sizeof(double) * count, hipMemcpyDeviceToHost, g.stream));
     if (in_window) HIPCHK(hipMemcpyAsync(in_window, g.d_winflag + (first_walker - 1), sizeof(int) * count, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int mw_sweep_steps(int first_walker, int count, const double* max_trans_bohr, const double* dv_max_bohr)
+{
+    MW_LOCK;
+    if (check_live() || check_walker(first_walker, count)) return 1;
+    if (!max_trans_bohr || !dv_max_bohr) { g.has_steps = false; return 0; }
+    if (!g.has_steps) {          // walkers outside the range given keep the common values
+        std::vector<double> all((size_t)g.nwalkers * 2);
+        for (int k = 0; k < g.nwalkers; ++k) { all[2 * (size_t)k] = g.sp.max_trans; all[2 * (size_t)k + 1] = g.sp.dv_max; }
+        HIPCHK(hipMemcpyAsync(g.d_wstep, all.data(), sizeof(double) * all.size(), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    std::vector<double> w((size_t)count * 2);
+    for (int k = 0; k < count; ++k) {
+        if (!(max_trans_bohr[k] > 0.0) || !(dv_max_bohr[k] >= 0.0)) return fail("mw_sweep_steps: walker %d has step sizes %g, %g", first_walker + k, max_trans_bohr[k], dv_max_bohr[k]);
+        w[2 * (size_t)k] = max_trans_bohr[k]; w[2 * (size_t)k + 1] = dv_max_bohr[k];
+    }
+    HIPCHK(hipMemcpyAsync(g.d_wstep + 2 * (size_t)(first_walker - 1), w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    g.has_steps = true;
+    return 0;
+}
+
+int mw_sweep_get_counters(int first_walker, int count, long long* accepted, long long* vol_attempted, long long* vol_accepted)
+{
+    MW_LOCK;
+    if (check_live() || check_walker(first_walker, count)) return 1;
+    std::vector<unsigned long long> a((size_t)count), v((size_t)count * 2);
+    HIPCHK(hipMemcpyAsync(a.data(), g.d_wacc + (first_walker - 1), sizeof(unsigned long long) * count, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(v.data(), g.d_wvol + 2 * (size_t)(first_walker - 1), sizeof(unsigned long long) * 2 * count, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (int k = 0; k < count; ++k) {
+        if (accepted) accepted[k] = (long long)a[(size_t)k];
+        if (vol_attempted) vol_attempted[k] = (long long)v[2 * (size_t)k];
+        if (vol_accepted) vol_accepted[k] = (long long)v[2 * (size_t)k + 1];
+    }
     return 0;
 }
 
@@ -1650,7 +1691,7 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
                        g.d_listm, g.d_list, g.d_nn, g.d_order, g.d_nns, g.d_cmax, g.d_energy, g.d_wls, g.d_wmu, g.d_wacc, g.d_wswitch, g.d_wshift, g.sp, g.d_wweight, g.d_whist, g.d_wuhist,
                        g.d_sw_mubin, g.d_sw_binwidth, g.d_volume, g.d_wvol, g.d_wflag, g.N, g.S, g.ivcap, nmoves, seed, move0,
                        first_walker - 1, dlog, rstride, g.has_windows ? (const double*)g.d_wwin : (const double*)nullptr,
-                       g.d_wfac, g.d_wsum, g.d_winflag);
+                       g.d_wfac, g.d_wsum, g.d_winflag, g.has_steps ? g.d_wstep : nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }

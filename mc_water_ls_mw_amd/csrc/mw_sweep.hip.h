@@ -359,7 +359,7 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
                          int N, int S, int ivcap, int nmoves, unsigned long long seed, unsigned long long move0,
                          int walker0, double* __restrict__ mvlog, int rstride,
                          const double* __restrict__ wwin, double* __restrict__ wfac, double* __restrict__ wsum,
-                         int* __restrict__ winflag)
+                         int* __restrict__ winflag, const double* __restrict__ wstep)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ WaveScratch ws;
@@ -377,6 +377,7 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
         sp.mu_lo = wwin[4 * (size_t)wlk + 2]; sp.mu_hi = wwin[4 * (size_t)wlk + 3];
     }
     sp.in_window = sp.dd ? winflag[wlk] : 1;                              // mc_moves.F90:112,872
+    if (wstep) { sp.max_trans = wstep[2 * (size_t)wlk]; sp.dv_max = wstep[2 * (size_t)wlk + 1]; }   // per-walker step sizes (equilibration tuning, :1729-1732)
     double wlf = L == 2 ? wfac[wlk] : 0.0;                                // wl_factor of this walker (:1615,1677)
     double sumh = L == 2 ? wsum[wlk] : 0.0;                               // sumhist (:94,1638)
     const double invPi = 1.0 / 3.141592653589793238462643383279502884197;

@@ -24,7 +24,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         samplerun=False, weight=None, npt=False, pressure_atm=1.0,
         flat_chk_int=10000, wl_schedule=0, wl_flattol=0.05, wl_minhist=20, wl_useinvt=False, file_wl_factor=None,
         deltaG_int=100000, max_mc_cycles=None, eq_mc_cycles=0, outdir=None, thermalise=True, regauge=False,
-        parallel_strategy="mw", window_overlap=2, leshift=False, input_ref_enthalpy=None, wl_swetnam=False, wl_alpha=1.0):
+        parallel_strategy="mw", window_overlap=2, leshift=False, input_ref_enthalpy=None, wl_swetnam=False, wl_alpha=1.0,
+        eq_adjust_mc=False, mc_target_ratio=0.5, monitor_int=1000, mc_max_trans_ang=1.1, mc_dv_max_ang=0.924):
     """Run `cycles` MC cycles of `walkers` two-lattice walkers on this GPU.  Returns a dict of results.
 
     ``flat_chk_int`` ... ``file_wl_factor``: the Wang-Landau schedule (mc_check_flatness, :291-294;
@@ -38,7 +39,9 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
     'dd' (mc_moves.F90:659-709: every walker of every GPU is one window of ``world x walkers``, overlapping its
     neighbours by ``window_overlap`` bins, with its own increment and flatness check and no exchange; the windows are
     stitched at the end as mc_monitor_stats does, :1851-1925).  ``leshift`` / ``input_ref_enthalpy``: userparams.f90:41,57;
-    ``wl_swetnam`` / ``wl_alpha``: mc_moves.F90:1636-1653."""
+    ``wl_swetnam`` / ``wl_alpha``: mc_moves.F90:1636-1653.  ``eq_adjust_mc`` / ``mc_target_ratio`` / ``monitor_int``: every
+    monitor_int cycles the stored energies are replaced by freshly computed ones and, below eq_mc_cycles, every walker's
+    step sizes are tuned toward the target acceptance ratio (mc_monitor_stats, :1724-1732,1783-1787)."""
     from . import lattice as lat
     from .energy import EnergyModule
     from .schedule import WangLandauSchedule, WindowSchedules, delta_g_from_hist, log_unbiased_norm
@@ -64,7 +67,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         em.build_neighbours_batch(1, 2 * walkers)
         em.model_energy_batch(1, 2 * walkers)
         grid = MuGrid(nbins, -mu_range, mu_range)
-        farm = WalkerFarm(em, 2, temperature, 1.1, grid=grid, weight=weight, pressure_au=pressure_atm / 2.90363081e8)
+        farm = WalkerFarm(em, 2, temperature, mc_max_trans_ang, grid=grid, weight=weight, pressure_au=pressure_atm / 2.90363081e8)
         comms = farm.local_comms() if comms is None else comms             # one exchange object throughout
         skw = dict(wl_schedule=wl_schedule, wl_flattol=wl_flattol, wl_minhist=wl_minhist, wl_useinvt=wl_useinvt,
                    wl_swetnam=wl_swetnam, samplerun=samplerun, outdir=outdir)
@@ -106,14 +109,20 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                              wl_factor=sched.move_factor(cyc, n), log_unbiased_norm=lun)    # :1615,1655-1657
 
         if npt:                                                    # io.f90:171-172: vol 1/N against trans 0.5
-            farm.moves(trans_prob=0.5, vol_prob=1.0 / n, dv_max_ang=0.924)
+            farm.moves(trans_prob=0.5, vol_prob=1.0 / n, dv_max_ang=mc_dv_max_ang)
         for w in range(1, walkers + 1):                            # :703-704: a window on one side of mu = 0 fixes the lattice
             farm.set_state(w, (sched.windows[w - 1]["ls"] or 1) if dd else 1, farm.initial_mu(w))
+        from .lattice import ANG_TO_BOHR
+        step_t = np.full(walkers, mc_max_trans_ang * ANG_TO_BOHR)  # mc_max_trans / mc_dv_max of every walker, bohr (io.f90:165-166)
+        step_v = np.full(walkers, mc_dv_max_ang * ANG_TO_BOHR)
+        mon_acc = mon_vatt = mon_vacc = np.zeros(walkers, dtype=np.int64)
+        mon_cycle = 0
         t0 = time.perf_counter()
         synced, events, delta_g = None, [], None
         def ends_a_stretch(c):
             """Does the host have something to do after cycle c (or before cycle c + 1)?"""
             return (c == cycles or (c + 1) % list_update_int == 0 or c % mpi_sync_int == 0 or c % flat_chk_int == 0
+                    or c % monitor_int == 0
                     or (samplerun and c % deltaG_int == 0) or c + 1 == eq_mc_cycles or sched.invt_active)
 
         cyc = 0
@@ -137,6 +146,19 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                     farm.check_flags()
                 if not dd:                                         # (:270-272: the windows exchange nothing)
                     synced = farm.synchronise(comms, regauge=regauge)
+            if cyc % monitor_int == 0:                             # mc_monitor_stats, :281-284
+                em.sync()
+                acc, vatt, vacc = farm.counters()
+                if eq_adjust_mc and cyc < eq_mc_cycles:            # :1729-1732, every walker its own (each rank of the reference does)
+                    att_t = (cyc - mon_cycle) * n - (vatt - mon_vatt)
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        atr = (acc - mon_acc) / att_t
+                        avr = (vacc - mon_vacc) / (vatt - mon_vatt)
+                    step_t = np.where(att_t > 0, np.maximum(step_t * atr / mc_target_ratio, 0.1), step_t)
+                    step_v = np.where(vatt - mon_vatt > 0, np.maximum(step_v * avr / mc_target_ratio, 0.0001), step_v)
+                    farm.set_steps(step_t, step_v)
+                mon_acc, mon_vatt, mon_vacc, mon_cycle = acc, vatt, vacc, cyc
+                em.model_energy_batch(1, 2 * walkers)              # :1783-1787: stored energies <- computed ones
             if cyc % flat_chk_int == 0:                            # :291-294
                 em.sync()
                 if dd:
@@ -182,7 +204,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                    weight_max=None if synced is None else float(synced[0].max()),
                    wl_factor=(joined["wl_factor"] if dd else float(farm.factors(1, 1)[0][0]) if wl_swetnam else sched.wl_factor),
                    wl_invt_active=sched.invt_active, flatness_events=events, delta_g=delta_g,
-                   ref_enthalpy=farm.ref_enthalpy)
+                   ref_enthalpy=farm.ref_enthalpy,
+                   max_trans_bohr=step_t[:32].tolist(), dv_max_bohr=step_v[:32].tolist())
         out["tables"] = synced
         out["joined"] = joined
         if dd:
@@ -218,6 +241,8 @@ def main():
     ap.add_argument("--leshift", action="store_true")
     ap.add_argument("--wl-swetnam", action="store_true")
     ap.add_argument("--wl-alpha", type=float, default=1.0)
+    ap.add_argument("--eq-adjust", action="store_true", help="eq_adjust_mc: tune the step sizes during equilibration")
+    ap.add_argument("--monitor", type=int, default=1000, help="monitor_int")
     ap.add_argument("--regauge", action="store_true",
                     help="exchange step sums the weight increments proper and subtracts the window minimum once "
                          "(default: the reference's arithmetic, comms_mpi.f90:256-270)")
@@ -243,7 +268,7 @@ def main():
               wl_schedule=args.wl_schedule, wl_flattol=args.wl_flattol, wl_minhist=args.wl_minhist,
               wl_useinvt=args.wl_useinvt, outdir=args.outdir, regauge=args.regauge, parallel_strategy=args.strategy,
               window_overlap=args.window_overlap, eq_mc_cycles=args.eq_cycles, leshift=args.leshift,
-              wl_swetnam=args.wl_swetnam, wl_alpha=args.wl_alpha)
+              wl_swetnam=args.wl_swetnam, wl_alpha=args.wl_alpha, eq_adjust_mc=args.eq_adjust, monitor_int=args.monitor)
     tabs = res.pop("tables")
     res.pop("walker1_tables"), res.pop("walker1_positions"), res.pop("first_walkers")
     joined = res.pop("joined")

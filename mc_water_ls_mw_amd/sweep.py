@@ -197,6 +197,23 @@ class WalkerFarm:
                                                  iw.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
         return f, sh, iw.astype(bool)
 
+    def set_steps(self, max_trans_bohr=None, dv_max_bohr=None, first_walker=1):
+        """Per-walker step sizes in bohr (None: everybody back on the common ones)."""
+        if max_trans_bohr is None or dv_max_bohr is None:
+            self.em._chk(self.L.mw_sweep_steps(1, self.nwalkers, None, None))
+            return
+        a = np.ascontiguousarray(max_trans_bohr, dtype=np.float64)
+        b = np.ascontiguousarray(dv_max_bohr, dtype=np.float64)
+        self.em._chk(self.L.mw_sweep_steps(first_walker, len(a), a.ctypes.data_as(_dp), b.ctypes.data_as(_dp)))
+
+    def counters(self, first_walker=1, count=None):
+        """(accepted translations, attempted volume moves, accepted volume moves) per walker since configuration."""
+        count = self.nwalkers - first_walker + 1 if count is None else count
+        _lp = ctypes.POINTER(ctypes.c_longlong)
+        a, v, w = (np.zeros(count, dtype=np.int64) for _ in range(3))
+        self.em._chk(self.L.mw_sweep_get_counters(first_walker, count, a.ctypes.data_as(_lp), v.ctypes.data_as(_lp), w.ctypes.data_as(_lp)))
+        return a, v, w
+
     def tables_range(self, first_walker=1, count=None):
         """(weight, histogram, unbiased_hist), each count x nbins."""
         count = self.nwalkers - first_walker + 1 if count is None else count

@@ -241,3 +241,22 @@ def test_ice1_sample_dd_example_in_miniature(so, c_oracle):
     assert np.allclose(res["joined"]["unbiased_hist"], ju, rtol=1e-8, atol=0)
     assert ju[:50].sum() > 0 and ju[50:].sum() > 0
     assert res["delta_g"]["kT"] == pytest.approx(osch.delta_g(ju, grid.binwidth), rel=1e-7)
+
+
+def test_equilibration_step_size_tuning_on_the_farm_follows_the_pinned_oracle(so, c_oracle):
+    """eq_adjust_mc (every shipped example sets it): two independent NPT walkers, a report every 4 cycles, 13 equilibration
+    cycles -- each walker tunes its own mc_max_trans / mc_dv_max from its own acceptance ratios (each rank of the reference
+    does) and gets its stored energies refreshed, as tests/test_options_pin.py pins against the reference program."""
+    from mc_water_ls_mw_amd.farm import run
+    b = boxes48()
+    res = run([b[0][0], b[1][0]], [b[0][1], b[1][1]], walkers=2, cycles=20, temperature=200.0, seed=pin.SEED,
+              thermalise=False, list_update_int=10, mpi_sync_int=10 ** 9, wl_factor=F0, npt=True, pressure_atm=1.0,
+              eq_mc_cycles=13, eq_adjust_mc=True, monitor_int=4, flat_chk_int=10 ** 9)
+    transP = 0.5 / (0.5 + 1.0 / 48)
+    for k in range(2):
+        st, w, hi, max_trans, dv_max, history = top.replay_with_step_adjustment(so, c_oracle, boxes48(), 20, 13, 4, transP, walker=k)
+        fw = res["first_walkers"][k]
+        assert res["max_trans_bohr"][k] == pytest.approx(max_trans, rel=1e-12) and res["dv_max_bohr"][k] == pytest.approx(dv_max, rel=1e-12)
+        assert np.abs(np.array(fw["positions"]) - st.xyz).max() < 1e-8 and fw["ls"] == st.ls
+        assert np.allclose(fw["tables"][1], hi, rtol=1e-12, atol=1e-12) and np.allclose(fw["tables"][0], w, rtol=1e-9, atol=1e-11)
+    assert res["max_trans_bohr"][0] != res["max_trans_bohr"][1]              # every walker its own

@@ -209,3 +209,56 @@ def test_dd_npt_run_in_its_window_matches_the_reference_program(tmp_path, so, c_
     assert np.abs(st.h - pin.run_reference.hmatrix).max() < 1e-10
     assert np.abs(st.xyz - ljr).max() < 1e-9 and st.ls == ls
     assert hist.sum() > 0 and np.allclose(hi, hist, rtol=1e-12, atol=1e-12) and np.allclose(w, wgt, rtol=1e-10, atol=1e-11)
+
+
+def replay_with_step_adjustment(so, c_oracle, boxes, cycles, eq, monitor_int, transP, target=0.5, walker=0):
+    """NPT mc_cycle loop with mc_monitor_stats' equilibration tuning (mc_moves.F90:1724-1732): every monitor_int cycles
+    below eq_mc_cycles, max_trans *= (accepted / attempted translations since the last report) / target (at least 0.1
+    bohr), dv_max likewise from the volume moves (at least 1e-4 bohr); and the stored energies are replaced by freshly
+    computed ones (:1783-1787)."""
+    from mc_water_ls_mw_amd.lattice import ANG_TO_BOHR
+    from mc_water_ls_mw_amd.sweep import KB, MuGrid
+    from oracle import FullSweepState
+    grid = MuGrid(101, -400.0, 400.0)
+    beta, p = 1.0 / (KB * 200.0), 1.0 / pin.AUP_TO_ATM
+    st = FullSweepState(c_oracle, [b[0] for b in boxes], [b[1] for b in boxes])
+    mu = st.model_energy[0] + p * st.volume[0] - st.model_energy[1] - p * st.volume[1]
+    st.ls_mu = mu * beta - 48.0 * np.log(st.volume[0] / st.volume[1])
+    w, hi, uh = np.zeros(101), np.zeros(101), np.zeros(101)
+    max_trans, dv_max = 1.1 * ANG_TO_BOHR, 0.924 * ANG_TO_BOHR
+    acc0, vol0, moves0 = 0, np.zeros(2, dtype=np.int64), 0
+    history = []
+    for cyc in range(1, cycles + 1):
+        if cyc % 10 == 0:
+            st.rebuild_lists(c_oracle)
+        so.full(st, 48, pin.SEED, walker, (cyc - 1) * 48, transP, dv_max, beta, max_trans, grid, w, hi, uh,
+                record=cyc >= eq, samplerun=False, always_switch=True, npt=True, wl_factor=F0, pressure=p)
+        if cyc % monitor_int == 0:
+            att_v, acc_v = int(st.nvol[0] - vol0[0]), int(st.nvol[1] - vol0[1])
+            att_t, acc_t = cyc * 48 - moves0 - att_v, int(st.accepted - acc0)
+            if cyc < eq:
+                max_trans = max(max_trans * (acc_t / att_t) / target, 0.1)
+                dv_max = max(dv_max * (acc_v / att_v) / target, 0.0001)
+            history.append((cyc, max_trans, dv_max))
+            for l in range(2):                                                 # compute_model_energy(ils), :1783-1787
+                st.model_energy[l] = c_oracle.model_energy(st.xyz[l], st.iv(l), *st.lists[l])
+            acc0, vol0, moves0 = st.accepted, st.nvol.copy(), cyc * 48
+    return st, w, hi, max_trans, dv_max, history
+
+
+def test_equilibration_step_size_tuning_matches_the_reference_program(tmp_path, so, c_oracle):
+    """eq_adjust_mc = .true. as in every shipped example: 13 equilibration cycles with a report every 4, then 7 more.
+    The checkpoint holds the tuned mc_max_trans / mc_dv_max next to the configuration they produced."""
+    vol_prob = 0.1
+    transP = 0.5 / (0.5 + vol_prob)
+    boxes, e_ref, ljr, ls, hist, wgt = pin.run_reference(str(tmp_path / "run"), 2, 200, 20, samplerun=False, always_switch=True,
+                                                         tables=True, npt=True, vol_prob=vol_prob, transP=transP,
+                                                         book_extra="eq_adjust_mc = .true.\nmonitor_int = 4\neq_mc_cycles = 13")
+    ref_steps = np.frombuffer(pin.run_reference.records[2], dtype="<f8")
+    st, w, hi, max_trans, dv_max, history = replay_with_step_adjustment(so, c_oracle, boxes, 20, 13, 4, transP)
+    assert len(history) == 5 and history[2][1] != history[0][1]                 # tuned at cycles 4, 8, 12; left alone at 16, 20
+    assert ref_steps[0] == pytest.approx(max_trans, rel=1e-12) and ref_steps[1] == pytest.approx(dv_max, rel=1e-12)
+    assert max_trans != pytest.approx(1.1 * 1.8897259886, rel=1e-3)
+    assert np.abs(st.h - pin.run_reference.hmatrix).max() < 1e-10
+    assert np.abs(st.xyz - ljr).max() < 1e-9 and st.ls == ls
+    assert np.allclose(hi, hist, rtol=1e-12, atol=1e-12) and np.allclose(w, wgt, rtol=1e-10, atol=1e-11)
