@@ -25,7 +25,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         flat_chk_int=10000, wl_schedule=0, wl_flattol=0.05, wl_minhist=20, wl_useinvt=False, file_wl_factor=None,
         deltaG_int=100000, max_mc_cycles=None, eq_mc_cycles=0, outdir=None, thermalise=True, regauge=False,
         parallel_strategy="mw", window_overlap=2, leshift=False, input_ref_enthalpy=None, wl_swetnam=False, wl_alpha=1.0,
-        eq_adjust_mc=False, mc_target_ratio=0.5, monitor_int=1000, mc_max_trans_ang=1.1, mc_dv_max_ang=0.924):
+        eq_adjust_mc=False, mc_target_ratio=0.5, monitor_int=1000, mc_max_trans_ang=1.1, mc_dv_max_ang=0.924,
+        latt_sync_int=10000):
     """Run `cycles` MC cycles of `walkers` two-lattice walkers on this GPU.  Returns a dict of results.
 
     ``flat_chk_int`` ... ``file_wl_factor``: the Wang-Landau schedule (mc_check_flatness, :291-294;
@@ -41,7 +42,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
     stitched at the end as mc_monitor_stats does, :1851-1925).  ``leshift`` / ``input_ref_enthalpy``: userparams.f90:41,57;
     ``wl_swetnam`` / ``wl_alpha``: mc_moves.F90:1636-1653.  ``eq_adjust_mc`` / ``mc_target_ratio`` / ``monitor_int``: every
     monitor_int cycles the stored energies are replaced by freshly computed ones and, below eq_mc_cycles, every walker's
-    step sizes are tuned toward the target acceptance ratio (mc_monitor_stats, :1724-1732,1783-1787)."""
+    step sizes are tuned toward the target acceptance ratio (mc_monitor_stats, :1724-1732,1783-1787).  ``latt_sync_int``:
+    every so many cycles lattice 2 of every walker is re-imposed from its lattice 1 (mc_check_chain_synchronisation, :296-300)."""
     from . import lattice as lat
     from .energy import EnergyModule
     from .schedule import WangLandauSchedule, WindowSchedules, delta_g_from_hist, log_unbiased_norm
@@ -110,6 +112,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
 
         if npt:                                                    # io.f90:171-172: vol 1/N against trans 0.5
             farm.moves(trans_prob=0.5, vol_prob=1.0 / n, dv_max_ang=mc_dv_max_ang)
+        farm.set_reference()                                       # ref_hmatrix / ref_ljr (init.f90:90,106) for the chain synchronisation
         for w in range(1, walkers + 1):                            # :703-704: a window on one side of mu = 0 fixes the lattice
             farm.set_state(w, (sched.windows[w - 1]["ls"] or 1) if dd else 1, farm.initial_mu(w))
         from .lattice import ANG_TO_BOHR
@@ -122,7 +125,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         def ends_a_stretch(c):
             """Does the host have something to do after cycle c (or before cycle c + 1)?"""
             return (c == cycles or (c + 1) % list_update_int == 0 or c % mpi_sync_int == 0 or c % flat_chk_int == 0
-                    or c % monitor_int == 0
+                    or c % monitor_int == 0 or c % latt_sync_int == 0
                     or (samplerun and c % deltaG_int == 0) or c + 1 == eq_mc_cycles or sched.invt_active)
 
         cyc = 0
@@ -168,6 +171,9 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                     ev = sched.check_flatness(cyc, n, farm, comms)
                     if ev["action"] != "none":
                         events.append(ev)
+            if cyc % latt_sync_int == 0:                           # :296-300
+                em.sync()
+                farm.chain_synchronise()
             if samplerun and cyc % deltaG_int == 0:                # :302-306
                 em.sync()
                 if dd:                                             # comms_join_uhist (:2535)

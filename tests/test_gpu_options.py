@@ -260,3 +260,33 @@ def test_equilibration_step_size_tuning_on_the_farm_follows_the_pinned_oracle(so
         assert np.abs(np.array(fw["positions"]) - st.xyz).max() < 1e-8 and fw["ls"] == st.ls
         assert np.allclose(fw["tables"][1], hi, rtol=1e-12, atol=1e-12) and np.allclose(fw["tables"][0], w, rtol=1e-9, atol=1e-11)
     assert res["max_trans_bohr"][0] != res["max_trans_bohr"][1]              # every walker its own
+
+
+def test_chain_synchronisation_inside_the_farm_loop_follows_the_pinned_oracle(so, c_oracle):
+    """latt_sync_int = 5: every fifth cycle of an NPT run lattice 2 is re-imposed from lattice 1 (the loop
+    tests/test_sweep_pin.py pins against the reference program, here through farm.run)."""
+    from mc_water_ls_mw_amd.farm import run
+    from mc_water_ls_mw_amd.lattice import ANG_TO_BOHR
+    from mc_water_ls_mw_amd.sweep import KB, MuGrid
+    from oracle import FullSweepState
+    b = boxes48()
+    res = run([b[0][0], b[1][0]], [b[0][1], b[1][1]], walkers=1, cycles=30, temperature=200.0, seed=pin.SEED,
+              thermalise=False, list_update_int=10, mpi_sync_int=10 ** 9, wl_factor=F0, npt=True, pressure_atm=1.0,
+              eq_mc_cycles=1, latt_sync_int=5, flat_chk_int=10 ** 9)
+    grid = MuGrid(101, -400.0, 400.0)
+    beta, p, transP = 1.0 / (KB * 200.0), 1.0 / pin.AUP_TO_ATM, 0.5 / (0.5 + 1.0 / 48)
+    st = FullSweepState(c_oracle, [b[0][0], b[1][0]], [b[0][1], b[1][1]])
+    mu = st.model_energy[0] + p * st.volume[0] - st.model_energy[1] - p * st.volume[1]
+    st.ls_mu = mu * beta - 48.0 * np.log(st.volume[0] / st.volume[1])
+    w, hi, uh = np.zeros(101), np.zeros(101), np.zeros(101)
+    for cyc in range(1, 31):
+        if cyc % 10 == 0:
+            st.rebuild_lists(c_oracle)
+        so.full(st, 48, pin.SEED, 0, (cyc - 1) * 48, transP, 0.924 * ANG_TO_BOHR, beta, 1.1 * ANG_TO_BOHR, grid, w, hi, uh,
+                record=True, samplerun=False, always_switch=True, npt=True, wl_factor=F0, pressure=p)
+        if cyc % 5 == 0:
+            so.chain_sync(st, beta, p)
+    fw = res["first_walkers"][0]
+    assert st.nvol[1] > 0 and np.abs(np.array(fw["positions"]) - st.xyz).max() < 1e-8 and fw["ls"] == st.ls
+    assert abs(fw["ls_mu"] - st.ls_mu) < 1e-6 * (1 + abs(st.ls_mu))
+    assert np.allclose(fw["tables"][1], hi, rtol=1e-12, atol=1e-12) and np.allclose(fw["tables"][0], w, rtol=1e-9, atol=1e-11)
