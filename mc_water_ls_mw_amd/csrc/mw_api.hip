@@ -126,6 +126,7 @@ struct Ctx {
     double *d_mtrial = nullptr, *d_meold = nullptr, *d_menew = nullptr;
     unsigned int* d_mcnt = nullptr;
     int* d_mperm = nullptr;        // sorted request -> caller's index
+    int* d_mdecl = nullptr;        // [0] count, then {request, box} of the requests k_move_energy left to k_move_fallback
     int4* d_mwork = nullptr;       // work items {box, begin, end, 0}
     int mwork_cap = 0, mwork_n = 0;
     bool mlds = false;
@@ -310,7 +311,7 @@ int ensure_moves(int n)
     HIPCHK(hipStreamSynchronize(g.stream));
     if (g.d_mimol) {
         HIPCHK(hipFree(g.d_mimol)); HIPCHK(hipFree(g.d_mtrial)); HIPCHK(hipFree(g.d_meold));
-        HIPCHK(hipFree(g.d_menew)); HIPCHK(hipFree(g.d_mcnt)); HIPCHK(hipFree(g.d_mperm));
+        HIPCHK(hipFree(g.d_menew)); HIPCHK(hipFree(g.d_mcnt)); HIPCHK(hipFree(g.d_mperm)); HIPCHK(hipFree(g.d_mdecl));
         g.d_mimol = nullptr; g.mcap = 0;
     }
     int cap = 1024;
@@ -321,6 +322,7 @@ int ensure_moves(int n)
     HIPCHK(hipMalloc(&g.d_menew, sizeof(double) * cap));
     HIPCHK(hipMalloc(&g.d_mcnt, sizeof(unsigned int) * 4 * cap));
     HIPCHK(hipMalloc(&g.d_mperm, sizeof(int) * cap));
+    HIPCHK(hipMalloc(&g.d_mdecl, sizeof(int) * (2 * (size_t)cap + 1)));
     g.mcap = cap;
     return 0;
 }
@@ -474,7 +476,7 @@ void release_all()
                     g.d_wswitch, g.d_wshift, g.d_wvol, g.d_wflag, g.d_wwin, g.d_wfac, g.d_wsum, g.d_winflag, g.d_wstep, g.d_volume, g.d_swlog, g.d_tabscratch, g.d_pos, g.d_ivect,
                     g.d_nivect, g.d_list, g.d_listm, g.d_nn, g.d_stats, g.d_order, g.d_nns, g.d_cmax, g.d_cin, g.d_grid,
                     g.d_usegrid, g.d_cellid, g.d_shift, g.d_sorted, g.d_wrel, g.d_wpos, g.d_wsh, g.d_ccount, g.d_cstart, g.d_ccursor, g.d_partial,
-                    g.d_cpartial, g.d_energy, g.d_counts, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.d_mperm,
+                    g.d_cpartial, g.d_energy, g.d_counts, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.d_mperm, g.d_mdecl,
                     g.d_mwork};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g.h_pin) (void)hipHostFree(g.h_pin);
@@ -1099,15 +1101,20 @@ static int launch_moves(int mode)
 {
     if (g.mn == 0) return 0;
     const size_t iv_bytes = kMoveScratch + mw::lds_vec_bytes((size_t)g.ivcap);
+    HIPCHK(hipMemsetAsync(g.d_mdecl, 0, sizeof(int), g.stream));           // nothing declined yet
     if (g.mlds)
         hipLaunchKernelGGL(mw::k_move_energy<true>, dim3(g.mwork_n), dim3(1024),
                            iv_bytes + mw::lds_vec_bytes((size_t)g.N) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
-                           g.d_meold, g.d_menew, g.d_mcnt, g.N, g.ivcap, mode);
+                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, mode);
     else
         hipLaunchKernelGGL(mw::k_move_energy<false>, dim3(g.mwork_n), dim3(1024), iv_bytes, g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
-                           g.d_meold, g.d_menew, g.d_mcnt, g.N, g.ivcap, mode);
+                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, mode);
+    HIPCHK(hipGetLastError());
+    // the requests the fused routine declined (none on ice): plain routine, one wavefront each
+    hipLaunchKernelGGL(mw::k_move_fallback, dim3(std::min(1024, (g.mn + 3) / 4)), dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_listm, g.d_nn,
+                       g.d_mimol, g.d_mtrial, g.d_mperm, g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, mode);
     HIPCHK(hipGetLastError());
     g.mmode = mode;
     return 0;

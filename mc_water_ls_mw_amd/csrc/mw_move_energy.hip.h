@@ -511,6 +511,7 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
                    const int* __restrict__ perm,
                    double* __restrict__ e_old, double* __restrict__ e_new,
                    unsigned int* __restrict__ counts,   // [nreq][4]: inter_old, slots_old, inter_new, slots_new
+                   int* __restrict__ declined,          // [0] = number of requests left to k_move_fallback, then {request, box} pairs
                    int N, int ivcap, int mode)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -582,17 +583,53 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
         MoveRes r;
         const bool fast = move_energy_wave(getpos, getiv, row, nnof, ws, niv, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r);
         if (!fast) {
-            Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
-            Override tr; tr.idx = i; tr.x = xn; tr.y = yn; tr.z = zn;
-            r.eo = local_energy_wave(P, IV, LM, NN, i, none, none, lane, r.io, r.so);
-            r.en = local_energy_wave(P, IV, LM, NN, i, tr, none, lane, r.in_, r.sn);
-        }
-        if (lane == 0) {
+            // a request the fused routine declines (a row longer than 32 entries, more than kCap in-range neighbours, a
+            // molecule that neighbours its own image -- never on ice) is left to k_move_fallback: with the plain routine
+            // inlined here its registers counted against this loop (37 scalar registers spilled to vector lanes, ~30
+            // vector instructions per request on moving them), and calling it out of line costs scratch (+8 % time)
+            if (lane == 0) {
+                const int k = atomicAdd(&declined[0], 1);
+                declined[1 + 2 * k] = m; declined[2 + 2 * k] = b;
+            }
+        } else if (lane == 0) {
             const size_t o = (size_t)perm[m];
             if (mode & 1) { e_old[o] = r.eo; counts[4 * o] = r.io; counts[4 * o + 1] = r.so; }
             if (mode & 2) { e_new[o] = r.en; counts[4 * o + 2] = r.in_; counts[4 * o + 3] = r.sn; }
         }
         cur = nxt; i = i_nx; e = e_nx; tx = tx_nx; ty = ty_nx; tz = tz_nx;
+    }
+}
+
+// The requests k_move_energy declined, one wavefront each with the plain routine (positions and rows from global memory).
+//   grid = any, block = 256; exits at once when nothing was declined
+__global__ __launch_bounds__(256)
+void k_move_fallback(const double* __restrict__ pos, const double* __restrict__ ivect,
+                     const uint32_t* __restrict__ listm, const int* __restrict__ nn,
+                     const int* __restrict__ req_imol, const double* __restrict__ req_trial, const int* __restrict__ perm,
+                     double* __restrict__ e_old, double* __restrict__ e_new, unsigned int* __restrict__ counts,
+                     const int* __restrict__ declined, int N, int ivcap, int mode)
+{
+    const int n = declined[0];
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)(blockIdx.x * (blockDim.x >> 6)) + (int)(threadIdx.x >> 6), nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int k = wave; k < n; k += nwaves) {
+        const int m = declined[1 + 2 * k], b = declined[2 + 2 * k];
+        const double* P  = pos + (size_t)b * N * 3;
+        const double* IV = ivect + (size_t)b * ivcap * 3;
+        const uint32_t* LM = listm + (size_t)b * N * kRow;
+        const int* NN = nn + (size_t)b * N;
+        const int i = req_imol[m];
+        Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
+        Override tr; tr.idx = -1; tr.x = tr.y = tr.z = 0.0;
+        if (mode & 2) { tr.idx = i; tr.x = req_trial[3 * (size_t)m]; tr.y = req_trial[3 * (size_t)m + 1]; tr.z = req_trial[3 * (size_t)m + 2]; }
+        MoveRes r;
+        r.eo = local_energy_wave(P, IV, LM, NN, i, none, none, lane, r.io, r.so);
+        r.en = local_energy_wave(P, IV, LM, NN, i, tr, none, lane, r.in_, r.sn);
+        if (lane == 0) {
+            const size_t o = (size_t)perm[m];
+            if (mode & 1) { e_old[o] = r.eo; counts[4 * o] = r.io; counts[4 * o + 1] = r.so; }
+            if (mode & 2) { e_new[o] = r.en; counts[4 * o + 2] = r.in_; counts[4 * o + 3] = r.sn; }
+        }
     }
 }
 

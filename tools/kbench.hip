@@ -36,7 +36,7 @@ static void launch_mv()
     hipLaunchKernelGGL((mw::k_move_energy<true, LAYOUT>), dim3(g.mwork_n), dim3(1024),
                        iv_bytes + mw::lds_vec_bytes((size_t)g.N) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
                        g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
-                       g.d_meold, g.d_menew, g.d_mcnt, g.N, g.ivcap, 3);
+                       g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, 3);
 }
 
 int main(int argc, char** argv)
