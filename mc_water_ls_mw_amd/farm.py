@@ -247,6 +247,7 @@ def main():
     ap.add_argument("--leshift", action="store_true")
     ap.add_argument("--wl-swetnam", action="store_true")
     ap.add_argument("--wl-alpha", type=float, default=1.0)
+    ap.add_argument("--no-thermalise", action="store_true", help="every walker starts from the input configuration itself (as the ranks of the reference do)")
     ap.add_argument("--eq-adjust", action="store_true", help="eq_adjust_mc: tune the step sizes during equilibration")
     ap.add_argument("--monitor", type=int, default=1000, help="monitor_int")
     ap.add_argument("--regauge", action="store_true",
@@ -274,7 +275,8 @@ def main():
               wl_schedule=args.wl_schedule, wl_flattol=args.wl_flattol, wl_minhist=args.wl_minhist,
               wl_useinvt=args.wl_useinvt, outdir=args.outdir, regauge=args.regauge, parallel_strategy=args.strategy,
               window_overlap=args.window_overlap, eq_mc_cycles=args.eq_cycles, leshift=args.leshift,
-              wl_swetnam=args.wl_swetnam, wl_alpha=args.wl_alpha, eq_adjust_mc=args.eq_adjust, monitor_int=args.monitor)
+              wl_swetnam=args.wl_swetnam, wl_alpha=args.wl_alpha, eq_adjust_mc=args.eq_adjust, monitor_int=args.monitor,
+              thermalise=not args.no_thermalise)
     tabs = res.pop("tables")
     res.pop("walker1_tables"), res.pop("walker1_positions"), res.pop("first_walkers")
     joined = res.pop("joined")

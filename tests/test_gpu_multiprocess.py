@@ -47,3 +47,15 @@ def test_two_rank_bench_line():
     assert res["value"] > res["per_gpu"] > 0
     assert res["roofline"]["kernel"] in ("k_move_energy", "k_model_energy") and res["cpu_baseline"] is None
     assert "gloo all-reduce" in res["config"]["exchange"]
+
+
+def test_two_rank_dd_farm_stitches_its_windows():
+    """parallel_strategy = 'dd' over two processes: one walker = one window each (leshift puts the start inside the
+    overlap of both), no exchange during the run, the windows joined at the end by an all-gather over the ranks."""
+    res = _launch(["-m", "mc_water_ls_mw_amd.farm", "--walkers", "1", "--cycles", "40", "--strategy", "dd", "--leshift",
+                   "--eq-cycles", "3", "--flat-chk", "8", "--wl-schedule", "1", "--wl-minhist", "-1", "--no-thermalise",
+                   "--backend", "gloo", "--share-device"])
+    assert res["world"] == 2 and res["ranks_agree"] is True                 # both ranks hold the same joined weights
+    lo, hi = res["joined_weight_range"]
+    assert hi > lo and res["in_window"] == [True]
+    assert [e["action"] for e in res["flatness_events"]][:2] == ["first reset", "halved"]
