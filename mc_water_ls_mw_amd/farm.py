@@ -12,6 +12,7 @@ walkers of all GPUs (comms_allreduce_eta/hist, comms_mpi.f90:244-277,461-494).
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import time
@@ -26,7 +27,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         deltaG_int=100000, max_mc_cycles=None, eq_mc_cycles=0, outdir=None, thermalise=True, regauge=False,
         parallel_strategy="mw", window_overlap=2, leshift=False, input_ref_enthalpy=None, wl_swetnam=False, wl_alpha=1.0,
         eq_adjust_mc=False, mc_target_ratio=0.5, monitor_int=1000, mc_max_trans_ang=1.1, mc_dv_max_ang=0.924,
-        latt_sync_int=10000):
+        latt_sync_int=10000, chkpt_dump_int=None, restart=False):
     """Run `cycles` MC cycles of `walkers` two-lattice walkers on this GPU.  Returns a dict of results.
 
     ``flat_chk_int`` ... ``file_wl_factor``: the Wang-Landau schedule (mc_check_flatness, :291-294;
@@ -43,7 +44,11 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
     ``wl_swetnam`` / ``wl_alpha``: mc_moves.F90:1636-1653.  ``eq_adjust_mc`` / ``mc_target_ratio`` / ``monitor_int``: every
     monitor_int cycles the stored energies are replaced by freshly computed ones and, below eq_mc_cycles, every walker's
     step sizes are tuned toward the target acceptance ratio (mc_monitor_stats, :1724-1732,1783-1787).  ``latt_sync_int``:
-    every so many cycles lattice 2 of every walker is re-imposed from its lattice 1 (mc_check_chain_synchronisation, :296-300)."""
+    every so many cycles lattice 2 of every walker is re-imposed from its lattice 1 (mc_check_chain_synchronisation, :296-300).
+    ``chkpt_dump_int`` / ``restart`` (with ``outdir``): every walker writes the reference's own checkpoint file --
+    ``checkpointRRR.dat.{1,2}`` alternately, R = its global index (mc_checkpoint_write, :324-390; at most 1000 walkers in
+    all) -- and a restarted run takes cycle number, step sizes, increment, tables, cells, reference and current positions
+    and the active lattice from the newer readable one (mc_checkpoint_load, :393-501) and runs ``cycles`` MORE cycles."""
     from . import lattice as lat
     from .energy import EnergyModule
     from .schedule import WangLandauSchedule, WindowSchedules, delta_g_from_hist, log_unbiased_norm
@@ -59,6 +64,17 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             em.hmatrix[2 * w + l] = h_pair[l]
             em.ljr[2 * w + l] = (lat.thermalise(x_pair[l], sigma_ang, 7919 * (rank * walkers + w) + l)
                                  if thermalise else np.asarray(x_pair[l], dtype=np.float64))
+    start_cycle, chk = 0, None
+    if restart:                                                            # mc_checkpoint_load
+        from . import io as mwio
+        chk = [mwio.latest_checkpoint(outdir, rank * walkers + w)[1] for w in range(walkers)]
+        start_cycle = chk[0]["cycle"]                                      # (rank 0's, broadcast: :441)
+        for w, c in enumerate(chk):
+            if c["nwater"] != n or len(c["hmatrix"]) != 2:
+                raise ValueError("checkpoint does not match this run")
+            em.hmatrix[2 * w:2 * w + 2] = c["hmatrix"]
+            em.ljr[2 * w:2 * w + 2] = c["ljr"]
+    last_cycle = start_cycle + cycles
     em._chk(em.L.mw_init(device, n, 2 * walkers, em.maxneigh))
     em._live = True
     try:
@@ -113,23 +129,62 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         if npt:                                                    # io.f90:171-172: vol 1/N against trans 0.5
             farm.moves(trans_prob=0.5, vol_prob=1.0 / n, dv_max_ang=mc_dv_max_ang)
         farm.set_reference()                                       # ref_hmatrix / ref_ljr (init.f90:90,106) for the chain synchronisation
+        if chk is not None:                                        # the rest of mc_checkpoint_load
+            farm._ref_h = np.array([h_pair[l] for _ in range(walkers) for l in range(2)], dtype=np.float64)   # init.f90:90: the input cells
+            farm._s_ref = np.einsum("bnd,bdk->bnk", np.concatenate([c["ref_ljr"] for c in chk]), np.linalg.inv(em.hmatrix))
+            farm.set_tables_range(1, weight=np.array([c["weight"] for c in chk]), histogram=np.array([c["histogram"] for c in chk]),
+                                  unbiased_hist=np.array([c["unbiased_hist"] for c in chk]) if samplerun else None)
+            comms.set_histogram(chk[0]["histogram"])               # :455-458 (the weights' baseline is NOT re-based there either)
+            if samplerun:
+                comms.set_uhistogram(chk[0]["unbiased_hist"])
+            step_t0 = np.array([c["mc_max_trans"] for c in chk]); step_v0 = np.array([c["mc_dv_max"] for c in chk])
+            if not dd:
+                sched.wl_factor = chk[0]["wl_factor"]              # :447-448,462-464
+                sched.invt_active = chk[0]["wl_invt_active"]
+                if sched.wl_factor < sched.orig_wl_factor:
+                    sched.firstcycle = False
         for w in range(1, walkers + 1):                            # :703-704: a window on one side of mu = 0 fixes the lattice
-            farm.set_state(w, (sched.windows[w - 1]["ls"] or 1) if dd else 1, farm.initial_mu(w))
+            ls0 = chk[w - 1]["ls"] if chk is not None else ((sched.windows[w - 1]["ls"] or 1) if dd else 1)
+            farm.set_state(w, ls0, farm.initial_mu(w))
         from .lattice import ANG_TO_BOHR
         step_t = np.full(walkers, mc_max_trans_ang * ANG_TO_BOHR)  # mc_max_trans / mc_dv_max of every walker, bohr (io.f90:165-166)
         step_v = np.full(walkers, mc_dv_max_ang * ANG_TO_BOHR)
+        if chk is not None:
+            step_t, step_v = step_t0, step_v0
+            farm.set_steps(step_t, step_v)
+        nchk = 0
+
+        def write_checkpoints(c_):                                 # mc_checkpoint_write, :324-390
+            from . import io as mwio
+            nonlocal nchk
+            if comms.world_size * walkers > 1000:
+                raise ValueError("checkpoint files are numbered with three digits: at most 1000 walkers in all")
+            h = farm.sync_cells() if npt else np.array(em.hmatrix)
+            x = np.zeros((2 * walkers, n, 3))
+            em._chk(em.L.mw_download_positions_range(1, 2 * walkers, x.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+            ref_ljr = np.einsum("bnk,bkd->bnd", farm._s_ref, h)    # ref_ljr follows the cell (fractional reference kept)
+            wt, hi, uh = farm.tables_range()
+            facs = farm.factors()[0] if (dd or wl_swetnam) else np.full(walkers, sched.wl_factor)
+            for k in range(walkers):
+                st = farm.state(k + 1)
+                mwio.write_checkpoint(os.path.join(outdir, "checkpoint%03d.dat.%d" % (comms.rank * walkers + k, 1 + nchk % 2)),
+                                      dict(nwater=n, cycle=c_, mc_max_trans=step_t[k], mc_dv_max=step_v[k], wl_factor=facs[k],
+                                           histogram=hi[k], weight=wt[k], wl_invt_active=sched.invt_active, samplerun=samplerun,
+                                           unbiased_hist=uh[k], hmatrix=h[2 * k:2 * k + 2], ref_ljr=ref_ljr[2 * k:2 * k + 2],
+                                           ljr=x[2 * k:2 * k + 2], ls=st["ls"]))
+            nchk += 1
         mon_acc = mon_vatt = mon_vacc = np.zeros(walkers, dtype=np.int64)
         mon_cycle = 0
         t0 = time.perf_counter()
         synced, events, delta_g = None, [], None
         def ends_a_stretch(c):
             """Does the host have something to do after cycle c (or before cycle c + 1)?"""
-            return (c == cycles or (c + 1) % list_update_int == 0 or c % mpi_sync_int == 0 or c % flat_chk_int == 0
-                    or c % monitor_int == 0 or c % latt_sync_int == 0
+            return (c == last_cycle or (c + 1) % list_update_int == 0 or c % mpi_sync_int == 0 or c % flat_chk_int == 0
+                    or c % monitor_int == 0 or c % latt_sync_int == 0 or (chkpt_dump_int is not None and c % chkpt_dump_int == 0)
                     or (samplerun and c % deltaG_int == 0) or c + 1 == eq_mc_cycles or sched.invt_active)
 
-        cyc = 0
-        while cyc < cycles:
+        cyc = mon_cycle = start_cycle
+        while cyc < last_cycle:
             first = cyc + 1
             if first % list_update_int == 0:                       # mc_moves.F90:217-222
                 if npt:
@@ -187,6 +242,9 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                     with open(os.path.join(outdir, "unbiased_histogram_%010d.dat" % cyc), "w") as fh:
                         for m_, p_ in zip(grid.mu_bin, normp):
                             fh.write(f"  {float(m_)!r}        {float(p_)!r}\n")
+            if chkpt_dump_int is not None and cyc % chkpt_dump_int == 0:   # :311-315
+                em.sync()
+                write_checkpoints(cyc)
         em.sync()
         if npt or dd:
             farm.check_flags()                                     # every walker, not only the ones read out below

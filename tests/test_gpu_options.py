@@ -290,3 +290,25 @@ def test_chain_synchronisation_inside_the_farm_loop_follows_the_pinned_oracle(so
     assert st.nvol[1] > 0 and np.abs(np.array(fw["positions"]) - st.xyz).max() < 1e-8 and fw["ls"] == st.ls
     assert abs(fw["ls_mu"] - st.ls_mu) < 1e-6 * (1 + abs(st.ls_mu))
     assert np.allclose(fw["tables"][1], hi, rtol=1e-12, atol=1e-12) and np.allclose(fw["tables"][0], w, rtol=1e-9, atol=1e-11)
+
+
+def test_farm_restarts_from_its_own_checkpoints_and_the_files_are_the_references(tmp_path):
+    """chkpt_dump_int / restart: two NPT walkers write checkpointRRR.dat.{1,2} in the reference's format (mc_checkpoint_write,
+    mc_moves.F90:324-390); a second run restarted from them ends where the uninterrupted run ends (lists are rebuilt at the
+    same point of both runs: list_update_int = 11, restart after cycle 10)."""
+    from mc_water_ls_mw_amd import io as mwio
+    from mc_water_ls_mw_amd.farm import run
+    b = boxes48()
+    kw = dict(walkers=2, temperature=200.0, seed=pin.SEED, thermalise=False, list_update_int=11, mpi_sync_int=10 ** 9,
+              wl_factor=F0, npt=True, pressure_atm=1.0, eq_mc_cycles=1, flat_chk_int=10 ** 9, outdir=str(tmp_path))
+    full = run([b[0][0], b[1][0]], [b[0][1], b[1][1]], cycles=20, **kw)
+    run([b[0][0], b[1][0]], [b[0][1], b[1][1]], cycles=10, chkpt_dump_int=5, **kw)
+    path, c = mwio.latest_checkpoint(str(tmp_path), 1)                      # walker 2 = "rank" 1
+    assert path.endswith("checkpoint001.dat.2") and c["cycle"] == 10 and c["nwater"] == 48 and c["hmatrix"].shape == (2, 3, 3)
+    assert c["histogram"].sum() > 0 and not c["samplerun"]
+    rest = run([b[0][0], b[1][0]], [b[0][1], b[1][1]], cycles=10, restart=True, **kw)
+    for k in range(2):
+        a, r = full["first_walkers"][k], rest["first_walkers"][k]
+        assert np.abs(np.array(a["positions"]) - np.array(r["positions"])).max() < 1e-8 and a["ls"] == r["ls"]
+        assert np.allclose(a["tables"][1], r["tables"][1], rtol=1e-12, atol=1e-12)
+        assert np.allclose(a["tables"][0], r["tables"][0], rtol=1e-9, atol=1e-11)
