@@ -305,6 +305,9 @@ def main():
     ap.add_argument("--leshift", action="store_true")
     ap.add_argument("--wl-swetnam", action="store_true")
     ap.add_argument("--wl-alpha", type=float, default=1.0)
+    ap.add_argument("--chkpt", type=int, default=None, help="chkpt_dump_int: cycles between checkpoint files (needs --outdir)")
+    ap.add_argument("--restart", action="store_true", help="continue from the checkpoint files in --outdir")
+    ap.add_argument("--latt-sync", type=int, default=10000, help="latt_sync_int")
     ap.add_argument("--no-thermalise", action="store_true", help="every walker starts from the input configuration itself (as the ranks of the reference do)")
     ap.add_argument("--eq-adjust", action="store_true", help="eq_adjust_mc: tune the step sizes during equilibration")
     ap.add_argument("--monitor", type=int, default=1000, help="monitor_int")
@@ -334,7 +337,7 @@ def main():
               wl_useinvt=args.wl_useinvt, outdir=args.outdir, regauge=args.regauge, parallel_strategy=args.strategy,
               window_overlap=args.window_overlap, eq_mc_cycles=args.eq_cycles, leshift=args.leshift,
               wl_swetnam=args.wl_swetnam, wl_alpha=args.wl_alpha, eq_adjust_mc=args.eq_adjust, monitor_int=args.monitor,
-              thermalise=not args.no_thermalise)
+              thermalise=not args.no_thermalise, chkpt_dump_int=args.chkpt, restart=args.restart, latt_sync_int=args.latt_sync)
     tabs = res.pop("tables")
     res.pop("walker1_tables"), res.pop("walker1_positions"), res.pop("first_walkers")
     joined = res.pop("joined")
