@@ -364,7 +364,7 @@ int launch_model_energy(int first, int count)
                            g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
     HIPCHK(hipGetLastError());
     if (ge.nsplit > 1) {           // split boxes: the partials of box b live at [b*nsplit .. b*nsplit+nsplit); unsplit boxes wrote their energy themselves
-        hipLaunchKernelGGL(mw::k_sum_partials, dim3((count + 255) / 256), dim3(256), 0, g.stream, g.d_partial, g.d_cpartial,
+        hipLaunchKernelGGL(mw::k_sum_partials, dim3(count), dim3(64), 0, g.stream, g.d_partial, g.d_cpartial,
                            g.d_energy, g.d_counts, box0, count, ge.nsplit);
         HIPCHK(hipGetLastError());
     }
@@ -440,7 +440,8 @@ int launch_build(int first, int count)
         const int nseg = (g.N + g.order_seg - 1) / g.order_seg;
         const int ngroups = (std::min(g.N, g.order_seg) + 63) / 64;
         const size_t shmem = g.order_kbits < 0 ? 0 : sizeof(int) * ((size_t)ngroups << g.order_kbits);
-        hipLaunchKernelGGL(mw::k_list_order, dim3(nseg, count), dim3(1024), shmem, g.stream, g.d_listm, g.d_nn, g.d_cin, g.d_stats,
+        const int nthreads = std::min(1024, std::max(64, (std::min(g.N, g.order_seg) + 63) & ~63));
+        hipLaunchKernelGGL(mw::k_list_order, dim3(nseg, count), dim3(nthreads), shmem, g.stream, g.d_listm, g.d_nn, g.d_cin, g.d_stats,
                            g.d_list, g.d_order, g.d_nns, g.d_cmax, g.N, g.S, box0, g.order_kbits, g.order_seg);
         HIPCHK(hipGetLastError());
     }

@@ -308,19 +308,23 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
 // (A "last workgroup sums" scheme inside k_model_energy needs agent-scope release/acquire around a counter -- on
 // gfx950 an L2 write-back and invalidate per workgroup -- which took the 64 x 32768 launch from 0.19 to 0.46 ms by
 // throwing away the L2 lines its position gathers live on; a second tiny launch is cheaper.)
-__global__ void k_sum_partials(const double* __restrict__ partial, const unsigned long long* __restrict__ cpartial,
-                               double* __restrict__ energy, unsigned long long* __restrict__ counts,
-                               int box0, int count, int nsplit)
+__global__ __launch_bounds__(64)
+void k_sum_partials(const double* __restrict__ partial, const unsigned long long* __restrict__ cpartial,
+                    double* __restrict__ energy, unsigned long long* __restrict__ counts,
+                    int box0, int count, int nsplit)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count) return;
-    const int b = box0 + t;
+    // one wavefront per box: lane l adds the partials l, l + 64, ... in that order, then a fixed DPP tree -- the same
+    // sum whatever the launch looked like, and one coalesced read instead of a chain of nsplit dependent loads per box
+    const int b = box0 + (int)blockIdx.x, lane = threadIdx.x;
+    if ((int)blockIdx.x >= count) return;
     double e = 0.0; unsigned long long p = 0, q = 0;
-    for (int s = 0; s < nsplit; ++s) {
+    for (int s = lane; s < nsplit; s += 64) {
         const size_t o = (size_t)b * nsplit + s;
         e += partial[o]; p += cpartial[2 * o]; q += cpartial[2 * o + 1];
     }
-    energy[b] = e; counts[2 * b] = p; counts[2 * b + 1] = q;
+    e = readlane_f64(dpp_wave_sum(e), 63);
+    p = wave_sum_u64(p); q = wave_sum_u64(q);
+    if (lane == 0) { energy[b] = e; counts[2 * b] = p; counts[2 * b + 1] = q; }
 }
 
 }  // namespace mw

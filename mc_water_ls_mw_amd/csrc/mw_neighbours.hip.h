@@ -708,7 +708,8 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
 //   C  column t of the slot-major list <- row order[t] of the molecule-major list (coalesced stores), central-image
 //      entries first, zero-padded to the longest row of the column's group of 64.
 // kbits = number of key bits kept (the (key, group) table must fit kOrderSlots); kbits < 0: identity order.
-//   grid = (segments, boxes), block = 1024
+//   grid = (segments, boxes), block = min(1024, segment length): a 64-molecule segment of a large box is one wavefront's work
+//   (with 1024 threads fifteen of sixteen wavefronts idled through every barrier: 583 us instead of ~150 for 64 x 32768)
 // =====================================================================================
 constexpr int kOrderSlots = 32768;      // ints of dynamic LDS at most (128 KiB)
 
@@ -721,6 +722,7 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
     __shared__ int wsum[16];
     const int b = box0 + blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int NT = (int)blockDim.x;                                   // 1024 for a whole LDS-sized box, 64 for the 64-molecule segments of large boxes
     const int i0 = blockIdx.x * seg, i1 = min(N, i0 + seg);          // this workgroup's molecules = its list columns
     const int ngroups = (i1 - i0 + 63) >> 6;
     const int ngroups_box = (N + 63) >> 6;
@@ -742,18 +744,18 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
     };
 
     if (kbits < 0) {
-        for (int i = i0 + tid; i < i1; i += 1024) { ORD[i] = i; NNS[i] = min(NN[i], S); }
+        for (int i = i0 + tid; i < i1; i += NT) { ORD[i] = i; NNS[i] = min(NN[i], S); }
     } else {
         // hist[group][key]: the lanes of a wavefront share the group and differ in key, i.e. in LDS bank (the scan below
         // walks it in (key, group) order: element e is key e / ngroups, group e % ngroups)
         const int K = 1 << kbits, M = K * ngroups;
         auto hslot = [&](int key, int grp) { return grp * K + key; };
-        for (int e = tid; e < M; e += 1024) hist[e] = 0;
+        for (int e = tid; e < M; e += NT) hist[e] = 0;
         __syncthreads();
-        for (int i = i0 + tid; i < i1; i += 1024) atomicAdd(&hist[hslot(keyof(i, NN[i]), (i - i0) >> 6)], 1);
+        for (int i = i0 + tid; i < i1; i += NT) atomicAdd(&hist[hslot(keyof(i, NN[i]), (i - i0) >> 6)], 1);
         __syncthreads();
         // exclusive scan of hist[0..M): `per` consecutive elements per thread
-        const int per = (M + 1023) / 1024;
+        const int per = (M + NT - 1) / NT;
         const int e0 = min(M, tid * per), e1 = min(M, e0 + per);
         int local = 0;
         for (int e = e0; e < e1; ++e) local += hist[hslot(e / ngroups, e % ngroups)];
@@ -766,7 +768,7 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
         for (int w = 0; w < wid; ++w) run += wsum[w];
         for (int e = e0; e < e1; ++e) { const int sl = hslot(e / ngroups, e % ngroups), v = hist[sl]; hist[sl] = run; run += v; }
         __syncthreads();
-        for (int base = i0; base < i1; base += 1024) {
+        for (int base = i0; base < i1; base += NT) {
             const int i = base + tid;
             const bool valid = i < i1;
             const int n = valid ? NN[i] : 0;
@@ -787,7 +789,7 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
     // Column t <- row ORD[t], entries of the central image first: the full-box kernel then skips the image-vector
     // gather for the slots every lane of a wavefront knows to be central (c0min).  NNS[t] = n | n0 << 8 (n0 = central
     // entries), CM[group] = longest row | smallest n0 << 8.
-    for (int base = i0; base < i1; base += 1024) {
+    for (int base = i0; base < i1; base += NT) {
         const int t = base + tid;
         const bool valid = t < i1;
         const int i = valid ? ORD[t] : 0;
