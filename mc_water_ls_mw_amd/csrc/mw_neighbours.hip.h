@@ -57,9 +57,9 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
     // per-box statistics: min nn, max nn (max > S means overflow)
     int mn = wave_min_i(active ? cnt : 0x7fffffff);
     int mx = wave_max_i(active ? cnt : 0);
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(&stats[2 * b], mn);
-        atomicMax(&stats[2 * b + 1], mx);
+    if ((threadIdx.x & 63) == 0) {          // (look first: see k_cell_pairs)
+        if (mn < __hip_atomic_load(&stats[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&stats[2 * b], mn);
+        if (mx > __hip_atomic_load(&stats[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&stats[2 * b + 1], mx);
     }
 }
 
@@ -370,9 +370,9 @@ void k_cell_search(const double* __restrict__ pos, const double* __restrict__ iv
     }
     int mn = wave_min_i(active ? cnt : 0x7fffffff);
     int mx = wave_max_i(active ? cnt : 0);
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(&stats[2 * b], mn);
-        atomicMax(&stats[2 * b + 1], mx);
+    if ((threadIdx.x & 63) == 0) {          // (look first: see k_cell_pairs)
+        if (mn < __hip_atomic_load(&stats[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&stats[2 * b], mn);
+        if (mx > __hip_atomic_load(&stats[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&stats[2 * b + 1], mx);
     }
 }
 
@@ -689,7 +689,12 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
         __builtin_amdgcn_wave_barrier();                                      // rows are reused by the next block of molecules
     }
     wmin = wave_min_i(wmin); wmax = wave_max_i(wmax);
-    if (lane == 0) { atomicMin(&stats[2 * b], wmin); atomicMax(&stats[2 * b + 1], wmax); }
+    if (lane == 0) {
+        // thousands of wavefronts of a box report to the same two words: look first (the values only ever move one way,
+        // so a stale read can only cause a superfluous atomic, never a missed one) and touch them only to change them
+        if (wmin < __hip_atomic_load(&stats[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&stats[2 * b], wmin);
+        if (wmax > __hip_atomic_load(&stats[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&stats[2 * b + 1], wmax);
+    }
 }
 
 // =====================================================================================
