@@ -101,6 +101,7 @@ struct Ctx {
     double *d_wweight = nullptr, *d_whist = nullptr, *d_wuhist = nullptr;   // [walker][nbins]
     unsigned long long* d_wswitch = nullptr;
     int mchunk = 16;                 // requests per work item of the uploaded batch
+    bool m_noself = false;           // every box of the uploaded batch went through the cell grid: no molecule meets an image of itself
     double* d_wshift = nullptr;
     double* d_tabscratch = nullptr;  // [3 nbins last | 3 nbins out | chunks x nbins partial] for mw_sweep_reduce_tables
     size_t tabscratch_n = 0;      // per walker: sum of the minima mc_update_wl_bins subtracted since the last read-out
@@ -654,6 +655,8 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
                                hipFuncAttributeMaxDynamicSharedMemorySize, MW_MAXNEIGH_LIMIT * 256 * (int)sizeof(uint32_t)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_move_energy<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_move_energy<true, mw::kLayoutSoA, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
     {   // the sweep driver's dynamic LDS (image vectors of small or sheared cells, staged positions and rows) can pass 64 KiB
         const void* sweeps[] = {reinterpret_cast<const void*>(&mw::k_sweep_translation<true, true, true>),
                                 reinterpret_cast<const void*>(&mw::k_sweep_translation<true, false, true>),
@@ -1031,7 +1034,11 @@ int mw_moves_upload(int n, const int* ils, const int* imol, const double* trial_
     }
     std::vector<int> start((size_t)g.nbox + 1, 0);
     int used_boxes = 0;
-    for (int b = 0; b < g.nbox; ++b) { start[(size_t)b + 1] = start[b] + cnt[(size_t)b + 1]; if (cnt[(size_t)b + 1]) ++used_boxes; }
+    g.m_noself = true;
+    for (int b = 0; b < g.nbox; ++b) {
+        start[(size_t)b + 1] = start[b] + cnt[(size_t)b + 1];
+        if (cnt[(size_t)b + 1]) { ++used_boxes; if (!g.h_usegrid[(size_t)b]) g.m_noself = false; }
+    }
     std::vector<int> perm((size_t)n), i0((size_t)n), fill(start.begin(), start.end() - 1);
     std::vector<double> tr(trial_xyz ? (size_t)3 * n : 0);
     for (int m = 0; m < n; ++m) {
@@ -1103,7 +1110,12 @@ static int launch_moves(int mode)
     if (g.mn == 0) return 0;
     const size_t iv_bytes = kMoveScratch + mw::lds_vec_bytes((size_t)g.ivcap);
     HIPCHK(hipMemsetAsync(g.d_mdecl, 0, sizeof(int), g.stream));           // nothing declined yet
-    if (g.mlds)
+    if (g.mlds && g.m_noself)
+        hipLaunchKernelGGL((mw::k_move_energy<true, mw::kLayoutSoA, false>), dim3(g.mwork_n), dim3(1024),
+                           iv_bytes + mw::lds_vec_bytes((size_t)g.N) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
+                           g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
+                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, mode);
+    else if (g.mlds)
         hipLaunchKernelGGL(mw::k_move_energy<true>, dim3(g.mwork_n), dim3(1024),
                            iv_bytes + mw::lds_vec_bytes((size_t)g.N) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,

@@ -252,7 +252,11 @@ static_assert(sizeof(WaveScratch) % 16 == 0, "scratch records must keep 16-byte 
 // Returns false (nothing written) when the request needs the plain routine.
 // `row(j, s)` returns list entry s of molecule j and `nnof(j)` its row length: global memory (molecule-major
 // list) or, for small systems in the sweep driver, LDS copies.
-template <typename PosFn, typename IvFn, typename RowFn, typename NnFn>
+// SELFIMG = false: the caller guarantees that no periodic image of a molecule can be a third body of its own neighbours
+// (cells at least three list radii wide along every cell vector -- every box that goes through the cell-grid builder):
+// a row entry with k == i is then the molecule itself, and the both-geometries branch and the inverse-image bookkeeping
+// behind it fall away (25 vector instructions per move).
+template <bool SELFIMG = true, typename PosFn, typename IvFn, typename RowFn, typename NnFn>
 __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn row, NnFn nnof,
                                                  WaveScratch* __restrict__ ws, int niv,
                                                  int i, int n_i, uint32_t e,
@@ -318,8 +322,11 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     // the image that undoes `kimg`: cells are numbered centre first, then lexicographically without the
     // centre (compute_ivects, molint.F90:174-217), so the opposite cell is the mirror position
     const int cc = (niv - 1) >> 1;
-    const int lin = kimg <= cc ? kimg - 1 : kimg, linv = niv - 1 - lin;
-    const int kinv = kimg == 0 ? 0 : (linv < cc ? linv + 1 : linv);
+    int kinv = 0;
+    if constexpr (SELFIMG) {
+        const int lin = kimg <= cc ? kimg - 1 : kimg, linv = niv - 1 - lin;
+        kinv = kimg == 0 ? 0 : (linv < cc ? linv + 1 : linv);
+    }
     // image (10 bits) | inverse image (10 bits) | in range of old, trial position (2 bits), by rank like jv
     const int flg = (int)((mo_ >> sl) & 1u) | (int)(((mn_ >> sl) & 1u) << 1);
     const int wv = __builtin_amdgcn_ds_permute(dstl << 2, kimg | (kinv << 10) | (flg << 20));
@@ -446,13 +453,16 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         getiv(k2, kvx, kvy, kvz);
         const double cjx = ws->c[0][own], cjy = ws->c[1][own], cjz = ws->c[2][own];
         const bool self = valid && (kk == i);
-        const bool selfimg = self && (k2 == ((wj >> 10) & 1023));   // the molecule itself, not an image: k's shift undoes j's
-        const bool selfmove = self && !selfimg;
+        bool selfmove = false;
+        if constexpr (SELFIMG) {
+            const bool selfimg = self && (k2 == ((wj >> 10) & 1023));   // the molecule itself, not an image: k's shift undoes j's
+            selfmove = self && !selfimg;
+        }
         const double box_ = (xk + kvx) + cjx;                                    // :332,334 (see the flush)
         const double boy_ = (yk + kvy) + cjy;
         const double boz_ = (zk + kvz) + cjz;
         const double s2o = box_ * box_ + boy_ * boy_ + boz_ * boz_;              // :335
-        if (__ballot(selfmove) != 0ull) {
+        if (SELFIMG && __ballot(selfmove) != 0ull) {
             // an image of the molecule itself as third body moves with it: both geometries, in line (rare)
             if (selfmove) {
                 const int fl = wj >> 20;
@@ -504,7 +514,7 @@ constexpr int kMoveChunk = 2048;   // requests per work item when the box is sta
 
 // (LAYOUT: SoA measures 1.4 % faster than the paired layout here -- 1288 vs 1306 us, tools/kbench -- now that the scan
 // reads one vector less per slot; the full-box kernel keeps the paired layout, where it is the faster one)
-template <bool LDSPOS, int LAYOUT = kLayoutSoA>
+template <bool LDSPOS, int LAYOUT = kLayoutSoA, bool SELFIMG = true>
 __global__ __launch_bounds__(1024)
 void k_move_energy(const double* __restrict__ pos, const double* __restrict__ ivect,
                    const int* __restrict__ nivect, const uint32_t* __restrict__ listm,
@@ -583,7 +593,7 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
         if (mode & 2) { xn = tx; yn = ty; zn = tz; }
 
         MoveRes r;
-        const bool fast = move_energy_wave(getpos, getiv, row, nnof, ws, niv, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r);
+        const bool fast = move_energy_wave<SELFIMG>(getpos, getiv, row, nnof, ws, niv, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r);
         if (!fast) {
             // a request the fused routine declines (a row longer than 32 entries, more than kCap in-range neighbours, a
             // molecule that neighbours its own image -- never on ice) is left to k_move_fallback: with the plain routine
