@@ -272,7 +272,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     const int half = lane >> 5, sl = lane & 31;
     const bool has = sl < n_i;
     const int j = has ? (int)(e & kJMask) : 0, kimg = has ? (int)(e >> kJBits) : 0;
-    if (__ballot(has && j == i) != 0ull) return false;
+    if (SELFIMG && __ballot(has && j == i) != 0ull) return false;
     double xj, yj, zj, jvx, jvy, jvz;
     getpos(j, xj, yj, zj);
     getiv(kimg, jvx, jvy, jvz);
