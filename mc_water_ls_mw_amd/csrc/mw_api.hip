@@ -1050,12 +1050,14 @@ int mw_moves_upload(int n, const int* ils, const int* imol, const double* trial_
     g.mlds = lds_fits_move(g.N, g.ivcap) && ((long long)n * 2048 >= (long long)used_boxes * 24 * g.N);
     // Requests per work item.  Inside an item the wavefronts draw requests dynamically, so large items waste little
     // at their end and stage the box once for more work; but there must be enough items to fill the chip:
-    // aim at >= 4 items per CU, between 256 and the LDS capacity kMoveChunk.
+    // aim at >= 2 items per CU, between 256 and the LDS capacity kMoveChunk (measured on 512 x 2048 requests: items of
+    // 256 / 512 / 1024 / 2048 requests take 1.375 / 1.316 / 1.291 / 1.286 ms; MW_MOVE_CHUNK overrides).
     int chunk = 16;
     if (g.mlds) {
-        const long long want = (long long)n / (4LL * std::max(1, g.cu));
+        const long long want = (long long)n / (2LL * std::max(1, g.cu));
         chunk = 256;
         while (chunk < mw::kMoveChunk && chunk < want) chunk *= 2;
+        if (const char* ev = std::getenv("MW_MOVE_CHUNK")) { const int v = std::atoi(ev); if (v >= 64 && v <= mw::kMoveChunk) chunk = v; }
     }
     g.mchunk = chunk;
     std::vector<int4> work;
