@@ -828,18 +828,41 @@ void k_list_order(const uint32_t* __restrict__ listm, const int* __restrict__ nn
             if (lane == 0 && valid) CM[t >> 6] = nmax | ((c0min > 255 ? 255 : c0min) << 8);
             continue;
         }
-        for (int pass = 0; pass < 2; ++pass) {
-            if (fastrow) {
+        if (fastrow) {
+            // one pass: count the central-image entries first (registers only), then every entry goes straight to its
+            // slot -- central ones from 0 up, the others from n0 up -- with ONE store per entry instead of two predicated ones
+            int n0 = 0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (4 * u < nmax) {
-                        const uint32_t e[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t e[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
 #pragma unroll
-                        for (int v = 0; v < 4; ++v)
-                            if (4 * u + v < n && ((e[v] >> kJBits) == 0u) == (pass == 0)) { L[(size_t)w * N + t] = e[v]; ++w; }
+                for (int v = 0; v < 4; ++v) n0 += (4 * u + v < n && (e[v] >> kJBits) == 0u) ? 1 : 0;
+            }
+            int wc = 0, wb = n0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (4 * u < nmax) {
+                    const uint32_t e[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        if (4 * u + v < n) {
+                            const bool central = (e[v] >> kJBits) == 0u;
+                            const int dst = central ? wc : wb;
+                            L[(size_t)dst * N + t] = e[v];
+                            wc += central ? 1 : 0; wb += central ? 0 : 1;
+                        }
                     }
                 }
-            } else
+            }
+            if (valid) {
+                for (int z = n; z < nmax; ++z) L[(size_t)z * N + t] = 0u;          // zero-padded to the group's longest row
+                NNS[t] = n | (n0 << 8);
+            }
+            const int c0min = __builtin_amdgcn_readfirstlane(wave_min_i(valid ? n0 : 0x7fff));
+            if (lane == 0 && valid) CM[t >> 6] = nmax | ((c0min > 255 ? 255 : c0min) << 8);
+            continue;
+        }
+        for (int pass = 0; pass < 2; ++pass) {                // rows longer than 32 entries: two passes over the row in memory
             for (int s4 = 0; s4 < nmax; s4 += 4) {
                 if (s4 < n) {
                     const uint4 v = row[s4 >> 2];
