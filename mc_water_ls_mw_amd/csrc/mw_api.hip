@@ -19,6 +19,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <unistd.h>
 
 namespace {
 
@@ -140,6 +141,9 @@ struct Ctx {
     hipStream_t sstream = nullptr;
     mw::MailHead* h_head = nullptr;  mw::MailHead* d_head = nullptr;
     mw::MailSlot* h_slots = nullptr; mw::MailSlot* d_slots = nullptr;
+    mw::MailSlot* req_slots = nullptr;  // where requests are posted: h_slots, or device memory the host writes through the BAR
+    mw::MailSlot* d_req = nullptr;      // the same lines as the server kernel addresses them
+    void* req_dev_alloc = nullptr;
     int nslots = 0;
     bool srv_running = false, srv_enabled = true;
     unsigned long long sseq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -474,6 +478,7 @@ void release_all()
     if (g.sstream) { (void)hipStreamSynchronize(g.sstream); (void)hipStreamDestroy(g.sstream); }
     if (g.h_head) (void)hipHostFree(g.h_head);
     if (g.h_slots) (void)hipHostFree(g.h_slots);
+    if (g.req_dev_alloc) { (void)hipFree(g.req_dev_alloc); g.req_dev_alloc = nullptr; }
     void* ptrs[] = {g.d_hmat, g.d_sw_mubin, g.d_sw_binwidth, g.d_wweight, g.d_whist, g.d_wuhist, g.d_wls, g.d_wmu, g.d_wacc,
                     g.d_wswitch, g.d_wshift, g.d_wvol, g.d_wflag, g.d_wwin, g.d_wfac, g.d_wsum, g.d_winflag, g.d_wstep, g.d_volume, g.d_swlog, g.d_tabscratch, g.d_pos, g.d_ivect,
                     g.d_nivect, g.d_list, g.d_listm, g.d_nn, g.d_stats, g.d_order, g.d_nns, g.d_cmax, g.d_cin, g.d_grid,
@@ -643,6 +648,29 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
         HIPCHK(hipHostGetDevicePointer((void**)&g.d_slots, g.h_slots, 0));
         const char* ev = std::getenv("MW_LOCAL_SERVER");
         g.srv_enabled = !(ev && *ev == '0');
+        g.req_slots = g.h_slots; g.d_req = g.d_slots;
+        const char* rq = std::getenv("MW_SERVER_REQ");
+        if (!(rq && std::strcmp(rq, "host") == 0)) {
+            // Request lines in fine-grained DEVICE memory, written by the host through the PCIe BAR: the server polls
+            // local memory (0.45 us a poll instead of a 1.3 us PCIe read, and an idle server puts no traffic on the
+            // bus) and a request reaches it as one posted write.  Only where the host can address device memory (large
+            // BAR): probed with a system call that reports EFAULT instead of faulting; otherwise, or with
+            // MW_SERVER_REQ=host, the request lines stay in host-mapped memory next to the reply line (which the host
+            // polls, so it stays there either way).
+            void* p = nullptr;
+            if (hipExtMallocWithFlags(&p, sizeof(mw::MailSlot) * 8, hipDeviceMallocFinegrained) == hipSuccess && p) {
+                bool ok = hipMemset(p, 0, sizeof(mw::MailSlot) * 8) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+                int fds[2];
+                if (ok && pipe(fds) == 0) {
+                    ok = write(fds[1], p, 8) == 8;
+                    close(fds[0]); close(fds[1]);
+                } else ok = false;
+                if (ok) { g.req_dev_alloc = p; g.req_slots = static_cast<mw::MailSlot*>(p); g.d_req = g.req_slots; }
+                else { (void)hipGetLastError(); (void)hipFree(p); }
+            } else (void)hipGetLastError();
+            if (!g.req_dev_alloc && rq && std::strcmp(rq, "device") == 0)
+                std::fprintf(stderr, "mw: MW_SERVER_REQ=device: device memory is not host-addressable here, requests stay in host memory\n");
+        }
     }
     g.h_ivect.assign(nb * g.ivcap * 3, 0.0);
     g.h_nivect.assign(nb, 0);
@@ -905,10 +933,10 @@ static int server_start_locked()
     static const bool stamps = std::getenv("MW_SERVER_STAMPS") != nullptr;
     static const bool plain = std::getenv("MW_SERVER_PLAIN_LOADS") != nullptr;      // experiment only: L1-cached position loads
     if (plain)
-        hipLaunchKernelGGL(mw::k_local_server<false>, dim3(1), dim3(64 * g.nslots), 0, g.sstream, g.d_head, g.d_slots, g.d_pos, g.d_ivect,
+        hipLaunchKernelGGL(mw::k_local_server<false>, dim3(g.nslots), dim3(64), 0, g.sstream, g.d_head, g.d_slots, g.d_req, g.d_pos, g.d_ivect,
                            g.d_nivect, g.d_listm, g.d_nn, g.N, g.ivcap, 300000LL, stamps ? 1 : 0);
     else
-        hipLaunchKernelGGL(mw::k_local_server<true>, dim3(1), dim3(64 * g.nslots), 0, g.sstream, g.d_head, g.d_slots, g.d_pos, g.d_ivect,
+        hipLaunchKernelGGL(mw::k_local_server<true>, dim3(g.nslots), dim3(64), 0, g.sstream, g.d_head, g.d_slots, g.d_req, g.d_pos, g.d_ivect,
                            g.d_nivect, g.d_listm, g.d_nn, g.N, g.ivcap, 300000LL, stamps ? 1 : 0);
     const hipError_t err = hipGetLastError();
     if (sw) (void)hipSetDevice(prev);
@@ -946,23 +974,32 @@ static int local_energy_served(int ils, int imol, const mw::Override& o1, const 
     std::lock_guard<std::mutex> slk(g_slot_mu[sl]);
     { std::lock_guard<std::mutex> lk(g_srv_mu); if (server_start_locked()) return 1; }
     volatile mw::MailSlot* m = g.h_slots + sl;
-    m->box = ils - 1; m->imol = imol - 1;
-    m->flags = 1 | (o1.idx >= 0 ? 2 : 0) | (o2.idx >= 0 ? 4 : 0);
-    m->prev = o2.idx >= 0 ? o2.idx : 0;
-    m->x1 = o1.x; m->y1 = o1.y; m->z1 = o1.z;
-    m->x2 = o2.x; m->y2 = o2.y; m->z2 = o2.z;
+    volatile mw::MailSlot* q = g.req_slots + sl;
+    q->box = ils - 1; q->imol = imol - 1;
+    q->flags = 1 | (o1.idx >= 0 ? 2 : 0) | (o2.idx >= 0 ? 4 : 0);
+    q->prev = o2.idx >= 0 ? o2.idx : 0;
+    q->x1 = o1.x; q->y1 = o1.y; q->z1 = o1.z;
+    q->x2 = o2.x; q->y2 = o2.y; q->z2 = o2.z;
     const unsigned long long seq = ++g.sseq[sl];
-    std::atomic_thread_fence(std::memory_order_release);
-    m->seq_a = seq;                     // (x86 stores become visible in program order: fields, seq_a, seq_b)
-    std::atomic_thread_fence(std::memory_order_release);
-    m->seq_b = seq;
+    // fields, seq_a, seq_b in this order: program order for write-back host memory; the store fences keep it for a
+    // write-combining mapping of device memory too
+    std::atomic_thread_fence(std::memory_order_release); __builtin_ia32_sfence();
+    q->seq_a = seq;
+    std::atomic_thread_fence(std::memory_order_release); __builtin_ia32_sfence();
+    q->seq_b = seq;
+    __builtin_ia32_sfence();
     for (long spin = 1;; ++spin) {
         if (m->rep_seq == seq) break;
         __builtin_ia32_pause();
         if ((spin & 0xfffff) == 0) {                          // every ~million polls: is the server still there?
             std::lock_guard<std::mutex> lk(g_srv_mu);
             if (reinterpret_cast<volatile int*>(&g.h_head->exited)[0] != 0) {
-                // it left (idle limit, racing with this request) -- or it faulted: the stream tells
+                // it left (idle limit, racing with this request) -- or it faulted: the stream tells.  The slots' wavefronts
+                // leave one by one: the others are told to go too (each finishes the request it has; a request posted
+                // meanwhile is picked up by the server started below), or a slot kept busy by another thread would
+                // hold this one up for as long as it stays busy.
+                reinterpret_cast<volatile int*>(&g.h_head->quit)[0] = 1;
+                std::atomic_thread_fence(std::memory_order_seq_cst);
                 int prev = -1;
                 const bool sw = hipGetDevice(&prev) == hipSuccess && prev != g.device && hipSetDevice(g.device) == hipSuccess;
                 const hipError_t err = hipStreamSynchronize(g.sstream);

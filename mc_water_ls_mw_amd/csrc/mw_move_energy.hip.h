@@ -256,6 +256,13 @@ static_assert(sizeof(WaveScratch) % 16 == 0, "scratch records must keep 16-byte 
 // (cells at least three list radii wide along every cell vector -- every box that goes through the cell-grid builder):
 // a row entry with k == i is then the molecule itself, and the both-geometries branch and the inverse-image bookkeeping
 // behind it fall away (25 vector instructions per move).
+#ifdef MW_LAT_STAMPS      // tools/kbench built with -DMW_LAT_STAMPS only: where one wavefront's time goes (100 MHz ticks)
+__device__ unsigned long long g_lat_stamps[16];
+#define MW_STAMP(k) do { if (lane == 0) g_lat_stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MW_STAMP(k) do { } while (0)
+#endif
+
 template <bool SELFIMG = true, typename PosFn, typename IvFn, typename RowFn, typename NnFn>
 __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn row, NnFn nnof,
                                                  WaveScratch* __restrict__ ws, int niv,
@@ -268,6 +275,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     // `e` arrives as entry (lane & 31) of imol's row, fetched by the caller ahead of time (whatever the row
     // length: rows are padded).  Rows longer than 32 entries take the plain routine, and so does a molecule
     // that neighbours one of its own periodic images.
+    MW_STAMP(0);
     if (n_i > 32) return false;
     const int half = lane >> 5, sl = lane & 31;
     const bool has = sl < n_i;
@@ -287,6 +295,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     const unsigned int U = mo_ | mn_;
     const int cntU = __popc(U);
     if (cntU > kCap) return false;
+    MW_STAMP(1);
 
     double rinv = 0.0, e1 = 0.0, g = 0.0;
     if (in) pair_terms(r2, rinv, e1, g);
@@ -354,6 +363,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     // chunk's slot -> (owner rank, owner's packed word, row entry) fetch is issued TWO CHUNKS AHEAD of its
     // evaluation -- the first two right here, before the j--i--k stage -- so the row fetch (global memory for
     // the big boxes) is never waited for.
+    MW_STAMP(2);
     int nbefore = 0;                                         // row ends in the chunks already fetched (wave-uniform)
     auto fetch = [&](int t, int& own, int& wj, uint32_t& ent) {
         const unsigned long long M = ws->cm[t >> 6];         // one address for the whole wave
@@ -372,6 +382,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
 
     // ---- j--i--k triplets: pairs (a < b) of in-range neighbours, one pair per lane ------------
     // (molint.F90:302-318; a is the earlier list slot, so cos is formed in the reference's order)
+    MW_STAMP(3);
     const int npairs = cntU * (cntU - 1) / 2;
     for (int p0 = 0; p0 < npairs; p0 += 64) {
         const int p = p0 + lane;
@@ -405,6 +416,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     // range are queued (entry + owner rank, 8 bytes) in the wave's scratch.  FLUSH: whenever 64 are
     // queued (and at the end) one full pass does the expensive part -- rsqrt, reciprocal, exp and the two
     // cosines -- with every lane busy, instead of three passes at one third occupancy.
+    MW_STAMP(4);
     int nq = 0;                                              // queued entries (wave-uniform)
     auto flush = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -415,13 +427,13 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
             const int qw = ws->qown[lane];
             const int own = qw & 31, fl = qw >> 25;
             const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
-            double xk, yk, zk, kvx, kvy, kvz;
-            getpos(kk, xk, yk, zk);
-            getiv(k2, kvx, kvy, kvz);
             const double pjx = ws->q[0][own], pjy = ws->q[1][own], pjz = ws->q[2][own];
             const double ro = ws->rinvo[own], rn = ws->rinvn[own], go_ = ws->go[own], gn_ = ws->gn[own];
             // r_jk = (r_k + ivect(k)) + (ivect(j) - q_j)   (:332,334, the last two terms taken together in pass 0: the very
             // expression the scan used for the in-range decision)
+            double xk, yk, zk, kvx, kvy, kvz;
+            getpos(kk, xk, yk, zk);
+            getiv(k2, kvx, kvy, kvz);
             const double bx = (xk + kvx) + ws->c[0][own];
             const double by = (yk + kvy) + ws->c[1][own];
             const double bz = (zk + kvz) + ws->c[2][own];
@@ -492,8 +504,10 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         }
         nq += c;
     }
+    MW_STAMP(5);
     if (nq > 0) flush();
     __builtin_amdgcn_wave_barrier();                          // scratch is reused by the wave's next request
+    MW_STAMP(6);
 
     // Wave sums on the DPP network (no LDS round trips): afterwards lane 63 holds the totals.
     double eo, en;                                                                                 // :397
@@ -503,6 +517,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     res.eo = eo; res.en = en;
     res.io = (unsigned int)__popc(mo_) + nto; res.in_ = (unsigned int)__popc(mn_) + ntn;
     res.so = so; res.sn = sn;
+    MW_STAMP(7);
     return true;
 }
 
@@ -676,16 +691,20 @@ void k_local_energy_single(double* __restrict__ pos, const double* __restrict__ 
 // sites, mc_moves.F90:1010,1083): a kernel launch plus its completion cost ~30 us, fifteen times what the
 // reference spends on the whole evaluation, so the engine keeps ONE small kernel resident instead -- started by
 // the first single call, stopped by any entry point that changes device state behind its back (uploads, list
-// builds, the batch kernels) and by mw_finalize, and by itself after `idle_limit` empty polls.  Wavefront w of
-// its one workgroup serves mail slot w (lattice ils goes to slot (ils - 1) % nslots, so the two lattices of a
-// move can be evaluated concurrently from two host threads): it polls the slot's request word in host-mapped
-// memory, evaluates the request with local_energy_wave (positions read past the L1: this kernel itself commits
-// the two overridden positions between requests), writes energy + counts and then the sequence word back.  The
-// cost of a call is a PCIe round trip plus the evaluation, not a launch.
+// builds, the batch kernels) and by mw_finalize, and by itself after `idle_limit` empty polls.  Workgroup w (one
+// wavefront) serves mail slot w (lattice ils goes to slot (ils - 1) % nslots, so the two lattices of a move can
+// be evaluated concurrently from two host threads): it polls the slot's request lines (device memory the host
+// writes through the BAR, or host-mapped memory), evaluates the request with move_energy_wave (positions read
+// past the L1: this kernel itself commits the two overridden positions between requests), and writes energy +
+// sequence word to the reply line in host memory.  The cost of a call is a posted PCIe write each way, a poll
+// and the evaluation, not a launch.
+// One workgroup per slot, not one wavefront of a shared workgroup: a compute unit's vector memory pipeline returns
+// data in order, and with eight wavefronts polling across PCIe (1.3 us a read) every gather of the one that is
+// working queued behind their polls -- 8.9 us an evaluation against 3.6 us on a compute unit of its own.
 // =====================================================================================
-struct MailSlot {                       // host-mapped, 64-byte aligned; one per served slot
-    // request, line A (the host writes the fields of both lines, then seq_a, then seq_b: a 64-byte line read over
-    // PCIe is one snapshot, so a line that shows the new sequence word shows its new fields)
+struct MailSlot {                       // 64-byte aligned; one per served slot (request lines and reply line may live in different copies)
+    // request, line A (the host writes the fields of both lines, then seq_a, then seq_b, a store fence between them:
+    // a line that shows the new sequence word shows its new fields, and seq_b == seq_a says both lines are in)
     unsigned long long seq_a;
     int box, imol;                      // 0-based
     double x1, y1, z1;                  // position of imol, if flags & 2
@@ -705,17 +724,17 @@ static_assert(sizeof(MailSlot) == 192, "two request lines and one reply line");
 struct MailHead { int quit; int exited; int pad[14]; };
 
 template <bool COHERENT>
-__global__ __launch_bounds__(512)
-void k_local_server(MailHead* __restrict__ head, MailSlot* __restrict__ slots,
+__global__ __launch_bounds__(64)
+void k_local_server(MailHead* __restrict__ head, MailSlot* __restrict__ slots, const MailSlot* __restrict__ reqs,
                     double* __restrict__ pos, const double* __restrict__ ivect, const int* __restrict__ nivect,
                     const uint32_t* __restrict__ listm, const int* __restrict__ nn,
                     int N, int ivcap, long long idle_limit, int stamps)
 {
-    __shared__ WaveScratch wsall[8];
+    __shared__ WaveScratch ws;
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = blockIdx.x;
     MailSlot* m = slots + w;
-    const unsigned long long* words = reinterpret_cast<const unsigned long long*>(m);
+    const unsigned long long* words = reinterpret_cast<const unsigned long long*>(reqs + w);    // request lines
     unsigned long long last = __hip_atomic_load(&m->rep_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     long long idle = 0;
     auto word = [&](unsigned long long v, int l) {
@@ -753,7 +772,7 @@ void k_local_server(MailHead* __restrict__ head, MailSlot* __restrict__ slots,
             auto nnof = [&](int jx) { return NNb[jx]; };
             MoveRes res;
             double e;
-            if (move_energy_wave(getpos, getiv, row, nnof, &wsall[w], nivect[b], i, nnof(i), row(i, lane & 31), xi, yi, zi, xi, yi, zi, lane, res)) {
+            if (move_energy_wave(getpos, getiv, row, nnof, &ws, nivect[b], i, nnof(i), row(i, lane & 31), xi, yi, zi, xi, yi, zi, lane, res)) {
                 e = res.eo;
             } else {
                 unsigned int ni, ns;

@@ -128,6 +128,11 @@ class EnergyModule:
         self._stale = [True] * self.num_lattices     # set by compute_ivects: bulk position change pending
         self._live = False
         self.warnings = []
+        # the single call is latency-bound: everything that can be prepared once is
+        self._local = self.L.mw_local_energy_patched
+        self._e_out = [ctypes.c_double(0.0) for _ in range(self.num_lattices)]    # per lattice: distinct lattices may be
+        self._e_ref = [ctypes.byref(v) for v in self._e_out]                      # queried from distinct host threads
+        self._ljr_seen, self._ljr_addr = None, 0
 
     # -- plumbing ------------------------------------------------------------------
     def _chk(self, rc):
@@ -254,14 +259,28 @@ class EnergyModule:
             raise MwError(f"molecule index {imol} outside 1..{self.nwater}")
         if self._stale[b]:
             self._upload(ils)
-        r = np.ascontiguousarray(self.ljr[b, imol - 1], dtype=np.float64)
         prev = self._last_imol[b]
-        e = ctypes.c_double(0.0)
-        if prev >= 1 and prev != imol:
-            rp = np.ascontiguousarray(self.ljr[b, prev - 1], dtype=np.float64)
-            self._chk(self.L.mw_local_energy_patched(ils, imol, _d(r), prev, _d(rp), ctypes.byref(e)))
+        e, eref = self._e_out[b], self._e_ref[b]
+        lj = self.ljr
+        if lj is not self._ljr_seen:           # (re)bound by the caller: its address, once, if it is laid out as we pass it
+            ok = lj.dtype == np.float64 and lj.flags.c_contiguous and lj.shape == (self.num_lattices, self.nwater, 3)
+            self._ljr_seen, self._ljr_addr = lj, (lj.ctypes.data if ok else 0)
+        base = self._ljr_addr
+        if base:                                # the two positions straight out of the caller's array (24 bytes per molecule)
+            row = base + 24 * (b * self.nwater - 1)
+            if prev >= 1 and prev != imol:
+                rc = self._local(ils, imol, ctypes.c_void_p(row + 24 * imol), prev, ctypes.c_void_p(row + 24 * prev), eref)
+            else:
+                rc = self._local(ils, imol, ctypes.c_void_p(row + 24 * imol), 0, None, eref)
+            if rc:
+                self._chk(rc)
         else:
-            self._chk(self.L.mw_local_energy_patched(ils, imol, _d(r), 0, None, ctypes.byref(e)))
+            r = np.ascontiguousarray(lj[b, imol - 1], dtype=np.float64)
+            if prev >= 1 and prev != imol:
+                rp = np.ascontiguousarray(lj[b, prev - 1], dtype=np.float64)
+                self._chk(self._local(ils, imol, _d(r), prev, _d(rp), eref))
+            else:
+                self._chk(self._local(ils, imol, _d(r), 0, None, eref))
         self._last_imol[b] = imol
         return e.value
 

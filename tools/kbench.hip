@@ -11,6 +11,7 @@
 #include <chrono>
 #include <functional>
 #include <map>
+#include <thread>
 
 #define CK(x) do { if ((x)) { fprintf(stderr, "FAIL %s: %s\n", #x, mw_last_error()); return 1; } } while (0)
 #define HK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP FAIL %s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -125,11 +126,43 @@ int main(int argc, char** argv)
                 tp += (double)g.h_slots[0].pad_c[0] * 0.01; te += (double)g.h_slots[0].pad_c[1] * 0.01;
             }
             printf("time  server: poll read %.2f us, evaluation %.2f us (device clock, mean of 1000)\n", tp / 1000, te / 1000);
+#ifdef MW_LAT_STAMPS      // (build with -DMW_LAT_STAMPS: the stamps themselves cost a few tenths of a microsecond)
+            double acc8[8] = {0};
+            for (int k = 0; k < 200; ++k) {
+                const int im = 1 + (k * 53) % N;
+                mw_local_energy_patched(1, im, &p1[3 * (size_t)(im - 1)], 0, nullptr, &e);
+                unsigned long long st[16];
+                (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(mw::g_lat_stamps), sizeof st);
+                for (int q = 1; q < 8; ++q) acc8[q] += (double)(st[q] - st[q - 1]) * 0.01;
+            }
+            printf("time  inside one evaluation (us): own row %.2f | compaction %.2f | row fetch issue %.2f | j-i-k pairs %.2f | scan %.2f | last flush %.2f | sums %.2f\n",
+                   acc8[1] / 200, acc8[2] / 200, acc8[3] / 200, acc8[4] / 200, acc8[5] / 200, acc8[6] / 200, acc8[7] / 200);
+#endif
         }
         const auto t0 = std::chrono::steady_clock::now();
         const double acc = run(20000);
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 20000.0;
         printf("time  mw_local_energy_patched, one call (server %s)   %8.2f us   (sum %.6f)\n", g.srv_enabled ? "resident" : "off: one launch per call", us, acc);
+        if (g.srv_enabled && W >= 2) {   // two host threads, one lattice each (the reference's dormant OpenMP sections): each has its own slot
+            std::vector<double> p2(pos.begin() + (size_t)N * 3, pos.begin() + (size_t)N * 6);
+            auto one = [&](int box, const std::vector<double>& pp, int ncalls, double* out) {
+                double a = 0.0, e = 0.0; int prev = 0; unsigned s = 777u + box;
+                for (int k = 0; k < ncalls; ++k) {
+                    s = s * 1664525u + 1013904223u;
+                    const int im = (int)(s % (unsigned)N) + 1;
+                    if (mw_local_energy_patched(box, im, &pp[3 * (size_t)(im - 1)], prev, prev ? &pp[3 * (size_t)(prev - 1)] : nullptr, &e)) break;
+                    a += e; prev = im;
+                }
+                *out = a;
+            };
+            double a1 = 0.0, a2 = 0.0;
+            const auto tt = std::chrono::steady_clock::now();
+            std::thread th(one, 2, std::cref(p2), 20000, &a2);
+            one(1, p1, 20000, &a1);
+            th.join();
+            printf("time  two threads, one lattice each, per PAIR of calls  %8.2f us   (sums %.6f %.6f)\n",
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tt).count() / 20000.0, a1, a2);
+        }
         double em = 0.0;
         const auto t1 = std::chrono::steady_clock::now();
         for (int k = 0; k < 200; ++k) CK(mw_model_energy(1, &em));
