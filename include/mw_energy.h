@@ -172,6 +172,10 @@ int mw_sweep_options(int record, int samplerun, int always_switch, int npt,
 /* leshift (userparams.f90:41; main.f90:146-150,173): the reference enthalpies of the two lattices enter the order
  * parameter (mc_moves.F90:1371,1526,1584) and the lattice-switch acceptance (:1567,1572).  (0, 0) = off. */
 int mw_sweep_leshift(double ref_enthalpy_1, double ref_enthalpy_2);
+/* The reference's -DMINU build as a run option (mc_moves.F90:1119-1140,1168-1170,1385-1401,1426-1429; off in every
+ * shipped example): an accepted translation or volume move also takes the walker to the lattice with the lower
+ * enthalpy (E + PV, minus ref_enthalpy under leshift), the acceptance carrying the switch's terms.  Two lattices only. */
+int mw_sweep_minu(int on);
 /* wl_swetnam (mc_moves.F90:1636-1653): after every recorded move the walker's increment becomes
  * min(orig_wl_factor, wl_alpha nbins log(rms deviation of its histogram from flat)); mu_min / mu_max of the whole grid. */
 int mw_sweep_swetnam(int on, double wl_alpha, double orig_wl_factor, double mu_min, double mu_max);

@@ -1294,7 +1294,7 @@ int mw_sweep_configure(int nlat, double beta, double max_trans, int nbins, int e
     HIPCHK(hipMemset(g.d_wsum, 0, sizeof(double) * g.nbox));
     HIPCHK(hipMemset(g.d_winflag, 0, sizeof(int) * g.nbox));
     g.has_windows = false; g.has_steps = false;
-    g.sp.dref = 0.0; g.sp.swetnam = 0; g.sp.dd = 0; g.sp.wl_alpha = 1.0; g.sp.orig_wl_factor = 0.0;
+    g.sp.dref = 0.0; g.sp.ref1 = g.sp.ref2 = 0.0; g.sp.minu = 0; g.sp.pad_minu = 0; g.sp.swetnam = 0; g.sp.dd = 0; g.sp.wl_alpha = 1.0; g.sp.orig_wl_factor = 0.0;
     g.sp.mu_min = mu_lo; g.sp.mu_max = mu_hi; g.sp.eq_cycles = 0; g.sp.in_window = 1;
     HIPCHK(hipMemset(g.d_wvol, 0, sizeof(unsigned long long) * 2 * g.nbox));
     HIPCHK(hipMemset(g.d_wflag, 0, sizeof(int) * g.nbox));
@@ -1367,6 +1367,17 @@ int mw_sweep_leshift(double ref_enthalpy_1, double ref_enthalpy_2)
     if (check_live()) return 1;
     if (!g.sweep_ready) return fail("mw_sweep_leshift: call mw_sweep_configure first");
     g.sp.dref = ref_enthalpy_1 - ref_enthalpy_2;
+    g.sp.ref1 = ref_enthalpy_1; g.sp.ref2 = ref_enthalpy_2;
+    return 0;
+}
+
+int mw_sweep_minu(int on)
+{
+    MW_LOCK;
+    if (check_live()) return 1;
+    if (!g.sweep_ready) return fail("mw_sweep_minu: call mw_sweep_configure first");
+    if (on && g.sp.nlat != 2) return fail("mw_sweep_minu: needs two lattices per walker");
+    g.sp.minu = on ? 1 : 0;
     return 0;
 }
 

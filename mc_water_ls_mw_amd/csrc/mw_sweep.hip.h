@@ -36,7 +36,31 @@ struct SweepParams {
     int swetnam, dd;                                // dd: parallel_strategy = 'dd' (window per walker, mc_moves.F90:181-210,659-709)
     double wl_alpha, orig_wl_factor, mu_min, mu_max;
     int eq_cycles, in_window;                       // dd: equilibration length (cycles); in_window: this walker's flag (filled per walker)
+    // the reference's -DMINU build (mc_moves.F90:1119-1140,1168-1170,1385-1401,1426-1429): an accepted move also takes the
+    // walker to the lattice of lower enthalpy; ref1/ref2 = ref_enthalpy(1:2) under leshift, 0 otherwise
+    int minu, pad_minu;
+    double ref1, ref2;
 };
+
+// The MINU branch of both move types: the lattice the move would end in; diffkT rewritten with the switch's terms if it differs.
+// E = trial energies, V = trial volumes, Eb / Vb = energy and volume of the CURRENT lattice before the move.
+__device__ __forceinline__ int dev_minu_branch(const SweepParams& sp, int ls, double E1, double E2, double V1, double V2,
+                                               double Eb, double Vb, bool vol_terms, int N, double new_eta, double old_eta,
+                                               double& diffkT)
+{
+    const double h1 = E1 + sp.pressure * V1 - sp.ref1, h2 = E2 + sp.pressure * V2 - sp.ref2;   // minloc, :1122-1126
+    const int lsn = h2 < h1 ? 2 : 1;
+    if (lsn != ls) {
+        const double En = lsn == 1 ? E1 : E2, Vn = lsn == 1 ? V1 : V2;
+        double d;
+        if (vol_terms) d = sp.beta * En - sp.beta * Eb + sp.beta * sp.pressure * (Vn - Vb) - (double)N * log(Vn / Vb) + new_eta - old_eta;   // :1131-1133,1396-1397
+        else           d = sp.beta * En - sp.beta * Eb + new_eta - old_eta;                                                                  // :1135
+        if (sp.ref1 != 0.0 || sp.ref2 != 0.0)                                                                                               // leshift, :1134,1136,1398
+            d = d - sp.beta * (lsn == 1 ? sp.ref1 : sp.ref2) + sp.beta * (ls == 1 ? sp.ref1 : sp.ref2);
+        diffkT = d;
+    }
+    return lsn;
+}
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
 {
@@ -101,7 +125,7 @@ __device__ __forceinline__ void dev_recipmatrix(const double* __restrict__ h, do
 }
 
 // -------------------------------------------------------------------------------------
-// Volume move of one walker by its wavefront: mc_volume (mc_moves.F90:1216-1534; MINU/leshift off; ref_ljr,
+// Volume move of one walker by its wavefront: mc_volume (mc_moves.F90:1216-1534; ref_ljr,
 // which only chain synchronisation reads, is not carried).  Rare (probability ~1/N per move), so it is an
 // out-of-line function: one symmetric hmatrix element of both lattices changes, every position is rescaled
 // through fractional coordinates (lanes over molecules), image vectors are rebuilt on the device in the
@@ -231,7 +255,7 @@ __device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, 
 __device__ __forceinline__
 int volume_move_wave(const VolCtx& c, const SweepParams& sp, const double* weight, const double* __restrict__ mu_bin,
                      const double* __restrict__ binwidth, double u0, double u1, double u2, double u3,
-                     int ls, double& ls_mu, double men[2], int lane)
+                     int& ls, double& ls_mu, double men[2], int lane)
 {
     const int L = c.L, N = c.N;
     double backup_e[2] = {men[0], men[1]}, old_vol[2] = {c.svol[0], c.svol[1]};
@@ -292,11 +316,16 @@ int volume_move_wave(const VolCtx& c, const SweepParams& sp, const double* weigh
             ls_mu = mu;
             new_eta = dev_eta_weight(sp, weight, mu_bin, binwidth, ls_mu);
         }
-        const double diffkT = sp.beta * dE + new_eta - old_eta + sp.beta * sp.pressure * (Vls - Vold)
-                              - (double)N * log(Vls / Vold);                                     // :1381-1382
+        double diffkT = sp.beta * dE + new_eta - old_eta + sp.beta * sp.pressure * (Vls - Vold)
+                        - (double)N * log(Vls / Vold);                                           // :1381-1382
+        int minu_ls = ls;
+        if (sp.minu && L == 2)                                                                   // :1385-1401
+            minu_ls = dev_minu_branch(sp, ls, men[0], men[1], c.svol[0], c.svol[1], ls == 1 ? backup_e[0] : backup_e[1], Vold, true, N,
+                                      new_eta, old_eta, diffkT);
         double cmp = exp(-diffkT);
         cmp = cmp > 1.0 ? 1.0 : cmp;
         ok = u3 < cmp ? 1 : 0;                                                                   // :1410
+        if (ok) ls = minu_ls;                                                                    // :1426-1429
     }
     if (!ok) {                                                                                   // :1426-1530
         double recip_new[2][9];
@@ -545,6 +574,7 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
         const double bk0 = men[0], bk1 = men[1];                                  // :1013
         men[0] = (men[0] - eo[0]) + en[0];                                        // :1016,1087
         men[1] = (men[1] - eo[1]) + en[1];
+        int minu_ls = ls;
         if (L == 1) {
             diffkT = sp.beta * dE0;                                               // :1106
         } else {
@@ -552,12 +582,16 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
             ls_mu = ls_mu + (dE0 - dE1) * sp.beta;
             const double eta_new = dev_eta_weight(sp, weight, mu_bin, binwidth, ls_mu);
             diffkT = (ls == 1 ? dE0 : dE1) * sp.beta + eta_new - eta_old;
+            if (sp.minu)                                                          // :1119-1140
+                minu_ls = dev_minu_branch(sp, ls, men[0], men[1], svol[0], svol[1], ls == 1 ? bk0 : bk1, ls == 1 ? svol[0] : svol[1],
+                                          sp.npt != 0, N, eta_new, eta_old, diffkT);
         }
         double pacc = exp(-diffkT);
         pacc = pacc > 1.0 ? 1.0 : pacc;
         ok = u5 < pacc;                                                           // :1145-1146 (false for NaN)
         if (ok) {
             ++acc;
+            ls = minu_ls;                                                         // :1168-1170
             if (lane == 0) {
 #pragma unroll
                 for (int l = 0; l < 2; ++l) if (l < L) {

@@ -50,7 +50,7 @@ ABI_SYMBOLS = (
     "mw_sweep_reduce_tables", "mw_sweep_broadcast_tables",
     "mw_sweep_get_tables_range", "mw_sweep_set_tables_range",
     "mw_sweep_moves", "mw_sweep_get_volume_moves", "mw_sweep_sync_cells", "mw_sweep_check_flags",
-    "mw_sweep_leshift", "mw_sweep_swetnam", "mw_sweep_dd", "mw_sweep_windows", "mw_sweep_set_factors", "mw_sweep_get_factors", "mw_sweep_steps", "mw_sweep_get_counters",
+    "mw_sweep_leshift", "mw_sweep_minu", "mw_sweep_swetnam", "mw_sweep_dd", "mw_sweep_windows", "mw_sweep_set_factors", "mw_sweep_get_factors", "mw_sweep_steps", "mw_sweep_get_counters",
 )
 
 

@@ -27,7 +27,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         deltaG_int=100000, max_mc_cycles=None, eq_mc_cycles=0, outdir=None, thermalise=True, regauge=False,
         parallel_strategy="mw", window_overlap=2, leshift=False, input_ref_enthalpy=None, wl_swetnam=False, wl_alpha=1.0,
         eq_adjust_mc=False, mc_target_ratio=0.5, monitor_int=1000, mc_max_trans_ang=1.1, mc_dv_max_ang=0.924,
-        latt_sync_int=10000, chkpt_dump_int=None, restart=False):
+        latt_sync_int=10000, chkpt_dump_int=None, restart=False, minu=False):
     """Run `cycles` MC cycles of `walkers` two-lattice walkers on this GPU.  Returns a dict of results.
 
     ``flat_chk_int`` ... ``file_wl_factor``: the Wang-Landau schedule (mc_check_flatness, :291-294;
@@ -48,7 +48,9 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
     ``chkpt_dump_int`` / ``restart`` (with ``outdir``): every walker writes the reference's own checkpoint file --
     ``checkpointRRR.dat.{1,2}`` alternately, R = its global index (mc_checkpoint_write, :324-390; at most 1000 walkers in
     all) -- and a restarted run takes cycle number, step sizes, increment, tables, cells, reference and current positions
-    and the active lattice from the newer readable one (mc_checkpoint_load, :393-501) and runs ``cycles`` MORE cycles."""
+    and the active lattice from the newer readable one (mc_checkpoint_load, :393-501) and runs ``cycles`` MORE cycles.
+    ``minu``: the reference's compile-time ``-DMINU`` variant as a run option (an accepted move also takes the walker to
+    the lattice of lower enthalpy, mc_moves.F90:1119-1140,1385-1401)."""
     from . import lattice as lat
     from .energy import EnergyModule
     from .schedule import WangLandauSchedule, WindowSchedules, delta_g_from_hist, log_unbiased_norm
@@ -107,6 +109,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             if ref is None or not np.any(np.abs(ref) > np.finfo(np.float64).tiny):
                 ref = farm.starting_enthalpy(1, npt)
             farm.leshift(ref)
+        if minu:
+            farm.minu(True)
         if wl_swetnam:
             farm.swetnam(True, wl_alpha, wl_factor)
             farm.set_factors(wl_factor=np.full(walkers, sched.wl_factors[0] if dd else sched.wl_factor))
@@ -303,6 +307,7 @@ def main():
     ap.add_argument("--window-overlap", type=int, default=2)
     ap.add_argument("--eq-cycles", type=int, default=0, help="eq_mc_cycles")
     ap.add_argument("--leshift", action="store_true")
+    ap.add_argument("--minu", action="store_true", help="the reference's -DMINU variant: accepted moves end in the lattice of lower enthalpy")
     ap.add_argument("--wl-swetnam", action="store_true")
     ap.add_argument("--wl-alpha", type=float, default=1.0)
     ap.add_argument("--chkpt", type=int, default=None, help="chkpt_dump_int: cycles between checkpoint files (needs --outdir)")
@@ -337,7 +342,7 @@ def main():
               wl_useinvt=args.wl_useinvt, outdir=args.outdir, regauge=args.regauge, parallel_strategy=args.strategy,
               window_overlap=args.window_overlap, eq_mc_cycles=args.eq_cycles, leshift=args.leshift,
               wl_swetnam=args.wl_swetnam, wl_alpha=args.wl_alpha, eq_adjust_mc=args.eq_adjust, monitor_int=args.monitor,
-              thermalise=not args.no_thermalise, chkpt_dump_int=args.chkpt, restart=args.restart, latt_sync_int=args.latt_sync)
+              thermalise=not args.no_thermalise, chkpt_dump_int=args.chkpt, restart=args.restart, latt_sync_int=args.latt_sync, minu=args.minu)
     tabs = res.pop("tables")
     res.pop("walker1_tables"), res.pop("walker1_positions"), res.pop("first_walkers")
     joined = res.pop("joined")

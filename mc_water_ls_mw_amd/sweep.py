@@ -148,6 +148,12 @@ class WalkerFarm:
         self.dref = r1 - r2
         self.em._chk(self.L.mw_sweep_leshift(ctypes.c_double(r1), ctypes.c_double(r2)))
 
+    def minu(self, on=True):
+        """The reference's ``-DMINU`` build as a run option (mc_moves.F90:1119-1140,1168-1170,1385-1401,1426-1429): an
+        accepted translation or volume move also takes the walker to the lattice of lower enthalpy (E + PV, less
+        ref_enthalpy under :meth:`leshift`), with the switch's terms in the acceptance."""
+        self.em._chk(self.L.mw_sweep_minu(int(bool(on))))
+
     def starting_enthalpy(self, walker=1, npt=False):
         """ref_enthalpy as main.f90:146-147 forms it from a walker's current full-box energies."""
         b = (walker - 1) * 2

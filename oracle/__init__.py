@@ -233,6 +233,10 @@ class SweepOracle:
     def set_leshift(self, ref1=0.0, ref2=0.0):
         self.L.mwo_set_leshift(ctypes.c_double(ref1), ctypes.c_double(ref2))
 
+    def set_minu(self, on):
+        """the reference compiled with -DMINU (mc_moves.F90:1119-1140,1385-1401): accepted moves end in the lattice of lower enthalpy"""
+        self.L.mwo_set_minu(int(on))
+
     def set_swetnam(self, on, alpha=1.0, orig_wl_factor=0.0, mu_min=0.0, mu_max=0.0, sumhist=0.0):
         self.L.mwo_set_swetnam(int(on), ctypes.c_double(alpha), ctypes.c_double(orig_wl_factor), ctypes.c_double(mu_min),
                                ctypes.c_double(mu_max), ctypes.c_double(sumhist))

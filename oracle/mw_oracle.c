@@ -423,7 +423,31 @@ static int g_swetnam = 0;
 static double g_wl_alpha = 1.0, g_orig_wl_factor = 0.0, g_mu_min = 0.0, g_mu_max = 0.0, g_sumhist = 0.0, g_wl_factor_now = 0.0;
 static int g_dd = 0, g_eq_cycles = 0, g_in_window = 1, g_not_in_window_at_eq = 0;
 
-void mwo_set_leshift(double ref1, double ref2) { g_dref = ref1 - ref2; }
+/* -DMINU (mc_moves.F90:1119-1140,1168-1170,1385-1401,1426-1429; a compile-time variant of the reference, off in its
+ * examples): every accepted translation or volume move also moves the walker to the lattice of lower enthalpy. */
+static int g_minu = 0, g_minu_lsn = 0;
+static double g_ref1 = 0.0, g_ref2 = 0.0;
+void mwo_set_leshift(double ref1, double ref2) { g_dref = ref1 - ref2; g_ref1 = ref1; g_ref2 = ref2; }
+void mwo_set_minu(int on) { g_minu = on; }
+/* the MINU branch shared by both move types: returns the lattice the move would end in, rewrites diffkT if it differs */
+static int minu_branch(int ls, const double *E, const double *V, const double *E_ls_backup, const double *V_ls_old,
+                       int npt_terms, int n, double beta, double pressure, double new_eta, double old_eta, double *diffkT)
+{
+    const double h1 = E[0] + pressure * V[0] - g_ref1, h2 = E[1] + pressure * V[1] - g_ref2;   /* minloc, :1122-1126 (refs 0 without leshift) */
+    const int lsn = h2 < h1 ? 2 : 1;
+    if (lsn != ls) {
+        double d;
+        if (npt_terms)                                                        /* :1131-1133, :1396-1397 */
+            d = beta * E[lsn - 1] - beta * *E_ls_backup + beta * pressure * (V[lsn - 1] - *V_ls_old)
+                - (double)n * log(V[lsn - 1] / *V_ls_old) + new_eta - old_eta;
+        else                                                                  /* :1135 */
+            d = beta * E[lsn - 1] - beta * *E_ls_backup + new_eta - old_eta;
+        if (g_ref1 != 0.0 || g_ref2 != 0.0)                                   /* leshift, :1134,1136,1398 */
+            d = d - beta * (lsn == 1 ? g_ref1 : g_ref2) + beta * (ls == 1 ? g_ref1 : g_ref2);
+        *diffkT = d;
+    }
+    return lsn;
+}
 void mwo_set_swetnam(int on, double alpha, double orig_wl_factor, double mu_min, double mu_max, double sumhist)
 {
     g_swetnam = on; g_wl_alpha = alpha; g_orig_wl_factor = orig_wl_factor; g_mu_min = mu_min; g_mu_max = mu_max; g_sumhist = sumhist;
@@ -602,6 +626,7 @@ static void sweep_impl(int nmoves, uint64_t seed, uint32_t walker, uint64_t move
             deltaE[l] = new_e[l] - old_e[l];
         }
         double diffkT;
+        int minu_ls = ls;
         if (nlat == 1) {
             diffkT = beta * deltaE[0];                                        /* :1106 */
         } else {
@@ -609,6 +634,9 @@ static void sweep_impl(int nmoves, uint64_t seed, uint32_t walker, uint64_t move
             ls_mu = ls_mu + (deltaE[0] - deltaE[1]) * beta;
             const double eta_new = eta_w(eta, ls_mu);
             diffkT = deltaE[ls - 1] * beta + eta_new - eta_old;
+            if (g_minu)                                                       /* :1119-1140 */
+                minu_ls = minu_branch(ls, model_energy, opt->volume, &backup[ls - 1], &opt->volume[ls - 1], opt->npt, n, beta,
+                                      opt->pressure, eta_new, eta_old, &diffkT);
         }
         const double zeta = u[5];                                             /* :1145 */
         double pacc = exp(-diffkT);
@@ -616,6 +644,7 @@ static void sweep_impl(int nmoves, uint64_t seed, uint32_t walker, uint64_t move
         const int ok = zeta < pacc;                                           /* :1146 (false for NaN) */
         if (ok) {
             ++acc;
+            ls = minu_ls;                                                     /* :1168-1170 */
         } else {                                                              /* :1182-1195 */
             for (int l = 0; l < nlat; ++l) {
                 double *p = LAT(l, xyz, 3 * n) + 3 * (imol - 1);
@@ -717,11 +746,16 @@ int mwo_volume_move(const double u[4], int nlat, int n, double *xyz, double *h, 
         new_eta = eta_w(eta, *ls_mu);
     }
     const double x = u[3];                                                    /* :1378 */
-    const double diffkT = beta * deltaE[ls - 1] + new_eta - old_eta + beta * pressure * (volume[ls - 1] - old_vol[ls - 1])
-                          - (double)n * log(volume[ls - 1] / old_vol[ls - 1]);   /* :1381-1382 */
+    double diffkT = beta * deltaE[ls - 1] + new_eta - old_eta + beta * pressure * (volume[ls - 1] - old_vol[ls - 1])
+                    - (double)n * log(volume[ls - 1] / old_vol[ls - 1]);         /* :1381-1382 */
+    g_minu_lsn = ls;
+    if (g_minu && nlat == 2)                                                  /* :1385-1401 */
+        g_minu_lsn = minu_branch(ls, model_energy, volume, &backup_e[ls - 1], &old_vol[ls - 1], 1, n, beta, pressure,
+                                 new_eta, old_eta, &diffkT);
     double compare = exp(-diffkT);
     if (compare > 1.0) compare = 1.0;
-    if (x < compare) return 1;                                                /* :1410 */
+    if (x < compare) return 1;                                                /* :1410 (with MINU the caller takes g_minu_lsn, :1426-1429) */
+    g_minu_lsn = ls;
     /* rejected, :1426-1530 */
     for (int l = 0; l < nlat; ++l) {
         volume[l] = old_vol[l];
@@ -769,6 +803,7 @@ void mwo_sweep_full(int nmoves, uint64_t seed, uint32_t walker, uint64_t move0, 
             const int ok = mwo_volume_move(u, nlat, n, xyz, h, volume, ivect, ivstride, nivect, maxneigh, nn, jn, vn,
                                            beta, dv_max, opt->pressure, eta, *ls, ls_mu, model_energy);
             if (nvol) { ++nvol[0]; if (ok == 1) ++nvol[1]; }
+            if (ok == 1 && g_minu && nlat == 2) *ls = g_minu_lsn;                                      /* :1426-1429 */
             int sw = 0;
             if (nlat == 2) {
                 opt->volume[0] = volume[0]; opt->volume[1] = volume[1];

@@ -141,6 +141,7 @@ void mwo_move_uniforms8(uint64_t seed, uint32_t walker, uint64_t move, double u[
  * 'dd' (mc_moves.F90:181-210,243-248,913): in_window = walker_in_window at entry; mwo_get_dd returns it and whether the
  * walker was outside its window at cycle eq_cycles (the reference stops there). */
 void mwo_set_leshift(double ref1, double ref2);
+void mwo_set_minu(int on);   /* -DMINU variant of mc_moves.F90 (:1119-1140,1385-1401) */
 void mwo_set_swetnam(int on, double alpha, double orig_wl_factor, double mu_min, double mu_max, double sumhist);
 void mwo_get_swetnam(double *sumhist, double *wl_factor);
 void mwo_set_dd(int on, int eq_cycles, int in_window);

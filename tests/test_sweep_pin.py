@@ -84,7 +84,7 @@ def read_records(path):
 
 def run_reference(d, num_lattices, temperature, cycles, weight=None, grid=None, samplerun=None, always_switch=False,
                   tables=False, npt=False, vol_prob=None, transP=1.0, latt_sync=None, mc_extra="", book_extra="", run_env={},
-                  par_extra=""):
+                  par_extra="", program=None):
     from mc_water_ls_mw_amd import lattice as lat
     os.makedirs(d)
     samplerun = (weight is not None) if samplerun is None else samplerun
@@ -101,7 +101,7 @@ def run_reference(d, num_lattices, temperature, cycles, weight=None, grid=None, 
             for mu, w in zip(grid.mu_bin, weight):
                 fh.write(f"  {float(mu)!r}        {float(w)!r}\n")
     env = dict(os.environ, MW_WRAP_SWITCH="1" if always_switch else "0", MW_WRAP_TRANSP=repr(float(transP)), **run_env)
-    out = subprocess.run([RNG, "ice.input"], cwd=d, capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([program or RNG, "ice.input"], cwd=d, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, (out.stdout[-800:], out.stderr[-800:])
     therm = [f for f in os.listdir(d) if f.endswith("_therm.dat")][0]
     e_ev = np.array([float(ln.split()[1]) for ln in open(os.path.join(d, therm))])
