@@ -160,6 +160,38 @@ struct LdsVecs {
     }
 };
 
+// Stage the flat [n][3] array `src` into LDS in layout LAYOUT with THREADS threads.  The loads of a batch are ALL
+// issued before the first store: the plain loop `dst[slot(t)] = src[t]` compiles to load, wait, store per iteration
+// -- twelve HBM round trips in a row for a 4096-molecule box (~10 us of a workgroup that lives ~48 us).
+template <int LAYOUT, int THREADS>
+__device__ __forceinline__ void stage_vecs(double* __restrict__ dst, const double* __restrict__ src, int count, int n, int tid)
+{
+    constexpr int kBatch = 12;                           // (`count` vectors are copied; `n` is the layout's capacity)
+    const int total = 3 * count;
+    if (total <= 0) return;
+    for (int base = 0; base < total; base += kBatch * THREADS) {
+        double v[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) { const int t = base + tid + k * THREADS; v[k] = src[t < total ? t : total - 1]; }
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) { const int t = base + tid + k * THREADS; if (t < total) dst[LdsVecs<LAYOUT>::slot(t, n)] = v[k]; }
+    }
+}
+
+// The image vectors of a box (a few dozen, 3 x niv doubles): the first THREADS elements are requested with `stage_iv_begin`
+// BEFORE the positions are staged and stored with `stage_iv_end` after, so their round trip overlaps the box's.
+template <int THREADS>
+__device__ __forceinline__ double stage_iv_begin(const double* __restrict__ IV, int niv, int tid)
+{
+    return niv > 0 ? IV[tid < 3 * niv ? tid : 0] : 0.0;
+}
+template <int LAYOUT, int THREADS>
+__device__ __forceinline__ void stage_iv_end(double* __restrict__ siv, const double* __restrict__ IV, int niv, int ivcap, int tid, double first)
+{
+    if (tid < 3 * niv) siv[LdsVecs<LAYOUT>::slot(tid, ivcap)] = first;
+    for (int t = tid + THREADS; t < 3 * niv; t += THREADS) siv[LdsVecs<LAYOUT>::slot(t, ivcap)] = IV[t];   // (more than THREADS / 3 images: small sheared cells)
+}
+
 // ---- wave / block reductions ---------------------------------------------------------
 // Inclusive prefix sums over the 64 lanes through the DPP network: four shifts inside each row of 16
 // lanes, then lane 15 of a row into the next row and lane 31 into the upper half.  Lane 63 ends up with

@@ -237,21 +237,8 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
     double* spos = smem;
     double* siv = smem + (LDSPOS ? lds_vec_bytes((size_t)N) / 8 : 0);
     uint32_t* queue = reinterpret_cast<uint32_t*>(siv + lds_vec_bytes((size_t)ivcap) / 8) + tid;   // [kQCap + 1][BLOCK]
-    for (int t = tid; t < niv * 3; t += BLOCK) siv[LdsVecs<LAYOUT>::slot(t, ivcap)] = IV[t];
-    if (LDSPOS) {
-        for (int t = tid; t < 3 * N; t += BLOCK) spos[LdsVecs<LAYOUT>::slot(t, N)] = P[t];   // coalesced read of the box
-    }
-    if (tid == 0) s_ticket = BLOCK / 64;
-    __syncthreads();
-
-    const LdsVecs<LAYOUT> vpos{spos, N}, viv{siv, ivcap};
-    auto getiv = [&](int k, double& x, double& y, double& z) { viv.get(k, x, y, z); };
-    auto getpos = [&](int j, double& x, double& y, double& z) {
-        if constexpr (LDSPOS) vpos.get(j, x, y, z);
-        else { const double* p = P + 3 * (size_t)j; x = p[0]; y = p[1]; z = p[2]; }
-    };
-
-    unsigned int np = 0, nt = 0;                         // directed in-range pairs, i-centred triplets of this lane's molecules
+    // first list reads of this wavefront's first group: nothing in them depends on the staged box, so they are in flight
+    // while it is being staged (behind the barrier they would be one more exposed HBM round trip per workgroup)
     const int a0 = split * chunk;                        // a multiple of 64: whole groups (at most kMaxGroups)
     const int a1 = min(N, a0 + chunk);
     const int g0 = a0 >> 6, G = ((a1 + 63) >> 6) - g0;   // this workgroup's groups: g0 .. g0 + G - 1
@@ -267,6 +254,20 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
 #pragma unroll
         for (int u = 0; u < 8; ++u) cur[u] = list_load(rs, col, u, N, S);
     }
+    const double iv_first = stage_iv_begin<BLOCK>(IV, niv, tid);
+    if (LDSPOS) stage_vecs<LAYOUT, BLOCK>(spos, P, N, N, tid);                  // coalesced read of the box, all loads in flight together
+    stage_iv_end<LAYOUT, BLOCK>(siv, IV, niv, ivcap, tid, iv_first);
+    if (tid == 0) s_ticket = BLOCK / 64;
+    __syncthreads();
+
+    const LdsVecs<LAYOUT> vpos{spos, N}, viv{siv, ivcap};
+    auto getiv = [&](int k, double& x, double& y, double& z) { viv.get(k, x, y, z); };
+    auto getpos = [&](int j, double& x, double& y, double& z) {
+        if constexpr (LDSPOS) vpos.get(j, x, y, z);
+        else { const double* p = P + 3 * (size_t)j; x = p[0]; y = p[1]; z = p[2]; }
+    };
+
+    unsigned int np = 0, nt = 0;                         // directed in-range pairs, i-centred triplets of this lane's molecules
     while (grp >= 0) {                                   // wave-uniform
         int tk = 0;
         if (lane == 0) tk = __hip_atomic_fetch_add(&s_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

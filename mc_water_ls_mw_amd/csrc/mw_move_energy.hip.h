@@ -561,13 +561,29 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
     int* simol = reinterpret_cast<int*>(snn + (((size_t)N + 7) & ~(size_t)7));
     __shared__ int s_next;                                                   // next request nobody has taken yet
     const int nreq = w.z - w.y;                                              // <= kMoveChunk when LDSPOS
-    for (int t = tid; t < niv * 3; t += 1024) siv[LdsVecs<LAYOUT>::slot(t, ivcap)] = IV[t];
+    const double iv_first = stage_iv_begin<1024>(IV, niv, tid);
     if (LDSPOS) {
-        for (int t = tid; t < 3 * N; t += 1024) spos[LdsVecs<LAYOUT>::slot(t, N)] = P[t];
-        for (int t = tid; t < N; t += 1024) snn[t] = (unsigned char)NN[t];      // maxneigh <= 64
-        for (int t = tid; t < nreq; t += 1024) simol[t] = req_imol[w.y + t];
+        // every staging load of the item in flight before the first wait (a loop of load / wait / store per element costs a
+        // dozen HBM round trips in a row): row lengths and request molecules first, into registers, then the box
+        constexpr int kB = 4;
+        for (int base = 0; base < N; base += kB * 1024) {
+            int v[kB];
+#pragma unroll
+            for (int k = 0; k < kB; ++k) { const int t = base + tid + k * 1024; v[k] = NN[t < N ? t : N - 1]; }
+#pragma unroll
+            for (int k = 0; k < kB; ++k) { const int t = base + tid + k * 1024; if (t < N) snn[t] = (unsigned char)v[k]; }   // maxneigh <= 64
+        }
+        for (int base = 0; base < nreq; base += kB * 1024) {
+            int v[kB];
+#pragma unroll
+            for (int k = 0; k < kB; ++k) { const int t = base + tid + k * 1024; v[k] = req_imol[w.y + (t < nreq ? t : nreq - 1)]; }
+#pragma unroll
+            for (int k = 0; k < kB; ++k) { const int t = base + tid + k * 1024; if (t < nreq) simol[t] = v[k]; }
+        }
+        stage_vecs<LAYOUT, 1024>(spos, P, N, N, tid);
         if (tid == 0) s_next = 16;
     }
+    stage_iv_end<LAYOUT, 1024>(siv, IV, niv, ivcap, tid, iv_first);
     __syncthreads();
 
     const LdsVecs<LAYOUT> vpos{spos, N}, viv{siv, ivcap};
