@@ -359,14 +359,17 @@ Geo model_geo(int count)
 int launch_model_energy(int first, int count)
 {
     const Geo ge = model_geo(count);
-    dim3 grid(ge.nsplit, count);
+    // whole boxes staged in LDS, one workgroup per box: the workgroups are persistent, one per compute unit (its LDS holds
+    // one), each taking every g.cu-th box and reading its next box while the current one's tail drains
+    static const bool persist = !(std::getenv("MW_MODEL_PERSIST") && std::getenv("MW_MODEL_PERSIST")[0] == '0');   // 0: one workgroup per box (A/B only)
+    dim3 grid(ge.nsplit, persist && ge.lds && ge.nsplit == 1 ? std::min(count, g.cu) : count);
     const int box0 = first - 1;
     if (ge.lds)
         hipLaunchKernelGGL((mw::k_model_energy<true, 1024, kFullLayout>), grid, dim3(1024), ge.shmem, g.stream, g.d_pos, g.d_ivect,
-                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
+                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk, count);
     else
         hipLaunchKernelGGL((mw::k_model_energy<false, 256, kFullLayout, true>), grid, dim3(256), ge.shmem, g.stream, g.d_pos, g.d_ivect,
-                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk);
+                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk, count);
     HIPCHK(hipGetLastError());
     if (ge.nsplit > 1) {           // split boxes: the partials of box b live at [b*nsplit .. b*nsplit+nsplit); unsplit boxes wrote their energy themselves
         hipLaunchKernelGGL(mw::k_sum_partials, dim3(count), dim3(64), 0, g.stream, g.d_partial, g.d_cpartial,
@@ -560,7 +563,8 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
     g.nsplit_max = (nwater + 255) / 256;
     HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     const size_t nb = (size_t)nboxes, N = (size_t)nwater;
-    HIPCHK(hipMalloc(&g.d_pos, nb * N * 3 * sizeof(double)));
+    // (+ one staging ticket: k_model_energy reads whole tickets of the next box, the last of which may run past its end)
+    HIPCHK(hipMalloc(&g.d_pos, (nb * N * 3 + mw::kStageTicket) * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_ivect, nb * g.ivcap * 3 * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_nivect, nb * sizeof(int)));
     HIPCHK(hipMalloc(&g.d_hmat, nb * 9 * sizeof(double)));
@@ -626,7 +630,7 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
     HIPCHK(hipMalloc(&g.d_cpartial, nb * g.nsplit_max * 2 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&g.d_energy, nb * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_counts, nb * 2 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(g.d_pos, 0, nb * N * 3 * sizeof(double)));
+    HIPCHK(hipMemset(g.d_pos, 0, (nb * N * 3 + mw::kStageTicket) * sizeof(double)));
     HIPCHK(hipMemset(g.d_ivect, 0, nb * g.ivcap * 3 * sizeof(double)));
     HIPCHK(hipMemset(g.d_nivect, 0, nb * sizeof(int)));
     HIPCHK(hipMemset(g.d_nn, 0, nb * N * sizeof(int)));

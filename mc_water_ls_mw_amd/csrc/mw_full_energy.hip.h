@@ -203,10 +203,20 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
 }
 
 constexpr int kMaxGroups = 128;          // groups of 64 list columns per workgroup (chunk <= 8192)
+constexpr int kStageHold = 1;            // staging tickets a wavefront holds in registers (12 doubles per lane each; 2 or 3 spill at 1024 threads: measured slower)
+constexpr int kStageTicket = 64 * 12;    // doubles of the next box per staging ticket
 
 // The wavefronts of a workgroup draw groups of 64 list columns from an LDS ticket, heaviest group first (the
 // columns are sorted by work, ascending): a wavefront that drew cheap groups serves more of them, and the
 // workgroup's tail is made of the cheapest groups.
+//
+// A workgroup is PERSISTENT over boxes: it takes boxes blockIdx.y, blockIdx.y + gridDim.y, ... of the launch (the host
+// makes gridDim.y the number of compute units when whole boxes are staged in LDS -- one such workgroup fills a CU's LDS
+// -- and the number of boxes otherwise, which is the plain one-box-per-workgroup launch).  The next box cannot be staged
+// while the current one is in use (2 x 96 KiB do not fit), but it can be READ: a wavefront that has run out of groups
+// draws staging tickets (768 doubles of the next box each) and holds them in registers -- free now that its evaluation
+// is over -- until the slowest wavefront arrives at the barrier; then the registers go to LDS.  The HBM round trip of
+// the staging overlaps the workgroup's tail instead of following it; so do the first list reads of the next box.
 template <bool LDSPOS, int BLOCK, int LAYOUT, bool BATCH4 = false>
 __global__ __launch_bounds__(BLOCK)
 void k_model_energy(const double* __restrict__ pos, const double* __restrict__ ivect,
@@ -214,94 +224,169 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
                     const int* __restrict__ order, const int* __restrict__ nns, const int* __restrict__ cmax,
                     double* __restrict__ partial, unsigned long long* __restrict__ cpartial,
                     double* __restrict__ energy, unsigned long long* __restrict__ counts,
-                    int N, int S, int ivcap, int box0, int nsplit, int chunk)
+                    int N, int S, int ivcap, int box0, int nsplit, int chunk, int count)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double gsum[kMaxGroups];                  // per group of 64 columns: summed in group order at the end,
     __shared__ unsigned long long red_p[BLOCK / 64], red_t[BLOCK / 64];   // so the energy does not depend on who drew what
     __shared__ int s_ticket;
+    __shared__ int s_stage[2];                           // staging tickets, one counter per parity of the workgroup's box number
 
-    const int b = box0 + blockIdx.y;
     const int split = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int ngroups = (N + 63) >> 6;
-    const double* P  = pos + (size_t)b * N * 3;
-    const double* IV = ivect + (size_t)b * ivcap * 3;
-    const uint32_t* L = list + (size_t)b * S * N;
-    const int* ORD = order + (size_t)b * N;
-    const int* NNS = nns + (size_t)b * N;
-    const int* CM = cmax + (size_t)b * ngroups;
-    const int niv = nivect[b];
 
     // dynamic LDS: [positions when LDSPOS][image vectors][in-range queue kQCap x BLOCK u32]
     double* spos = smem;
     double* siv = smem + (LDSPOS ? lds_vec_bytes((size_t)N) / 8 : 0);
     uint32_t* queue = reinterpret_cast<uint32_t*>(siv + lds_vec_bytes((size_t)ivcap) / 8) + tid;   // [kQCap + 1][BLOCK]
-    // first list reads of this wavefront's first group: nothing in them depends on the staged box, so they are in flight
-    // while it is being staged (behind the barrier they would be one more exposed HBM round trip per workgroup)
     const int a0 = split * chunk;                        // a multiple of 64: whole groups (at most kMaxGroups)
     const int a1 = min(N, a0 + chunk);
     const int g0 = a0 >> 6, G = ((a1 + 63) >> 6) - g0;   // this workgroup's groups: g0 .. g0 + G - 1
-    const ListRsrc rs = list_rsrc(L, N, S);
+    const int w0 = __builtin_amdgcn_readfirstlane(wid);
+    const int first_grp = w0 < G ? g0 + G - 1 - w0 : -1; // first tickets: one per wavefront (wave-uniform, in a scalar register)
+    const int nstage = LDSPOS ? (3 * N + kStageTicket - 1) / kStageTicket : 0;
+
+    // first list reads of this wavefront's first group: nothing in them depends on the staged box, so they are in flight
+    // while it is being staged (behind the barrier they would be one more exposed HBM round trip per workgroup)
     uint32_t cur[8];
     int n_cur = 0, mol = 0;
-    const int w0 = __builtin_amdgcn_readfirstlane(wid);
-    int grp = w0 < G ? g0 + G - 1 - w0 : -1;             // first tickets: one per wavefront (wave-uniform, in a scalar register)
     uint32_t col = kNoColumn;
-    if (grp >= 0) {
-        const int t = grp * 64 + lane;
-        if (t < a1) { col = (uint32_t)t * 4u; n_cur = NNS[t]; mol = ORD[t]; }
+    auto first_reads = [&](int b) {
+        col = kNoColumn; n_cur = 0; mol = 0;
+        if (first_grp >= 0) {
+            const int t = first_grp * 64 + lane;
+            if (t < a1) { col = (uint32_t)t * 4u; n_cur = nns[(size_t)b * N + t]; mol = order[(size_t)b * N + t]; }
+            const ListRsrc r0 = list_rsrc(list + (size_t)b * S * N, N, S);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cur[u] = list_load(rs, col, u, N, S);
+            for (int u = 0; u < 8; ++u) cur[u] = list_load(r0, col, u, N, S);
+        }
+    };
+    int bi = blockIdx.y;                                 // the workgroup's current box, counted within the launch
+    {   // the workgroup's first box: staged straight from global memory, all of a thread's loads in flight together
+        const int b = box0 + bi;
+        const double* IV = ivect + (size_t)b * ivcap * 3;
+        const int niv = nivect[b];
+        first_reads(b);
+        const double iv_first = stage_iv_begin<BLOCK>(IV, niv, tid);
+        if (LDSPOS) stage_vecs<LAYOUT, BLOCK>(spos, pos + (size_t)b * N * 3, N, N, tid);
+        stage_iv_end<LAYOUT, BLOCK>(siv, IV, niv, ivcap, tid, iv_first);
+        if (tid == 0) { s_ticket = BLOCK / 64; s_stage[0] = 0; s_stage[1] = 0; }
     }
-    const double iv_first = stage_iv_begin<BLOCK>(IV, niv, tid);
-    if (LDSPOS) stage_vecs<LAYOUT, BLOCK>(spos, P, N, N, tid);                  // coalesced read of the box, all loads in flight together
-    stage_iv_end<LAYOUT, BLOCK>(siv, IV, niv, ivcap, tid, iv_first);
-    if (tid == 0) s_ticket = BLOCK / 64;
     __syncthreads();
 
     const LdsVecs<LAYOUT> vpos{spos, N}, viv{siv, ivcap};
     auto getiv = [&](int k, double& x, double& y, double& z) { viv.get(k, x, y, z); };
-    auto getpos = [&](int j, double& x, double& y, double& z) {
-        if constexpr (LDSPOS) vpos.get(j, x, y, z);
-        else { const double* p = P + 3 * (size_t)j; x = p[0]; y = p[1]; z = p[2]; }
-    };
 
-    unsigned int np = 0, nt = 0;                         // directed in-range pairs, i-centred triplets of this lane's molecules
-    while (grp >= 0) {                                   // wave-uniform
-        int tk = 0;
-        if (lane == 0) tk = __hip_atomic_fetch_add(&s_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        tk = __builtin_amdgcn_readfirstlane(tk);
-        const int gnext = tk < G ? g0 + G - 1 - tk : -1;
-        const bool act = col != kNoColumn;
-        uint32_t col_next = kNoColumn;
-        int n_next = 0, mol_next = 0;
-        if (gnext >= 0) {                                                    // one group ahead, like the list chunks
-            const int tn = gnext * 64 + lane;
-            if (tn < a1) { col_next = (uint32_t)tn * 4u; n_next = NNS[tn]; mol_next = ORD[tn]; }
-        }
-        const int cm = __builtin_amdgcn_readfirstlane(CM[grp]);
-        AtomSum a = atom_energy<BLOCK, BATCH4>(rs, col, col_next, mol, act ? (n_cur & 0xff) : 0, cm & 0xff, cm >> 8, N, S,
-                                       queue, getpos, getiv, cur);
-        if (act) { np += (unsigned int)a.cnt; nt += (unsigned int)(a.cnt * (a.cnt - 1) / 2); }
-        const double ge = dpp_wave_sum(act ? a.e : 0.0);             // fixed tree; total in lane 63
-        if (lane == 63) gsum[grp - g0] = ge;
-        n_cur = n_next; mol = mol_next; col = col_next; grp = gnext;
-    }
+    for (int it = 0;; ++it) {                            // the workgroup's boxes
+        const int b = box0 + bi;
+        const bool more = bi + (int)gridDim.y < count;   // workgroup-uniform
+        const double* P  = pos + (size_t)b * N * 3;
+        const int* ORD = order + (size_t)b * N;
+        const int* NNS = nns + (size_t)b * N;
+        const int* CM = cmax + (size_t)b * ngroups;
+        auto getpos = [&](int j, double& x, double& y, double& z) {
+            if constexpr (LDSPOS) vpos.get(j, x, y, z);
+            else { const double* p = P + 3 * (size_t)j; x = p[0]; y = p[1]; z = p[2]; }
+        };
+        const ListRsrc rs = list_rsrc(list + (size_t)b * S * N, N, S);
 
-    const unsigned long long wp = wave_sum_u64(np), wt = wave_sum_u64(nt);
-    if (lane == 0) { red_p[wid] = wp; red_t[wid] = wt; }
-    __syncthreads();
-    if (tid == 0) {
-        double e = 0.0; unsigned long long p = 0, t = 0;
-        for (int k = 0; k < G; ++k) e += gsum[k];
-        for (int w = 0; w < BLOCK / 64; ++w) { p += red_p[w]; t += red_t[w]; }
-        if (nsplit == 1) {                               // one workgroup per box: model_energy(ils) and its counts directly
-            energy[b] = e; counts[2 * b] = p; counts[2 * b + 1] = t;
-        } else {                                         // a split box: k_sum_partials adds the partials in split order
-            const size_t o = (size_t)(b) * nsplit + split;
-            partial[o] = e; cpartial[2 * o] = p; cpartial[2 * o + 1] = t;
+        unsigned int np = 0, nt = 0;                     // directed in-range pairs, i-centred triplets of this lane's molecules
+        int grp = first_grp;
+        while (grp >= 0) {                               // wave-uniform
+            int tk = 0;
+            if (lane == 0) tk = __hip_atomic_fetch_add(&s_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            tk = __builtin_amdgcn_readfirstlane(tk);
+            const int gnext = tk < G ? g0 + G - 1 - tk : -1;
+            const bool act = col != kNoColumn;
+            uint32_t col_next = kNoColumn;
+            int n_next = 0, mol_next = 0;
+            if (gnext >= 0) {                                                    // one group ahead, like the list chunks
+                const int tn = gnext * 64 + lane;
+                if (tn < a1) { col_next = (uint32_t)tn * 4u; n_next = NNS[tn]; mol_next = ORD[tn]; }
+            }
+            const int cm = __builtin_amdgcn_readfirstlane(CM[grp]);
+            AtomSum a = atom_energy<BLOCK, BATCH4>(rs, col, col_next, mol, act ? (n_cur & 0xff) : 0, cm & 0xff, cm >> 8, N, S,
+                                           queue, getpos, getiv, cur);
+            if (act) { np += (unsigned int)a.cnt; nt += (unsigned int)(a.cnt * (a.cnt - 1) / 2); }
+            const double ge = dpp_wave_sum(act ? a.e : 0.0);             // fixed tree; total in lane 63
+            if (lane == 63) gsum[grp - g0] = ge;
+            n_cur = n_next; mol = mol_next; col = col_next; grp = gnext;
         }
+        const unsigned long long wp = wave_sum_u64(np), wt = wave_sum_u64(nt);
+        if (lane == 0) { red_p[wid] = wp; red_t[wid] = wt; }
+
+        // out of groups.  If the workgroup has another box: its first list reads, its image vectors, and as many staging
+        // tickets as fit in registers -- all in flight while the other wavefronts finish
+        const int bn = box0 + bi + (int)gridDim.y;
+        double hold[kStageHold][12], iv_next = 0.0;
+        int held[kStageHold];
+        int nivn = 0;
+#pragma unroll
+        for (int q = 0; q < kStageHold; ++q) held[q] = -1;
+        if (more) {
+            first_reads(bn);
+            nivn = nivect[bn];
+            iv_next = stage_iv_begin<BLOCK>(ivect + (size_t)bn * ivcap * 3, nivn, tid);
+            if constexpr (LDSPOS) {
+                const double* Pn = pos + (size_t)bn * N * 3;
+#pragma unroll
+                for (int q = 0; q < kStageHold; ++q) {
+                    int tk = 0;
+                    if (lane == 0) tk = __hip_atomic_fetch_add(&s_stage[it & 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    tk = __builtin_amdgcn_readfirstlane(tk);
+                    held[q] = tk < nstage ? tk : -1;
+                    if (held[q] >= 0) {                  // (the box's last ticket may read past its end: d_pos is padded by one ticket)
+                        const double* src = Pn + (size_t)held[q] * kStageTicket + lane;
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) hold[q][k] = src[k * 64];
+                    }
+                }
+            }
+        }
+        __syncthreads();                                 // the box is done: its sums are in LDS, its staged positions free
+        if (tid == 0) {
+            double e = 0.0; unsigned long long p = 0, t = 0;
+            for (int k = 0; k < G; ++k) e += gsum[k];
+            for (int w = 0; w < BLOCK / 64; ++w) { p += red_p[w]; t += red_t[w]; }
+            if (nsplit == 1) {                           // one workgroup per box: model_energy(ils) and its counts directly
+                energy[b] = e; counts[2 * b] = p; counts[2 * b + 1] = t;
+            } else {                                     // a split box: k_sum_partials adds the partials in split order
+                const size_t o = (size_t)(b) * nsplit + split;
+                partial[o] = e; cpartial[2 * o] = p; cpartial[2 * o + 1] = t;
+            }
+            s_ticket = BLOCK / 64;
+            s_stage[(it + 1) & 1] = 0;                   // (the counter of THIS box is still in use below)
+        }
+        if (!more) break;
+        stage_iv_end<LAYOUT, BLOCK>(siv, ivect + (size_t)bn * ivcap * 3, nivn, ivcap, tid, iv_next);
+        if constexpr (LDSPOS) {
+            const double* Pn = pos + (size_t)bn * N * 3;
+#pragma unroll
+            for (int q = 0; q < kStageHold; ++q) {
+                if (held[q] >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) {
+                        const int t = held[q] * kStageTicket + k * 64 + lane;
+                        if (t < 3 * N) spos[LdsVecs<LAYOUT>::slot(t, N)] = hold[q][k];
+                    }
+                }
+            }
+            for (;;) {                                   // tickets nobody had registers for (all wavefronts arrived together, or a large box)
+                int tk = 0;
+                if (lane == 0) tk = __hip_atomic_fetch_add(&s_stage[it & 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                tk = __builtin_amdgcn_readfirstlane(tk);
+                if (tk >= nstage) break;
+                double v[12];
+                const double* src = Pn + (size_t)tk * kStageTicket + lane;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) v[k] = src[k * 64];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) { const int t = tk * kStageTicket + k * 64 + lane; if (t < 3 * N) spos[LdsVecs<LAYOUT>::slot(t, N)] = v[k]; }
+            }
+        }
+        __syncthreads();
+        bi += (int)gridDim.y;
     }
 }
 

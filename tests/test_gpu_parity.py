@@ -118,6 +118,38 @@ def test_batched_walkers_match_single_box_results(c_oracle):
         em.energy_deinit()
 
 
+def test_persistent_workgroups_over_many_boxes(c_oracle):
+    """More boxes than compute units, and not a multiple of them: the full-box kernel's workgroups are persistent (each takes
+    every 256th box and reads its next box while the current one drains), so box k's energy must not depend on which
+    workgroup served it, on what it served before, or on the sub-range of boxes a launch covers.  Every box has its own
+    positions AND its own cell (image vectors are re-staged per box); the box is small, so a staging ticket of 768 doubles
+    runs past its end into the following boxes."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.energy import load_boxes
+    h0, x0 = lat.ice_box("ih", (3, 2, 2), 0.0)
+    nb = 600
+    rng = np.random.default_rng(11)
+    scales = 1.0 + 0.01 * rng.standard_normal(nb)
+    hs = [h0 * s for s in scales]
+    xs = [lat.thermalise(x0, 0.15, 500 + w) * scales[w] for w in range(nb)]
+    em = load_boxes(hs, xs)
+    try:
+        e_all = em.model_energy_batch(1, nb).copy()
+        check = [0, 1, 255, 256, 257, 511, 512, 599] + [int(k) for k in rng.integers(0, nb, 12)]
+        for w in check:
+            iv = c_oracle.ivects(hs[w])
+            nn, jn, vn = c_oracle.neighbours(xs[w], iv)
+            ref = c_oracle.model_energy(xs[w], iv, nn, jn, vn)
+            assert abs(e_all[w] - ref) <= RTOL * abs(ref), w
+        # the same boxes through other launch shapes: a sub-range that starts in the middle, and one box at a time
+        sub = em.model_energy_batch(201, 300)
+        assert np.array_equal(sub, e_all[200:500])
+        for w in (0, 256, 599):
+            assert em.model_energy_batch(w + 1, 1)[0] == pytest.approx(e_all[w], rel=1e-13)
+    finally:
+        em.energy_deinit()
+
+
 def _triclinic_box(reps, sigma, seed):
     from mc_water_ls_mw_amd import lattice as lat
     h, x = lat.ice_ic_cell(2.73)

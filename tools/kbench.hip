@@ -24,8 +24,8 @@ static void launch_me(int nboxes)
     const Geo ge = model_geo(nboxes);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_model_energy<true, 1024, LAYOUT, BATCH4>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget); attr = true; }
-    hipLaunchKernelGGL((mw::k_model_energy<true, 1024, LAYOUT, BATCH4>), dim3(ge.nsplit, nboxes), dim3(1024), ge.shmem, g.stream, g.d_pos, g.d_ivect,
-                       g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, 0, ge.nsplit, ge.chunk);
+    hipLaunchKernelGGL((mw::k_model_energy<true, 1024, LAYOUT, BATCH4>), dim3(ge.nsplit, ge.nsplit == 1 ? std::min(nboxes, g.cu) : nboxes), dim3(1024), ge.shmem, g.stream, g.d_pos, g.d_ivect,
+                       g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, 0, ge.nsplit, ge.chunk, nboxes);
 }
 
 template <int LAYOUT>
@@ -87,9 +87,9 @@ int main(int argc, char** argv)
         auto big = [&](bool batch) {
             const Geo ge = model_geo(W);
             if (batch) hipLaunchKernelGGL((mw::k_model_energy<false, 256, mw::kLayoutPair, true>), dim3(ge.nsplit, W), dim3(256), ge.shmem, g.stream, g.d_pos, g.d_ivect,
-                       g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, 0, ge.nsplit, ge.chunk);
+                       g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, 0, ge.nsplit, ge.chunk, W);
             else hipLaunchKernelGGL((mw::k_model_energy<false, 256, mw::kLayoutPair, false>), dim3(ge.nsplit, W), dim3(256), ge.shmem, g.stream, g.d_pos, g.d_ivect,
-                       g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, 0, ge.nsplit, ge.chunk);
+                       g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, 0, ge.nsplit, ge.chunk, W);
         };
         vs.push_back({"k_model_energy<global, slot at a time>", [=] { big(false); }, {}});
         vs.push_back({"k_model_energy<global, BATCH4>", [=] { big(true); }, {}});
