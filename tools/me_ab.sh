@@ -1,5 +1,5 @@
 #!/bin/bash
-# k_model_energy A/B on one box: persistent workgroups (default) against one workgroup per box (MW_MODEL_PERSIST=0).
+# k_model_energy A/B on one box (same binary): persistent workgroups (default) against one workgroup per box (MW_MODEL_PERSIST=0).
 cd "$(dirname "$0")/.."
 for r in 1 2 3; do
 for v in 1 0; do
