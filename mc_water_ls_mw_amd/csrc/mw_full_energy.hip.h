@@ -280,7 +280,7 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
 
     for (int it = 0;; ++it) {                            // the workgroup's boxes
         const int b = box0 + bi;
-        const bool more = bi + (int)gridDim.y < count;   // workgroup-uniform
+        const bool more = LDSPOS && bi + (int)gridDim.y < count;   // workgroup-uniform (boxes gathered through L2 are launched one per workgroup)
         const double* P  = pos + (size_t)b * N * 3;
         const int* ORD = order + (size_t)b * N;
         const int* NNS = nns + (size_t)b * N;
