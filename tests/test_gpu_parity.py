@@ -376,3 +376,52 @@ def test_concurrent_host_threads_are_serialised(c_oracle):
             assert np.array_equal(got[ils], np.broadcast_to(want[ils], (6, 48)))
     finally:
         em.energy_deinit()
+
+
+_SINGLE_CALL_SCRIPT = """
+import json, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from conftest import load_golden
+from mc_water_ls_mw_amd.energy import load_boxes
+z1, z2 = load_golden("ic48_t015"), load_golden("ih48_t020")
+em = load_boxes([z1["h"], z2["h"]], [z1["xyz"], z2["xyz"]])
+rng = np.random.default_rng(5)
+out = []
+for step in range(300):                       # the caller's pattern: move a molecule on the host, ask, sometimes put it back
+    ils, i = int(rng.integers(1, 3)), int(rng.integers(1, 49))
+    old = em.ljr[ils - 1, i - 1].copy()
+    em.ljr[ils - 1, i - 1] += rng.normal(0, 0.3, 3)
+    out.append(em.compute_local_real_energy(i, ils))
+    if step % 3 == 0:
+        em.ljr[ils - 1, i - 1] = old          # silent revert (mc_moves.F90:1186)
+    if step % 50 == 49:
+        em.compute_model_energy(ils)          # an exclusive entry: stops and restarts the resident server
+        out.append(float(em.model_energy[ils - 1]))
+em.energy_deinit()
+print(json.dumps([float(v).hex() for v in out]))
+"""
+
+
+def test_single_call_paths_agree(tmp_path):
+    """The drop-in single call has three transports -- request lines in device memory (default where the host can address
+    it), request lines in host-mapped memory (MW_SERVER_REQ=host), one kernel launch per call (MW_LOCAL_SERVER=0).  The
+    same sequence of host-side moves, reverts and calls must return the same bits through the two server transports and
+    the same numbers (another summation order, 1e-12) through the launch path."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "calls.py"
+    script.write_text(_SINGLE_CALL_SCRIPT.format(root=ROOT, tests=os.path.join(ROOT, "tests")))
+    results = {}
+    for name, env in (("device", {"MW_SERVER_REQ": "device"}), ("host", {"MW_SERVER_REQ": "host"}), ("launch", {"MW_LOCAL_SERVER": "0"})):
+        out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert out.returncode == 0, out.stderr[-2000:]
+        results[name] = json.loads(out.stdout.strip().splitlines()[-1])
+    assert len(results["device"]) == 306
+    assert results["device"] == results["host"]                          # the same kernel behind both transports: the same bits
+    dev = np.array([float.fromhex(v) for v in results["device"]])
+    lau = np.array([float.fromhex(v) for v in results["launch"]])         # another evaluation order (plain routine): last-bit differences
+    assert np.all(np.abs(dev - lau) <= 1e-12 * np.abs(dev))
