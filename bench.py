@@ -341,7 +341,8 @@ def main():
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         try:
             if args.backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                        pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=True))   # (see WalkerComms: the exchange must not queue behind the engine's kernels)
             else:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
         except Exception as err:                      # noqa: BLE001  (N = 1 only: the bench still measures the kernels)
@@ -385,12 +386,9 @@ def main():
     weight, hist, uhist = np.zeros(NBINS), np.zeros(NBINS), np.zeros(NBINS)
 
     def step(k, timed):
-        if timed and k < 2000:
-            em.timer_start(2 * k); em.model_energy_launch(1, W); em.timer_stop(2 * k)
-            em.timer_start(2 * k + 1); em.moves_launch(); em.timer_stop(2 * k + 1)
-        else:
-            em.model_energy_launch(1, W)
-            em.moves_launch()
+        # one host call per step: full-box energies of all walkers, then their trial moves (timed steps: with the engine's
+        # HIP events around each kernel, on the engine's stream)
+        em.step_launch(1, W, 2 * k if (timed and k < 2000) else -1)
         if exchange:
             hist[(k * 7 + rank) % NBINS] += 1.0
             weight[(k * 7 + rank) % NBINS] += 0.05

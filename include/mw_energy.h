@@ -133,6 +133,12 @@ int mw_moves_fetch(double *e_old, double *e_new);
  * (nn(i) + sum of nn(j) over in-range j), which prices the call's algorithmic bytes. */
 int mw_moves_counts(long long out[4]);
 int mw_model_energy_launch(int first_ils, int count);
+/* Both launches of a step in one host call: the full-box energies of boxes first_ils .. first_ils+count-1, then the staged
+ * moves (mw_model_energy_launch + mw_moves_launch).  timer_slot >= 0 brackets them with the engine's event timers:
+ * slot timer_slot around the full-box kernel, timer_slot + 1 around the move kernels (read with mw_timer_elapsed_ms).
+ * A step whose kernels take ~1.4 ms is otherwise preceded by six host calls, and a host that waits for an exchange
+ * between steps (as the walker farm does) cannot issue them ahead. */
+int mw_step_launch(int first_ils, int count, int timer_slot);
 int mw_model_energy_fetch(int first_ils, int count, double *e_out);
 int mw_build_neighbours_launch(int first_ils, int count);
 int mw_sync(void);

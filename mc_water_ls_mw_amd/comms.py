@@ -39,6 +39,10 @@ class WalkerComms:
         self._buf = torch.zeros(3 * self.nbins, dtype=torch.float64, device=self.device)
         self._stage = torch.zeros(3 * self.nbins, dtype=torch.float64,
                                   pin_memory=self.device.type == "cuda")
+        # The exchange has a HIP stream of its own, at high priority: its copies and the collective are a few microseconds
+        # of work, and queued behind a millisecond kernel of the engine on the default priority they would start only
+        # when that kernel ends -- the host, which waits for the result, could then not issue the next step ahead.
+        self._stream = torch.cuda.Stream(device=self.device, priority=-1) if self.device.type == "cuda" else None
 
     @property
     def world_size(self):
@@ -56,9 +60,16 @@ class WalkerComms:
         # (with a process group the collective is issued even for one rank: N = 1 and N = 8 run the same code)
         self._stage[:n].copy_(torch.from_numpy(np.ascontiguousarray(delta, dtype=np.float64)))
         buf = self._buf[:n]
-        buf.copy_(self._stage[:n], non_blocking=True)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-        self._stage[:n].copy_(buf)   # synchronising D2H
+        if self._stream is None:
+            buf.copy_(self._stage[:n])
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            self._stage[:n].copy_(buf)
+        else:
+            with torch.cuda.stream(self._stream):
+                buf.copy_(self._stage[:n], non_blocking=True)
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                self._stage[:n].copy_(buf, non_blocking=True)
+            self._stream.synchronize()
         return self._stage[:n].numpy().copy()
 
     def _delta_sync(self, arr, last):

@@ -128,7 +128,8 @@ struct Ctx {
     double *d_mtrial = nullptr, *d_meold = nullptr, *d_menew = nullptr;
     unsigned int* d_mcnt = nullptr;
     int* d_mperm = nullptr;        // sorted request -> caller's index
-    int* d_mdecl = nullptr;        // [0] count, then {request, box} of the requests k_move_energy left to k_move_fallback
+    int* d_mdecl = nullptr;        // [0], [1] counts (alternate launches), then {request, box} of the requests k_move_energy left to k_move_fallback
+    int mdecl_par = 0;             // which count word the next launch uses (the fallback kernel zeroes the other)
     int4* d_mwork = nullptr;       // work items {box, begin, end, 0}
     int mwork_cap = 0, mwork_n = 0;
     bool mlds = false;
@@ -327,7 +328,9 @@ int ensure_moves(int n)
     HIPCHK(hipMalloc(&g.d_menew, sizeof(double) * cap));
     HIPCHK(hipMalloc(&g.d_mcnt, sizeof(unsigned int) * 4 * cap));
     HIPCHK(hipMalloc(&g.d_mperm, sizeof(int) * cap));
-    HIPCHK(hipMalloc(&g.d_mdecl, sizeof(int) * (2 * (size_t)cap + 1)));
+    HIPCHK(hipMalloc(&g.d_mdecl, sizeof(int) * (2 * (size_t)cap + 2)));
+    HIPCHK(hipMemset(g.d_mdecl, 0, 2 * sizeof(int)));
+    g.mdecl_par = 0;
     g.mcap = cap;
     return 0;
 }
@@ -1152,25 +1155,26 @@ static int launch_moves(int mode)
 {
     if (g.mn == 0) return 0;
     const size_t iv_bytes = kMoveScratch + mw::lds_vec_bytes((size_t)g.ivcap);
-    HIPCHK(hipMemsetAsync(g.d_mdecl, 0, sizeof(int), g.stream));           // nothing declined yet
+    const int kmode = mode | (g.mdecl_par << 2);                          // this launch's count word of the declined list (zeroed by the
+    g.mdecl_par ^= 1;                                                     // previous launch's k_move_fallback, or at allocation)
     if (g.mlds && g.m_noself)
         hipLaunchKernelGGL((mw::k_move_energy<true, mw::kLayoutSoA, false>), dim3(g.mwork_n), dim3(1024),
                            iv_bytes + mw::lds_vec_bytes((size_t)g.N) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
-                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, mode);
+                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode);
     else if (g.mlds)
         hipLaunchKernelGGL(mw::k_move_energy<true>, dim3(g.mwork_n), dim3(1024),
                            iv_bytes + mw::lds_vec_bytes((size_t)g.N) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
-                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, mode);
+                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode);
     else
         hipLaunchKernelGGL(mw::k_move_energy<false>, dim3(g.mwork_n), dim3(1024), iv_bytes, g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
-                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, mode);
+                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode);
     HIPCHK(hipGetLastError());
     // the requests the fused routine declined (none on ice): plain routine, one wavefront each
     hipLaunchKernelGGL(mw::k_move_fallback, dim3(std::min(1024, (g.mn + 3) / 4)), dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_listm, g.d_nn,
-                       g.d_mimol, g.d_mtrial, g.d_mperm, g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, mode);
+                       g.d_mimol, g.d_mtrial, g.d_mperm, g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode);
     HIPCHK(hipGetLastError());
     g.mmode = mode;
     return 0;
@@ -1181,6 +1185,24 @@ int mw_moves_launch(void)
     MW_LOCK;
     if (check_live()) return 1;
     return launch_moves(3);
+}
+
+int mw_step_launch(int first_ils, int count, int timer_slot)
+{
+    MW_LOCK;
+    if (check_live() || check_range(first_ils, count)) return 1;
+    const bool timed = timer_slot >= 0;
+    if (timed) {
+        if (timer_slot + 1 >= kTimerSlots) return fail("mw_step_launch: timer slot %d outside 0..%d", timer_slot, kTimerSlots - 2);
+        for (int s = timer_slot; s <= timer_slot + 1; ++s)
+            if (!g.ev[s][0]) { HIPCHK(hipEventCreate(&g.ev[s][0])); HIPCHK(hipEventCreate(&g.ev[s][1])); }
+        HIPCHK(hipEventRecord(g.ev[timer_slot][0], g.stream));
+    }
+    if (launch_model_energy(first_ils, count)) return 1;
+    if (timed) { HIPCHK(hipEventRecord(g.ev[timer_slot][1], g.stream)); HIPCHK(hipEventRecord(g.ev[timer_slot + 1][0], g.stream)); }
+    if (launch_moves(3)) return 1;
+    if (timed) HIPCHK(hipEventRecord(g.ev[timer_slot + 1][1], g.stream));
+    return 0;
 }
 
 int mw_moves_fetch(double* e_old, double* e_new)

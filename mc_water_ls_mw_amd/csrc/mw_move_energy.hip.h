@@ -538,7 +538,8 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
                    const int* __restrict__ perm,
                    double* __restrict__ e_old, double* __restrict__ e_new,
                    unsigned int* __restrict__ counts,   // [nreq][4]: inter_old, slots_old, inter_new, slots_new
-                   int* __restrict__ declined,          // [0] = number of requests left to k_move_fallback, then {request, box} pairs
+                   int* __restrict__ declined,          // [0], [1] = number of requests left to k_move_fallback (the word of this launch's parity,
+                                                        // mode bit 2), then {request, box} pairs
                    int N, int ivcap, int mode)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -631,8 +632,8 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
             // inlined here its registers counted against this loop (37 scalar registers spilled to vector lanes, ~30
             // vector instructions per request on moving them), and calling it out of line costs scratch (+8 % time)
             if (lane == 0) {
-                const int k = atomicAdd(&declined[0], 1);
-                declined[1 + 2 * k] = m; declined[2 + 2 * k] = b;
+                const int k = atomicAdd(&declined[(mode >> 2) & 1], 1);
+                declined[2 + 2 * k] = m; declined[3 + 2 * k] = b;
             }
         } else if (lane == 0) {
             const size_t o = (size_t)perm[m];
@@ -645,18 +646,22 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
 
 // The requests k_move_energy declined, one wavefront each with the plain routine (positions and rows from global memory).
 //   grid = any, block = 256; exits at once when nothing was declined
+// The list has two count words used by alternate launches (mode bit 2): this kernel zeroes the OTHER one, which the next
+// launch's k_move_energy will count in -- a memset per launch (a fill kernel and its dispatch gap, ~10 us) is saved.
 __global__ __launch_bounds__(256)
 void k_move_fallback(const double* __restrict__ pos, const double* __restrict__ ivect,
                      const uint32_t* __restrict__ listm, const int* __restrict__ nn,
                      const int* __restrict__ req_imol, const double* __restrict__ req_trial, const int* __restrict__ perm,
                      double* __restrict__ e_old, double* __restrict__ e_new, unsigned int* __restrict__ counts,
-                     const int* __restrict__ declined, int N, int ivcap, int mode)
+                     int* __restrict__ declined, int N, int ivcap, int mode)
 {
-    const int n = declined[0];
+    const int par = (mode >> 2) & 1;
+    const int n = declined[par];
+    if (blockIdx.x == 0 && threadIdx.x == 0) declined[par ^ 1] = 0;
     const int lane = threadIdx.x & 63;
     const int wave = (int)(blockIdx.x * (blockDim.x >> 6)) + (int)(threadIdx.x >> 6), nwaves = (int)(gridDim.x * (blockDim.x >> 6));
     for (int k = wave; k < n; k += nwaves) {
-        const int m = declined[1 + 2 * k], b = declined[2 + 2 * k];
+        const int m = declined[2 + 2 * k], b = declined[3 + 2 * k];
         const double* P  = pos + (size_t)b * N * 3;
         const double* IV = ivect + (size_t)b * ivcap * 3;
         const uint32_t* LM = listm + (size_t)b * N * kRow;

@@ -42,7 +42,7 @@ ABI_SYMBOLS = (
     "mw_model_energy_counts_total", "mw_neighbour_total",
     "mw_local_energy", "mw_local_energy_patched", "mw_local_energy_batch", "mw_delta_energy_batch",
     "mw_moves_upload", "mw_moves_launch", "mw_moves_fetch", "mw_moves_counts",
-    "mw_model_energy_launch", "mw_model_energy_fetch", "mw_build_neighbours_launch", "mw_sync",
+    "mw_model_energy_launch", "mw_step_launch", "mw_model_energy_fetch", "mw_build_neighbours_launch", "mw_sync",
     "mw_timer_start", "mw_timer_stop", "mw_timer_elapsed_ms", "mw_device_info",
     "mw_sweep_configure", "mw_set_model_energy", "mw_sweep_set_state", "mw_sweep_get_state",
     "mw_sweep_translation", "mw_sweep_translation_launch",
@@ -348,6 +348,11 @@ class EnergyModule:
 
     def model_energy_launch(self, first_ils, count):
         self._chk(self.L.mw_model_energy_launch(first_ils, count))
+
+    def step_launch(self, first_ils, count, timer_slot=-1):
+        """model_energy_launch + moves_launch in one host call; timer_slot >= 0: event timers timer_slot (full-box
+        kernel) and timer_slot + 1 (move kernels)."""
+        self._chk(self.L.mw_step_launch(first_ils, count, timer_slot))
 
     def model_energy_fetch(self, first_ils, count):
         out = np.zeros(count)

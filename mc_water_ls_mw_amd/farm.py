@@ -330,7 +330,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
+                                    pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=True))   # (see WalkerComms: the exchange must not queue behind the engine's kernels)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
