@@ -179,14 +179,17 @@ def kernel_roofline(name, alg_bytes, avg_ms, units, counters, copy_gbs):
     c = counters.get(name)
     if c:
         cyc = c["GRBM_GUI_ACTIVE"] / 8.0                        # the counter sums the 8 XCDs
+        cpu_ = counters.get("cycles_per_us")                    # shader clock during the counter passes (from the long kernel)
+        cyc_valu = c["dur_us_sq1"] * cpu_ if cpu_ and "dur_us_sq1" in c else cyc     # the launch's cycles in the pass that
+        cyc_lds = c["dur_us_sq2"] * cpu_ if cpu_ and "dur_us_sq2" in c else cyc      # counted VALU / LDS activity
         r["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
         if r["traffic"] is not None:
             r["hbm_traffic_frac"] = r["traffic"] / (c["avg_us"] * 1e-6) / (HBM_PEAK_GBS * 1e9)
-        busy = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * cyc)
+        busy = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * cyc_valu)
         r["valu"] = {"busy": busy, "insts_per_unit": c["SQ_INSTS_VALU"] * 64.0 / units,
                      "wave_insts_per_s": c["SQ_INSTS_VALU"] / (c["avg_us"] * 1e-6), "peak_wave_insts_per_s_f64": VALU_F64_PEAK,
                      "unit_of_work": "molecule" if name == "k_model_energy" else "trial move (old + new)"}
-        r["lds_busy"] = c["SQ_LDS_IDX_ACTIVE"] / (CUS * cyc) if "SQ_LDS_IDX_ACTIVE" in c else None
+        r["lds_busy"] = c["SQ_LDS_IDX_ACTIVE"] / (CUS * cyc_lds) if "SQ_LDS_IDX_ACTIVE" in c else None
         ceilings = {"valu": busy, "lds": r["lds_busy"] or 0.0, "hbm": r["hbm_traffic_frac"] or 0.0}
         r["bound"] = max(ceilings, key=ceilings.get)
         r["counters_tag"] = counters.get("tag")

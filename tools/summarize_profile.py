@@ -26,9 +26,13 @@ for name in ("fetch", "write", "sq1", "sq2"):
     path = os.path.join(src, f"pmc_{name}", f"{name}_counter_collection.csv")
     if not os.path.exists(path):
         continue
+    seen = set()
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if name in ("sq1", "sq2") and r["Dispatch_Id"] not in seen:     # the launch's duration IN THIS PASS (counters slow it)
+            seen.add(r["Dispatch_Id"])
+            pmc[k][f"dur_us_{name}"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
 W, M = bench["config"]["walkers_per_gpu"], bench["config"]["moves_per_walker"]
 traffic = {"walkers": W, "moves": M, "tag": tag}
@@ -71,6 +75,12 @@ for k, cs in sorted(pmc.items()):
         counters[short] = rec
     for c, v in sorted(rec.items()):
         sq_lines.append(f"{k:48s} {c:24s} {v:.6g}")
+# shader cycles per microsecond, from the long kernel (GRBM_GUI_ACTIVE sums the 8 XCDs; both in the sq2 pass).  Cycle counts
+# of a kernel in a pass = its duration in that pass x this clock: GRBM_GUI_ACTIVE itself over-counts short kernels (a
+# persistent k_model_energy launch reads 25 % more "cycles" than its duration allows at the 2.4 GHz ceiling).
+mv = counters.get("k_move_energy", {})
+if "GRBM_GUI_ACTIVE" in mv and "dur_us_sq2" in mv:
+    counters["cycles_per_us"] = mv["GRBM_GUI_ACTIVE"] / 8.0 / mv["dur_us_sq2"]
 json.dump(counters, open(os.path.join(dst, "counters.json"), "w"), indent=1)
 open(os.path.join(dst, f"{tag}_pmc_counters.txt"), "w").write("\n".join(sq_lines) + "\n")
 print("\n".join(lines[:12]))
