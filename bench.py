@@ -168,37 +168,61 @@ def load_counters(W, M):
 
 
 def kernel_roofline(name, alg_bytes, avg_ms, units, counters, copy_gbs):
-    """SURVEY.md 8(d) convention (`achieved` = algorithmic bytes / launch time, against 8 TB/s) next to what the
-    counters say binds: VALU issue, LDS, or HBM traffic (each as a fraction of its own ceiling)."""
+    """The roofline block of one kernel.  `bound` names the ceiling the counters say binds -- FP64 VALU issue, the LDS
+    pipe, or HBM traffic, each as a fraction of its own ceiling -- and `achieved / peak / frac` are measured against THAT
+    ceiling, so `frac` cannot exceed 1:
+      valu: wave64 vector instructions per second (SQ_INSTS_VALU of this binary on this workload -- exact and the same in
+            every launch -- over the LIVE average launch time) against 1024 SIMDs x 2.4 GHz / 4 cycles per FP64 instruction;
+      hbm:  counter traffic (2 FETCH_SIZE + WRITE_SIZE) x 1024 bytes per launch over the live launch time against 8 TB/s;
+      lds:  SQ_LDS_IDX_ACTIVE cycles against the launch's cycles.
+    The SURVEY.md 8(d) convention (algorithmic bytes per launch / launch time against 8 TB/s) stays in the line as
+    `algorithmic_GBps` / `convention_frac`: for kernels that serve their operands from LDS it is a throughput
+    normalisation and can exceed 1, it says nothing about HBM."""
     sec = avg_ms * 1e-3
-    ach = alg_bytes / sec / 1e9
-    r = {"kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
-         "convention": "achieved = SURVEY.md 8(d) algorithmic bytes per launch / launch time; NOT the kernel's HBM traffic",
-         "traffic": None, "hbm_traffic_frac": None, "bound": None}
+    alg = alg_bytes / sec / 1e9
+    r = {"kernel": name, "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+         "algorithmic_GBps": alg, "convention_frac": alg / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
+         "avg_launch_ms": avg_ms,
+         "convention": "algorithmic_GBps = SURVEY.md 8(d) algorithmic bytes per launch / launch time; NOT the kernel's HBM traffic",
+         "hbm_traffic_frac": None}
     c = counters.get(name)
     if c:
-        cyc = c["GRBM_GUI_ACTIVE"] / 8.0                        # the counter sums the 8 XCDs
+        cyc_grbm = c["GRBM_GUI_ACTIVE"] / 8.0                   # the counter sums the 8 XCDs; over-counts sub-0.3-ms launches
         cpu_ = counters.get("cycles_per_us")                    # shader clock during the counter passes (from the long kernel)
-        cyc_valu = c["dur_us_sq1"] * cpu_ if cpu_ and "dur_us_sq1" in c else cyc     # the launch's cycles in the pass that
-        cyc_lds = c["dur_us_sq2"] * cpu_ if cpu_ and "dur_us_sq2" in c else cyc      # counted VALU / LDS activity
+        cyc_valu = c["dur_us_sq1"] * cpu_ if cpu_ and "dur_us_sq1" in c else cyc_grbm     # the launch's cycles in the pass that
+        cyc_lds = c["dur_us_sq2"] * cpu_ if cpu_ and "dur_us_sq2" in c else cyc_grbm      # counted VALU / LDS activity
         r["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
         if r["traffic"] is not None:
-            r["hbm_traffic_frac"] = r["traffic"] / (c["avg_us"] * 1e-6) / (HBM_PEAK_GBS * 1e9)
+            r["hbm_traffic_frac"] = r["traffic"] / sec / (HBM_PEAK_GBS * 1e9)
         busy = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * cyc_valu)
-        r["valu"] = {"busy": busy, "insts_per_unit": c["SQ_INSTS_VALU"] * 64.0 / units,
-                     "wave_insts_per_s": c["SQ_INSTS_VALU"] / (c["avg_us"] * 1e-6), "peak_wave_insts_per_s_f64": VALU_F64_PEAK,
+        issue = c["SQ_INSTS_VALU"] / sec                        # wave64 instructions per second at the LIVE launch time
+        r["valu"] = {"busy_duration": busy, "busy_grbm": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * cyc_grbm),
+                     "insts_per_unit": c["SQ_INSTS_VALU"] * 64.0 / units, "wave_insts_per_launch": c["SQ_INSTS_VALU"],
+                     "wave_insts_per_s": issue, "peak_wave_insts_per_s_f64": VALU_F64_PEAK,
                      "unit_of_work": "molecule" if name == "k_model_energy" else "trial move (old + new)"}
-        r["lds_busy"] = c["SQ_LDS_IDX_ACTIVE"] / (CUS * cyc_lds) if "SQ_LDS_IDX_ACTIVE" in c else None
-        ceilings = {"valu": busy, "lds": r["lds_busy"] or 0.0, "hbm": r["hbm_traffic_frac"] or 0.0}
+        lds_d = c["SQ_LDS_IDX_ACTIVE"] / (CUS * cyc_lds) if "SQ_LDS_IDX_ACTIVE" in c else None
+        r["lds"] = {"busy_duration": lds_d, "busy_grbm": c["SQ_LDS_IDX_ACTIVE"] / (CUS * cyc_grbm) if "SQ_LDS_IDX_ACTIVE" in c else None,
+                    "bank_conflict_share": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+                    if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE") else None}
+        ceilings = {"valu": busy, "lds": lds_d or 0.0, "hbm": r["hbm_traffic_frac"] or 0.0}
         r["bound"] = max(ceilings, key=ceilings.get)
+        if r["bound"] == "valu":
+            r["achieved"], r["peak"], r["unit"] = issue / 1e9, VALU_F64_PEAK / 1e9, "G wave64-instructions/s (FP64 VALU issue)"
+        elif r["bound"] == "hbm":
+            r["achieved"], r["peak"], r["unit"] = r["traffic"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            r["achieved"], r["peak"], r["unit"] = lds_d, 1.0, "LDS pipe busy (SQ_LDS_IDX_ACTIVE / CU cycles)"
+        r["frac"] = r["achieved"] / r["peak"]
         r["counters_tag"] = counters.get("tag")
-    elif copy_gbs and ach > copy_gbs:
-        r["bound"] = "not hbm: the algorithmic rate exceeds this box's measured copy ceiling (operands served from LDS / L2)"
+        r["counters_note"] = "instruction / byte counts per launch from profiles/counters.json (rocprofv3 --pmc passes of this binary on this configuration); launch time measured live"
     else:
-        r["bound"] = "unknown: no counter summary for this configuration under profiles/"
+        # no counter summary for this configuration: nothing says what binds, so no ceiling is claimed (frac stays null);
+        # the SURVEY.md 8(d) convention is in algorithmic_GBps / convention_frac
+        r["bound"] = ("unknown: no counter summary for this configuration under profiles/"
+                      + ("; not hbm -- the algorithmic rate exceeds this box's measured copy ceiling (operands served from LDS / L2)"
+                         if copy_gbs and alg > copy_gbs else ""))
+        r["achieved"], r["peak"], r["unit"] = alg, HBM_PEAK_GBS, "GB/s (SURVEY.md 8(d) convention, not traffic)"
     r["measured_copy_GBps"] = copy_gbs
-    r["frac_of_measured_copy"] = ach / copy_gbs if copy_gbs else None
     return r
 
 
@@ -281,6 +305,36 @@ def secondary_measurements(device):
     return out
 
 
+def self_launch(n, json_fd):
+    """`python bench.py --gpus N` without a launcher: start N children of this script, one rank per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (the environment torch.distributed.run would give
+    them), relay rank 0's ONE JSON line and return the worst exit status.  Called before anything in this process has
+    touched the GPU; the children are ordinary child processes (no exec from a process that holds the device)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.strip()]
+    if any(codes):
+        sys.stderr.write(f"bench.py --gpus {n}: rank exit codes {codes}\n")
+        return max((c if c > 0 else 1) for c in codes if c)
+    if len(lines) != 1:
+        sys.stderr.write(f"bench.py --gpus {n}: rank 0 printed {len(lines)} lines instead of one\n")
+        return 1
+    os.write(json_fd, (lines[0] + "\n").encode())
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -316,18 +370,28 @@ def main():
         h, xs = make_walkers(0, 1, args.sigma)
         emit(cpu_baseline(h, xs[0], args.moves, args.cpu_budget))
         return
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    # Rank / size bootstrap (what comms_initialise does with MPI_Comm_rank / _size, comms_mpi.f90:26-71): the launcher's
+    # environment if there is one -- it must then agree with --gpus -- otherwise this process IS the launcher.
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:                     # nothing here has touched the GPU (torch is not even imported yet)
+            raise SystemExit(self_launch(args.gpus, json_fd))
+        world = 1
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                             f"(python bench.py --gpus {args.gpus} launches them itself when WORLD_SIZE is unset)")
     all_cores = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:
         all_cores = cpu_all_cores(args)       # before this process initialises the GPU
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
     if args.share_device:
@@ -364,12 +428,8 @@ def main():
         em.hmatrix[b] = h
         em.ljr[b] = xs[b]
     # untimed set-up: mirror cells + positions, build every walker's Verlet list on the GPU
-    em._chk(em.L.mw_init(em.device, em.nwater, em.num_lattices, em.maxneigh))
-    em._live = True
     t_setup = time.perf_counter()
-    for b in range(1, W + 1):
-        em.compute_ivects(b)
-        em._upload(b)
+    em.setup_boxes()                                    # cells + positions of all walkers: a handful of transfers
     em.timer_start(4000)
     mn, mx = em.build_neighbours_batch(1, W)
     em.timer_stop(4000)
@@ -381,6 +441,12 @@ def main():
     trial = np.empty((W * M, 3))
     for b in range(W):
         imol[b * M:(b + 1) * M], trial[b * M:(b + 1) * M] = lat.trial_moves(xs[b], M, seed=1 + rank * W + b)
+    gold_path = os.path.join(ROOT, "tests", "golden", "ih4096_t015.npz")
+    gold = np.load(gold_path) if (rank == 0 and args.sigma == 0.15 and os.path.exists(gold_path)) else None
+    n_gold = 0
+    if gold is not None:        # walker 0 IS the fixture's configuration: its first moves are the fixture's trial moves
+        n_gold = min(M, len(gold["trial_imol"]))
+        imol[:n_gold], trial[:n_gold] = gold["trial_imol"][:n_gold], gold["trial_xyz"][:n_gold]
     em.moves_upload(ils, imol, trial)
     t_setup = time.perf_counter() - t_setup
 
@@ -442,6 +508,13 @@ def main():
     ms_full = float(np.mean([em.timer_ms(2 * k) for k in range(nk)]))
     ms_moves = float(np.mean([em.timer_ms(2 * k + 1) for k in range(nk)]))
     e_walker0 = em.model_energy_fetch(1, 1)[0]
+    moves_err = None
+    if gold is not None and n_gold:    # what the LAST timed k_move_energy launch left on the device, against the reference's values
+        eo, en = em.moves_fetch()
+        moves_err = float(max(np.max(np.abs(eo[:n_gold] - gold["trial_old"][:n_gold]) / np.abs(gold["trial_old"][:n_gold])),
+                              np.max(np.abs(en[:n_gold] - gold["trial_new"][:n_gold]) / np.abs(gold["trial_new"][:n_gold]))))
+        if not moves_err <= 1e-10:
+            raise SystemExit(f"walker 0: old/new local energies of the timed move kernel differ from the golden vector (max rel {moves_err:.3e})")
     name, cus, mem = em.device_info()
 
     # the ceiling a plain device-to-device copy reaches on this box (report against nominal AND this)
@@ -461,9 +534,8 @@ def main():
 
     if rank == 0:
         sanity = None
-        gold = os.path.join(ROOT, "tests", "golden", "ih4096_t015.npz")
-        if os.path.exists(gold) and args.sigma == 0.15:
-            ref = float(np.load(gold)["model_energy"])
+        if gold is not None:
+            ref = float(gold["model_energy"])
             sanity = abs(e_walker0 - ref) / abs(ref)
             if sanity > 1e-10:
                 raise SystemExit(f"walker 0 energy {e_walker0!r} differs from the golden vector {ref!r}")
@@ -507,6 +579,7 @@ def main():
             },
             "device": {"name": name, "compute_units": cus, "hbm_bytes": mem},
             "walker0_rel_err_vs_golden": sanity,
+            "walker0_moves_max_rel_err": moves_err, "walker0_moves_checked": n_gold,
             "setup_s": t_setup,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -60,6 +60,10 @@ int mw_constants(double out[8]);
  * 9 doubles, column k = cell vector k), rebuild the image vectors and mirror
  * them on the device.  *nivect_out (may be NULL) receives nivect(ils). */
 int mw_set_cell(int ils, const double h[9], int *nivect_out);
+/* The same for `count` consecutive boxes in one call: h = count x 9 doubles, nivect_out (may be NULL) = count ints.
+ * One host-to-device transfer per mirrored array for the whole range (energy_init's loop over lattices,
+ * molint.F90:122-136, for a farm of thousands of boxes). */
+int mw_set_cells_range(int first_ils, int count, const double *h, int *nivect_out);
 /* Copy out ivect(:,1:nivect,ils) (3 doubles each); returns nivect via *nivect_out. */
 int mw_get_ivects(int ils, double *out, int max_vectors, int *nivect_out);
 

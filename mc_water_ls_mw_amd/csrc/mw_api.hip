@@ -726,38 +726,63 @@ int mw_device_info(char* name, int name_len, int* compute_units, long long* glob
     return 0;
 }
 
+// Cells of `count` consecutive boxes in one go: image vectors (compute_ivects, molint.F90:174-217), volume, grid
+// descriptors on the host, then ONE copy per device array for the whole range (a farm of thousands of walkers sets up
+// in a handful of transfers instead of seven per box).
+static int set_cells_impl(int first_ils, int count, const double* h, int* nivect_out)
+{
+    std::vector<std::vector<double>> ivs((size_t)count);
+    std::vector<int> ns((size_t)count), imvs((size_t)count * 3);
+    int need = 0;
+    for (int k = 0; k < count; ++k) {
+        int imv[3] = {1, 1, 1};
+        const int n = host_ivects(h + 9 * (size_t)k, ivs[k], imv);
+        if (n < 0) return fail("mw_set_cell: cell of box %d is so small that it needs more than %d image vectors", first_ils + k, MW_MAX_IVECT);
+        ns[k] = n; imvs[3 * k] = imv[0]; imvs[3 * k + 1] = imv[1]; imvs[3 * k + 2] = imv[2];
+        need = std::max(need, n);
+    }
+    if (need > g.ivcap && grow_ivcap(need)) return 1;
+    std::vector<double> vol((size_t)count);
+    const size_t b0 = (size_t)(first_ils - 1);
+    for (int k = 0; k < count; ++k) {
+        const size_t off = (b0 + k) * g.ivcap * 3;
+        std::memcpy(&g.h_ivect[off], ivs[k].data(), ivs[k].size() * sizeof(double));
+        g.h_nivect[b0 + k] = ns[k];
+        // volume(ils) = |det hmatrix(:,:,ils)| as util_determinant expands it (util.f90:16-41; molint.F90:125)
+        const double* m = h + 9 * (size_t)k;   // m[(c-1)*3 + (r-1)] = hmatrix(r,c)
+        double det = m[0] * (m[4] * m[8] - m[7] * m[5]);
+        det = det - m[3] * (m[1] * m[8] - m[7] * m[2]);
+        det = det + m[6] * (m[1] * m[5] - m[4] * m[2]);
+        vol[k] = std::fabs(det);
+        g.h_grid[b0 + k] = make_grid(m, &imvs[3 * k], g.cstride);
+        g.h_usegrid[b0 + k] = (!g.force_brute && g.h_grid[b0 + k].nc[0] > 0) ? 1 : 0;
+        if (!g.h_usegrid[b0 + k]) g.h_grid[b0 + k].nc[0] = 0;
+        if (nivect_out) nivect_out[k] = ns[k];
+    }
+    HIPCHK(hipMemcpyAsync(g.d_ivect + b0 * g.ivcap * 3, &g.h_ivect[b0 * g.ivcap * 3], (size_t)count * g.ivcap * 3 * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.d_nivect + b0, &g.h_nivect[b0], (size_t)count * sizeof(int), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.d_hmat + 9 * b0, h, (size_t)count * 9 * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.d_volume + b0, vol.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.d_grid + b0, &g.h_grid[b0], (size_t)count * sizeof(mw::GridDesc), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.d_usegrid + b0, &g.h_usegrid[b0], (size_t)count * sizeof(int), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));      // `h` and `vol` are the caller's / this frame's
+    return 0;
+}
+
 int mw_set_cell(int ils, const double h[9], int* nivect_out)
 {
     MW_LOCK;
     if (check_live() || check_box(ils)) return 1;
-    std::vector<double> iv;
-    int imv[3] = {1, 1, 1};
-    const int n = host_ivects(h, iv, imv);
-    if (n < 0) return fail("mw_set_cell: cell of box %d is so small that it needs more than %d image vectors", ils, MW_MAX_IVECT);
-    if (n > g.ivcap && grow_ivcap(n)) return 1;
-    const size_t off = (size_t)(ils - 1) * g.ivcap * 3;
-    std::memcpy(&g.h_ivect[off], iv.data(), iv.size() * sizeof(double));
-    g.h_nivect[ils - 1] = n;
-    HIPCHK(hipMemcpyAsync(g.d_ivect + off, &g.h_ivect[off], iv.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemcpyAsync(g.d_nivect + (ils - 1), &g.h_nivect[ils - 1], sizeof(int), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemcpyAsync(g.d_hmat + 9 * (size_t)(ils - 1), h, 9 * sizeof(double), hipMemcpyHostToDevice, g.stream));
-    {   // volume(ils) = |det hmatrix(:,:,ils)| as util_determinant expands it (util.f90:16-41; molint.F90:125)
-        const double* m = h;   // m[(c-1)*3 + (r-1)] = hmatrix(r,c)
-        double det = m[0] * (m[4] * m[8] - m[7] * m[5]);
-        det = det - m[3] * (m[1] * m[8] - m[7] * m[2]);
-        det = det + m[6] * (m[1] * m[5] - m[4] * m[2]);
-        const double vol = std::fabs(det);
-        HIPCHK(hipMemcpyAsync(g.d_volume + (ils - 1), &vol, sizeof(double), hipMemcpyHostToDevice, g.stream));
-        HIPCHK(hipStreamSynchronize(g.stream));
-    }
-    g.h_grid[ils - 1] = make_grid(h, imv, g.cstride);
-    g.h_usegrid[ils - 1] = (!g.force_brute && g.h_grid[ils - 1].nc[0] > 0) ? 1 : 0;
-    if (!g.h_usegrid[ils - 1]) g.h_grid[ils - 1].nc[0] = 0;
-    HIPCHK(hipMemcpyAsync(g.d_grid + (ils - 1), &g.h_grid[ils - 1], sizeof(mw::GridDesc), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemcpyAsync(g.d_usegrid + (ils - 1), &g.h_usegrid[ils - 1], sizeof(int), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    if (nivect_out) *nivect_out = n;
-    return 0;
+    if (!h) return fail("mw_set_cell: null pointer");
+    return set_cells_impl(ils, 1, h, nivect_out);
+}
+
+int mw_set_cells_range(int first_ils, int count, const double* h, int* nivect_out)
+{
+    MW_LOCK;
+    if (check_live() || check_range(first_ils, count)) return 1;
+    if (!h) return fail("mw_set_cells_range: null pointer");
+    return set_cells_impl(first_ils, count, h, nivect_out);
 }
 
 int mw_get_ivects(int ils, double* out, int max_vectors, int* nivect_out)

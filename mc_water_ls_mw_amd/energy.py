@@ -36,7 +36,7 @@ _fp = ctypes.POINTER(ctypes.c_float)
 ABI_SYMBOLS = (
     "mw_init", "mw_finalize", "mw_is_initialised", "mw_last_error", "mw_constants",
     "mw_set_cell", "mw_get_ivects", "mw_upload_positions", "mw_download_positions", "mw_patch_position",
-    "mw_upload_positions_range", "mw_download_positions_range",
+    "mw_upload_positions_range", "mw_download_positions_range", "mw_set_cells_range",
     "mw_build_neighbours", "mw_build_neighbours_batch", "mw_get_neighbours",
     "mw_model_energy", "mw_model_energy_batch", "mw_model_energy_counts",
     "mw_model_energy_counts_total", "mw_neighbour_total",
@@ -147,14 +147,40 @@ class EnergyModule:
     # -- energy_init / energy_deinit (molint.F90:91-171) ------------------------------
     def energy_init(self):
         """Allocate, set volume(ils) = |det h|, then ivects + neighbours + energy per lattice."""
+        self.setup_boxes()                                                          # :125,134 + the mirrored positions
+        # :147-148 for every lattice: all lists in one batch of launches, then all energies in one launch
+        self.build_neighbours_batch(1, self.num_lattices)
+        self.model_energy_batch(1, self.num_lattices)
+
+    def setup_boxes(self):
+        """mw_init + volume(ils) = |det h| + compute_ivects + the mirrored positions of EVERY box, in a handful of
+        transfers whatever the number of boxes (farms hold thousands)."""
         self._chk(self.L.mw_init(self.device, self.nwater, self.num_lattices, self.maxneigh))
         self._live = True
-        for ils in range(1, self.num_lattices + 1):
-            self.volume[ils - 1] = abs(np.linalg.det(self.hmatrix[ils - 1]))       # :125
-            self.compute_ivects(ils)                                                # :134
-        for ils in range(1, self.num_lattices + 1):
-            self.compute_neighbours(ils)                                            # :147
-            self.compute_model_energy(ils)                                          # :148
+        self.volume[:] = np.abs(np.linalg.det(self.hmatrix))                        # :125
+        self.set_cells_range(1, self.num_lattices)                                  # :134
+        self.upload_range(1, self.num_lattices)
+
+    def set_cells_range(self, first_ils=1, count=None):
+        """compute_ivects for ``count`` consecutive lattices in one call (one transfer per device array)."""
+        count = self.num_lattices - first_ils + 1 if count is None else count
+        self._ils(first_ils), self._ils(first_ils + count - 1)
+        h = np.ascontiguousarray(self.hmatrix[first_ils - 1:first_ils - 1 + count], dtype=np.float64)
+        n = np.zeros(count, dtype=np.int32)
+        self._chk(self.L.mw_set_cells_range(first_ils, count, _d(h), _i(n)))
+        self.nivect[first_ils - 1:first_ils - 1 + count] = n
+        for b in range(first_ils - 1, first_ils - 1 + count):
+            self._stale[b] = True
+
+    def upload_range(self, first_ils=1, count=None):
+        """Mirror ljr of ``count`` consecutive lattices in one transfer."""
+        count = self.num_lattices - first_ils + 1 if count is None else count
+        self._ils(first_ils), self._ils(first_ils + count - 1)
+        x = np.ascontiguousarray(self.ljr[first_ils - 1:first_ils - 1 + count], dtype=np.float64)
+        self._chk(self.L.mw_upload_positions_range(first_ils, count, _d(x)))
+        for b in range(first_ils - 1, first_ils - 1 + count):
+            self._last_imol[b] = 0
+            self._stale[b] = False
 
     def energy_deinit(self):
         if self._live:

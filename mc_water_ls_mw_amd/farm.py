@@ -77,13 +77,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             em.hmatrix[2 * w:2 * w + 2] = c["hmatrix"]
             em.ljr[2 * w:2 * w + 2] = c["ljr"]
     last_cycle = start_cycle + cycles
-    em._chk(em.L.mw_init(device, n, 2 * walkers, em.maxneigh))
-    em._live = True
+    em.setup_boxes()                                   # cells + positions of every box in a handful of transfers
     try:
-        for b in range(1, 2 * walkers + 1):
-            em.volume[b - 1] = abs(np.linalg.det(em.hmatrix[b - 1]))
-            em.compute_ivects(b)
-            em._upload(b)
         em.build_neighbours_batch(1, 2 * walkers)
         em.model_energy_batch(1, 2 * walkers)
         grid = MuGrid(nbins, -mu_range, mu_range)

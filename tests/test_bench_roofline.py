@@ -34,18 +34,38 @@ def test_counter_summary_is_the_one_the_docs_quote():
 @pytest.mark.parametrize("kernel,alg_bytes,ms,units", [("k_model_energy", 387006480, 0.092, 512 * 4096),
                                                        ("k_move_energy", 10867775200, 1.26, 512 * 2048)])
 def test_roofline_block(bench, kernel, alg_bytes, ms, units):
+    """`frac` is measured against the ceiling `bound` names (FP64 VALU issue for both kernels) and cannot exceed 1; the
+    SURVEY.md 8(d) convention -- which does exceed 1 for the move kernel -- is carried beside it under its own name."""
     c = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
     r = bench.kernel_roofline(kernel, alg_bytes, ms, units, c, 5500.0)
-    assert r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert r["achieved"] == pytest.approx(alg_bytes / (ms * 1e-3) / 1e9) and r["frac"] == pytest.approx(r["achieved"] / 8000.0)
-    assert r["bound"] == "valu" and 0.5 < r["valu"]["busy"] < 1.0 and 0.3 < r["lds_busy"] < r["valu"]["busy"]
-    assert 0.0 < r["hbm_traffic_frac"] < 0.5                       # neither kernel moves anything like its algorithmic bytes
+    assert r["bound"] == "valu" and r["unit"].startswith("G wave64-instructions/s")
+    assert r["peak"] == pytest.approx(1024 * 2.4e9 / 4 / 1e9)
+    assert r["achieved"] == pytest.approx(c[kernel]["SQ_INSTS_VALU"] / (ms * 1e-3) / 1e9)
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.4 < r["frac"] <= 1.0
+    assert r["algorithmic_GBps"] == pytest.approx(alg_bytes / (ms * 1e-3) / 1e9)
+    assert r["convention_frac"] == pytest.approx(r["algorithmic_GBps"] / 8000.0)
+    v, l = r["valu"], r["lds"]
+    assert 0.5 < v["busy_duration"] < 1.0 and 0.3 < v["busy_grbm"] <= v["busy_duration"] * 1.05      # both cycle bases are printed
+    assert 0.2 < l["busy_duration"] < v["busy_duration"] and 0.0 <= l["bank_conflict_share"] < 1.0
+    assert 0.0 < r["hbm_traffic_frac"] < 0.6                       # neither kernel moves anything like its algorithmic bytes
     assert r["traffic"] < alg_bytes and r["counters_tag"] == c["tag"]
-    assert r["valu"]["wave_insts_per_s"] < r["valu"]["peak_wave_insts_per_s_f64"]
 
 
-def test_roofline_without_counters_does_not_claim_hbm(bench):
+def test_roofline_without_counters_claims_no_ceiling(bench):
     r = bench.kernel_roofline("k_move_energy", 10867775200, 1.26, 512 * 2048, {}, 5500.0)
-    assert r["traffic"] is None and r["bound"].startswith("not hbm")        # 8.6 TB/s algorithmic > the box's copy ceiling
+    assert r["traffic"] is None and r["frac"] is None and r["bound"].startswith("unknown") and "not hbm" in r["bound"]
+    assert r["convention_frac"] > 1.0                              # 8.6 TB/s algorithmic: the convention is not a roofline
     r = bench.kernel_roofline("k_model_energy", 387006480, 0.092, 512 * 4096, {}, 5500.0)
-    assert r["bound"].startswith("unknown")
+    assert r["bound"].startswith("unknown") and "not hbm" not in r["bound"] and r["frac"] is None
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """`--gpus N` with a launcher environment of another size is an error, never a silent 1-GPU run (and with no launcher
+    environment `--gpus N > 1` starts its own ranks: tests/test_gpu_multiprocess.py)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr and p.stdout.strip() == ""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr

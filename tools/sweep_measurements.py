@@ -25,12 +25,7 @@ def farm_for(cells, nlat, walkers, sigma, temperature):
         for l in range(nlat):
             em.hmatrix[w * nlat + l] = cells[l][0]
             em.ljr[w * nlat + l] = lat.thermalise(cells[l][1], sigma, 1000 * l + w)
-    em._chk(em.L.mw_init(0, em.nwater, em.num_lattices, em.maxneigh))
-    em._live = True
-    for b in range(1, walkers * nlat + 1):
-        em.volume[b - 1] = abs(np.linalg.det(em.hmatrix[b - 1]))
-        em.compute_ivects(b)
-        em._upload(b)
+    em.setup_boxes()
     em.build_neighbours_batch(1, walkers * nlat)
     em.model_energy_batch(1, walkers * nlat)
     grid = MuGrid(101, -8000.0, 8000.0) if nlat == 2 else None
@@ -40,8 +35,12 @@ def farm_for(cells, nlat, walkers, sigma, temperature):
     return em, farm
 
 
-def run(name, cells, nlat, walkers, nmoves, out):
+def run(name, cells, nlat, walkers, nmoves, out, wl=False, npt=False):
     em, farm = farm_for(cells, nlat, walkers, 0.1, 200.0)
+    if wl:            # what the replica farm runs per move: Wang-Landau update + a lattice-switch attempt (farm.py set_options)
+        farm.options(record=True, samplerun=False, always_switch=True, npt=npt, wl_factor=0.05)
+    if npt:           # io.f90:171-172: volume moves 1/N against translations 0.5
+        farm.moves(trans_prob=0.5, vol_prob=1.0 / len(cells[0][1]), dv_max_ang=0.924)
     farm.sweep_launch(20, seed=1, move0=0)
     em.sync()
     em.timer_start(0)
@@ -66,6 +65,11 @@ g = lambda n: dict(np.load(os.path.join(ROOT, "tests", "golden", n + ".npz")))  
 ic48, ih48 = g("ic48"), g("ih48")
 if only in (None, "pair48"):
     run("pair48 x 8192 walkers", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 8192, 480, out)
+if only in (None, "pair48wl"):
+    run("pair48 x 8192 walkers, WL update + switch per move", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 8192, 480, out, wl=True)
+if only in (None, "npt48"):
+    run("pair48 x 8192 walkers, NPT (volume moves), WL update + switch per move", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 8192, 480, out,
+        wl=True, npt=True)
 ic1536, ih1536 = g("ic1536"), g("ih1536")
 if only in (None, "pair1536"):
     run("pair1536 x 2048 walkers", [(ic1536["h"], ic1536["xyz"]), (ih1536["h"], ih1536["xyz"])], 2, 2048, 300, out)
