@@ -517,6 +517,22 @@ int mw_constants(double out[8])
     return 0;
 }
 
+// The instantiations of the Monte Carlo driver: lattices per walker (= wavefronts per workgroup) x residency (0: positions and
+// rows from global memory / L2, 1: positions in LDS, 2: positions and list rows in LDS) x with / without volume moves.
+static const void* sweep_kernel(int nlat, int residency, bool withvol)
+{
+#define MW_SWEEP_K(L, P, R, V) reinterpret_cast<const void*>(&mw::k_sweep<L, P, R, V>)
+    static const void* const tab[2][3][2] = {
+        {{MW_SWEEP_K(1, false, false, false), MW_SWEEP_K(1, false, false, true)},
+         {MW_SWEEP_K(1, true, false, false),  MW_SWEEP_K(1, true, false, true)},
+         {MW_SWEEP_K(1, true, true, false),   MW_SWEEP_K(1, true, true, true)}},
+        {{MW_SWEEP_K(2, false, false, false), MW_SWEEP_K(2, false, false, true)},
+         {MW_SWEEP_K(2, true, false, false),  MW_SWEEP_K(2, true, false, true)},
+         {MW_SWEEP_K(2, true, true, false),   MW_SWEEP_K(2, true, true, true)}}};
+#undef MW_SWEEP_K
+    return tab[nlat - 1][residency][withvol ? 1 : 0];
+}
+
 static int init_impl(int device, int nwater, int nboxes, int maxneigh);
 
 int mw_init(int device, int nwater, int nboxes, int maxneigh)
@@ -692,16 +708,8 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_move_energy<true, mw::kLayoutSoA, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
-    {   // the sweep driver's dynamic LDS (image vectors of small or sheared cells, staged positions and rows) can pass 64 KiB
-        const void* sweeps[] = {reinterpret_cast<const void*>(&mw::k_sweep_translation<true, true, true>),
-                                reinterpret_cast<const void*>(&mw::k_sweep_translation<true, false, true>),
-                                reinterpret_cast<const void*>(&mw::k_sweep_translation<false, false, true>),
-                                reinterpret_cast<const void*>(&mw::k_sweep_translation<true, true, false>),
-                                reinterpret_cast<const void*>(&mw::k_sweep_translation<true, false, false>),
-                                reinterpret_cast<const void*>(&mw::k_sweep_translation<false, false, false>)};
-        for (const void* f : sweeps)
-            HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
-    }
+    for (int v = 0; v < 12; ++v)   // the sweep driver's dynamic LDS (image vectors of small or sheared cells, staged positions and rows) can pass 64 KiB
+        HIPCHK(hipFuncSetAttribute(sweep_kernel(1 + (v & 1), (v >> 1) % 3, v >= 6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
     g.live = true;
     return 0;
 }
@@ -1772,14 +1780,16 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
         }
         dlog = g.d_swlog;
     }
-    const size_t iv_bytes = (size_t)g.sp.nlat * g.ivcap * 3 * sizeof(double);
-    const size_t pos_bytes = (size_t)g.sp.nlat * g.N * 3 * sizeof(double);
-    const bool ldspos = pos_bytes <= 16 * 1024;        // small systems: the walker's positions stay in LDS (8 walkers per CU)
-    // the reference's own system sizes: list rows (<= 32 entries) and row lengths in LDS as well
+    const int L = g.sp.nlat;
+    const bool withvol = g.sp.transP < 1.0;          // volume moves: the build that carries mc_volume
+    // Residency of a walker's data in LDS.  Small systems (the reference's own 48-molecule cells): positions, and -- when an
+    // entry (j, image) fits 16 bits (N <= 64) and no row is longer than 32 -- list rows and row lengths too, so that nothing
+    // in the move loop waits on global memory.  Eight walkers per CU (16 wavefronts of <= 128 VGPRs) want <= 20 KiB each.
+    const size_t pos_bytes = (size_t)L * g.N * 3 * sizeof(double);
+    const bool ldspos = pos_bytes <= 16 * 1024;
     bool ldslist = false;
     int rstride = 32;
-    size_t list_bytes = (size_t)g.sp.nlat * g.N * (32 * sizeof(uint32_t) + sizeof(int));
-    if (ldspos && iv_bytes + pos_bytes + list_bytes <= 17 * 1024) {
+    if (ldspos && g.N <= 64) {
         if (g.nnmax_version != g.list_version) {     // once per list rebuild: the longest row of ANY box
             std::vector<int> st((size_t)g.nbox * 2);
             HIPCHK(hipMemcpyAsync(st.data(), g.d_stats, st.size() * sizeof(int), hipMemcpyDeviceToHost, g.stream));
@@ -1789,30 +1799,25 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
             g.nnmax_cached = mx;                     // stats = {min nn, max nn} of the last list build of each box
             g.nnmax_version = g.list_version;
         }
-        ldslist = g.nnmax_cached <= 32;
-        if (ldslist) {                               // rows as short as the lists allow: LDS per walker sets the occupancy
+        if (g.nnmax_cached <= 32) {                  // rows as short as the lists allow: LDS per walker sets the occupancy
             rstride = std::max(4, (g.nnmax_cached + 3) & ~3);
-            list_bytes = (size_t)g.sp.nlat * g.N * (rstride * sizeof(uint32_t) + sizeof(int));
-            list_bytes = (list_bytes + 7) & ~(size_t)7;
+            ldslist = mw::sweep_lds(L, g.ivcap, g.N, g.sp.nbins, true, true, rstride, withvol).total <= 24 * 1024;
         }
     }
-    const size_t shmem = iv_bytes + (ldspos ? pos_bytes : 0) + (ldslist ? list_bytes : 0)
-                         + (g.sp.nlat == 2 ? (size_t)3 * g.sp.nbins * sizeof(double) : 0);   // weight, mu_bin, binwidth
-    const bool withvol = g.sp.transP < 1.0;          // volume moves: the build that carries the out-of-line mc_volume
-    // static LDS of the sweep kernel: one WaveScratch, the volume move's queue, cells (generous bound)
-    const size_t static_lds = sizeof(mw::WaveScratch) + (withvol ? (size_t)(mw::kQCap + 1) * 64 * sizeof(uint32_t) : 4) + 1024;
-    if (shmem + static_lds > (size_t)160 * 1024)
-        return fail("mw_sweep: %zu bytes of LDS per walker (image vectors %zu, positions %zu, list rows %zu) exceed the CU's 160 KiB",
-                    shmem + static_lds, iv_bytes, ldspos ? pos_bytes : (size_t)0, ldslist ? list_bytes : (size_t)0);
-    auto kern = withvol ? (ldslist ? mw::k_sweep_translation<true, true, true>
-                                   : (ldspos ? mw::k_sweep_translation<true, false, true> : mw::k_sweep_translation<false, false, true>))
-                        : (ldslist ? mw::k_sweep_translation<true, true, false>
-                                   : (ldspos ? mw::k_sweep_translation<true, false, false> : mw::k_sweep_translation<false, false, false>));
-    hipLaunchKernelGGL(kern, dim3(count), dim3(64), shmem, g.stream, g.d_pos, g.d_hmat, g.d_ivect, g.d_nivect,
-                       g.d_listm, g.d_list, g.d_nn, g.d_order, g.d_nns, g.d_cmax, g.d_energy, g.d_wls, g.d_wmu, g.d_wacc, g.d_wswitch, g.d_wshift, g.sp, g.d_wweight, g.d_whist, g.d_wuhist,
-                       g.d_sw_mubin, g.d_sw_binwidth, g.d_volume, g.d_wvol, g.d_wflag, g.N, g.S, g.ivcap, nmoves, seed, move0,
-                       first_walker - 1, dlog, rstride, g.has_windows ? (const double*)g.d_wwin : (const double*)nullptr,
-                       g.d_wfac, g.d_wsum, g.d_winflag, g.has_steps ? g.d_wstep : nullptr);
+    const mw::SweepLds lay = mw::sweep_lds(L, g.ivcap, g.N, g.sp.nbins, ldspos, ldslist, rstride, withvol);
+    const size_t static_lds = 512;                   // cells, hand-over words (generous bound)
+    if (lay.total + static_lds > (size_t)160 * 1024 - 8 * 1024)
+        return fail("mw_sweep: %u bytes of LDS per walker (image vectors %u, positions %u, list rows %u) exceed what a workgroup may have",
+                    lay.total, lay.pos - lay.iv, lay.tab - lay.pos, lay.nn - lay.row);
+    const void* kern = sweep_kernel(L, ldslist ? 2 : (ldspos ? 1 : 0), withvol);
+    const double* wwin = g.has_windows ? (const double*)g.d_wwin : (const double*)nullptr;
+    const double* wstep = g.has_steps ? (const double*)g.d_wstep : (const double*)nullptr;
+    int w0 = first_walker - 1;
+    void* args[] = {&g.d_pos, &g.d_hmat, &g.d_ivect, &g.d_nivect, &g.d_listm, &g.d_list, &g.d_nn, &g.d_order, &g.d_nns, &g.d_cmax,
+                    &g.d_energy, &g.d_wls, &g.d_wmu, &g.d_wacc, &g.d_wswitch, &g.d_wshift, &g.sp, &g.d_wweight, &g.d_whist, &g.d_wuhist,
+                    &g.d_sw_mubin, &g.d_sw_binwidth, &g.d_volume, &g.d_wvol, &g.d_wflag, &g.N, &g.S, &g.ivcap, &nmoves, &seed, &move0,
+                    &w0, &dlog, &rstride, &wwin, &g.d_wfac, &g.d_wsum, &g.d_winflag, &wstep};
+    HIPCHK(hipLaunchKernel(kern, dim3(count), dim3(64 * L), args, lay.total, g.stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

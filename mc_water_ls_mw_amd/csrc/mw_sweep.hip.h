@@ -12,15 +12,15 @@ namespace mw {
 // =====================================================================================
 // Device-resident translation-move driver: mc_water_translation
 // (mc_moves.F90:966-1213) with eta_weight (:893-964) and mu_to_bin (:2187-2215), for many
-// independent walkers at once.  One wavefront per walker runs its Markov chain move after
-// move: pick a molecule, draw the displacement in the active lattice, map it through
-// fractional coordinates into the partner lattice (:1042-1066), fused old/new local energy in
-// each lattice (move_energy_wave), update the order parameter mu and the multicanonical
-// weights' contribution, accept or revert (:1145-1209).  The caller-side bookkeeping of
-// model_energy (:1013-1016,1087,1190) is done here on the per-box energies.
+// independent walkers at once.  One workgroup per walker -- one wavefront per lattice -- runs its
+// Markov chain move after move: pick a molecule, draw the displacement in the active lattice, map
+// it through fractional coordinates into the partner lattice (:1042-1066), fused old/new local
+// energy in each lattice (move_energy_wave, the lattices side by side), update the order parameter
+// mu and the multicanonical weights' contribution, accept or revert (:1145-1209).  The caller-side
+// bookkeeping of model_energy (:1013-1016,1087,1190) is done here on the per-box energies.
 // Random numbers: Philox4x32-10, counter (move lo, move hi, walker, call), key = seed -- the same
 // stream as the oracle's mwo_move_uniforms.
-//   grid = walkers in the launch, block = 64
+//   grid = walkers in the launch, block = 64 x lattices
 // =====================================================================================
 struct SweepParams {
     double beta, max_trans;
@@ -78,32 +78,48 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
 }
 
-__device__ __forceinline__ int dev_mu_to_bin(const SweepParams& g, double mu)          // mc_moves.F90:2187-2215
+// -------------------------------------------------------------------------------------
+// Order parameter -> bin -> weight, LANE-PARALLEL.  These are scalar computations of the host program (a log, three
+// divisions, an exp per call) and a wavefront has no scalar double-precision unit: evaluated one after the other by all
+// 64 lanes they cost more vector instructions per move than one lattice's whole energy evaluation (profiles/r03a: 2200
+// VALU instructions per two-lattice move with the Wang-Landau update and a switch attempt, 1170 of them energy).  Here
+// every value of mu a move needs -- the trial value, the value a rejection restores, the current one -- sits in its own
+// lane and ONE instruction stream serves them all; likewise the move's exponentials.
+// -------------------------------------------------------------------------------------
+struct MuGridDev {                       // per walker, wave-uniform
+    double r_pos, a_pos, r_neg, a_neg, lr_pos, lr_neg, mu_lo, mu_hi;
+    int nbins, start_bin, end_bin, eta_interp, in_window;
+};
+
+__device__ __forceinline__ int lane_mu_to_bin(const MuGridDev& g, double mu)          // mc_moves.F90:2187-2215, one mu per lane
 {
-    if (fabs(mu) <= 0.5) return g.nbins / 2 + 1;
-    if (mu > 0.0) {
-        const double arg = 1.0 - (mu - 0.5) * (1.0 - g.r_pos) / g.a_pos;
-        return g.nbins / 2 + 2 + (int)(log(arg) / log(g.r_pos));
-    }
-    const double arg = 1.0 - (fabs(mu) - 0.5) * (1.0 - g.r_neg) / g.a_neg;
-    return g.nbins / 2 - (int)(log(arg) / log(g.r_neg));
+    const double a = fabs(mu);
+    const bool pos = mu > 0.0;
+    const double r = pos ? g.r_pos : g.r_neg, aa = pos ? g.a_pos : g.a_neg, lr = pos ? g.lr_pos : g.lr_neg;
+    const double arg = 1.0 - (a - 0.5) * (1.0 - r) / aa;
+    const int q = (int)(log(arg) / lr);
+    return a <= 0.5 ? g.nbins / 2 + 1 : (pos ? g.nbins / 2 + 2 + q : g.nbins / 2 - q);
 }
 
-__device__ __forceinline__ double dev_eta_weight(const SweepParams& g, const double* weight,
-                                                 const double* __restrict__ mu_bin, const double* __restrict__ binwidth,
-                                                 double mu)                                // mc_moves.F90:893-964
+// eta_weight (mc_moves.F90:893-964) for one mu per lane, bin k already known; w / mb / bw: 0-based tables in LDS.
+// The four interpolation branches of the reference are one expression with selected indices:
+//   eta = w(base) + (mu - mu_bin(base)) * 2 (w(hi) - w(lo)) / (binwidth(hi) + binwidth(lo)),   hi = lo + 1
+__device__ __forceinline__ double lane_eta(const MuGridDev& g, const double* w, const double* __restrict__ mb,
+                                           const double* __restrict__ bw, double mu, int k)
 {
-    // 'dd' walkers that have not reached their window yet carry no weight: the reference returns here without
+    const int nb = g.nbins;
+    const int kc = k < 1 ? 1 : (k > nb ? nb : k);               // (a bin outside the table only with mu outside the range: not used then)
+    const bool up = (kc == g.start_bin) || (kc != g.end_bin && mu > mb[kc - 1]);
+    int hi = up ? kc + 1 : kc;
+    hi = hi > nb ? nb : (hi < 2 ? 2 : hi);
+    const int lo = hi - 1;
+    const int base = (up || kc == g.end_bin) ? kc : (kc > 1 ? kc - 1 : 1);
+    double val = w[kc - 1];
+    if (g.eta_interp) val = w[base - 1] + (mu - mb[base - 1]) * (2.0 * (w[hi - 1] - w[lo - 1]) / (bw[hi - 1] + bw[lo - 1]));
+    // 'dd' walkers that have not reached their window yet carry no weight: the reference returns there without
     // assigning the function result (:913); 0 is what its comment asks for ("don't want to penalise walkers")
-    if (!g.in_window) return 0.0;
-    if (mu < g.mu_lo || mu > g.mu_hi) return 1.7976931348623157e308;                       // huge(1.0_dp)
-    const int k = dev_mu_to_bin(g, mu);
-    const double* w = weight - 1; const double* mb = mu_bin - 1; const double* bw = binwidth - 1;   // 1-based views
-    if (!g.eta_interp) return w[k];
-    if (k == g.start_bin) return w[k] + (mu - mb[k]) * (2.0 * (w[k + 1] - w[k]) / (bw[k] + bw[k + 1]));
-    if (k == g.end_bin)   return w[k] + (mu - mb[k]) * (2.0 * (w[k] - w[k - 1]) / (bw[k] + bw[k - 1]));
-    if (mu > mb[k])       return w[k] + (mu - mb[k]) * (2.0 * (w[k + 1] - w[k]) / (bw[k] + bw[k + 1]));
-    return w[k - 1] + (mu - mb[k - 1]) * (2.0 * (w[k] - w[k - 1]) / (bw[k] + bw[k - 1]));
+    val = (mu < g.mu_lo || mu > g.mu_hi) ? 1.7976931348623157e308 : val;      // huge(1.0_dp)
+    return g.in_window ? val : 0.0;
 }
 
 #define MW_HM(m, r, c) ((m)[((c) - 1) * 3 + ((r) - 1)])     // Fortran (r,c) of a column-major 3x3
@@ -252,38 +268,99 @@ __device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, 
     return esum;
 }
 
-__device__ __forceinline__
-int volume_move_wave(const VolCtx& c, const SweepParams& sp, const double* weight, const double* __restrict__ mu_bin,
-                     const double* __restrict__ binwidth, double u0, double u1, double u2, double u3,
-                     int& ls, double& ls_mu, double men[2], int lane)
+// -------------------------------------------------------------------------------------
+// The workgroup of a walker: one wavefront per lattice.  Each wavefront evaluates ITS lattice (the fused old/new local
+// energy of a translation, the rescaled box of a volume move); wavefront 0 then takes the move's decision -- order
+// parameter, weights, Metropolis test, Wang-Landau update, lattice switch -- and hands {accepted, active lattice} back.
+// Two workgroup barriers per move for two lattices, none for one.
+// -------------------------------------------------------------------------------------
+template <int NLAT>
+__device__ __forceinline__ void wg_sync()
 {
-    const int L = c.L, N = c.N;
-    double backup_e[2] = {men[0], men[1]}, old_vol[2] = {c.svol[0], c.svol[1]};
-    double old_h[2][9], recip_used[2][9];
-#pragma unroll
-    for (int l = 0; l < 2; ++l)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) { old_h[l][t] = c.shmat[l * 9 + t]; recip_used[l][t] = c.srecip[l * 9 + t]; }
-    __builtin_amdgcn_wave_barrier();
-    const int idim = (int)(u0 * 3.0) + 1, jdim = (int)(u1 * 3.0) + 1;                          // :1269-1272
-    const double dh = (2.0 * u2 - 1.0) * sp.dv_max;                                             // :1276
-    if (lane == 0) {
-        for (int l = 0; l < L; ++l) {                                                           // :1281-1282
-            MW_HM(c.shmat + 9 * l, idim, jdim) = MW_HM(c.shmat + 9 * l, idim, jdim) + dh;
-            if (idim != jdim) MW_HM(c.shmat + 9 * l, jdim, idim) = MW_HM(c.shmat + 9 * l, jdim, idim) + dh;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    double new_e[2] = {0.0, 0.0};
-    int bad = 0, nresc = 0;                                                                     // nresc: lattices rescaled so far
-    for (int l = 0; l < L; ++l) {                                                               // :1285-1358
-        dev_rescale(c, l, recip_used[l], c.shmat + 9 * l, lane);
-        nresc = l + 1;
+    if constexpr (NLAT == 1) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+constexpr int kUB = 16;                                   // moves per batch of uniforms (Philox calls are lanes of one pass)
+constexpr unsigned kSweepScratch = (unsigned)((sizeof(WaveScratch) + 15) & ~(size_t)15);
+constexpr unsigned kSweepScratchVol = (unsigned)(((kQCap + 1) * 64 * sizeof(uint32_t)) > kSweepScratch ? ((kQCap + 1) * 64 * sizeof(uint32_t)) : kSweepScratch);
+
+// Dynamic LDS of a walker's workgroup (byte offsets), the same arithmetic on the host (launch size) and on the device.
+struct SweepLds { unsigned iv, pos, tab, uni, mv, scr, row, nn, total, scr_bytes; };
+__host__ __device__ inline SweepLds sweep_lds(int L, int ivcap, int N, int nbins, bool ldspos, bool ldslist, int rstride, bool withvol)
+{
+    SweepLds o;
+    unsigned p = 0;
+    o.iv = p;  p += (unsigned)L * ivcap * 24u;                         // image vectors [L][ivcap][3]
+    o.pos = p; p += ldspos ? (unsigned)L * N * 24u : 0u;               // positions     [L][N][3]     (small systems)
+    o.tab = p; p += L == 2 ? 5u * nbins * 8u : 0u;                     // weight, mu_bin, binwidth, histogram, unbiased_hist
+    o.uni = p; p += kUB * 8u * 8u;                                     // uniforms of a batch of moves [kUB][8]
+    o.mv = p;  p += kUB * 32u;                                         // their molecule + displacement [kUB]{x, y, z, imol}
+    p = (p + 15u) & ~15u;
+    o.scr_bytes = withvol ? kSweepScratchVol : kSweepScratch;          // per wavefront: WaveScratch / the full-box energy's queue
+    o.scr = p; p += (unsigned)L * o.scr_bytes;
+    o.row = p; p += ldslist ? (unsigned)L * N * rstride * 2u : 0u;     // list rows, 16-bit entries (j | image << 6; N <= 64)
+    o.nn = p;  p += ldslist ? (unsigned)L * N : 0u;                    // row lengths, one byte each
+    o.total = (p + 15u) & ~15u;
+    return o;
+}
+
+// Volume move of one walker (mc_volume, mc_moves.F90:1216-1534; ref_ljr, which only chain synchronisation reads, is not
+// carried).  Rare (probability ~1/N per move).  One symmetric hmatrix element of both lattices changes; every wavefront
+// rescales ITS lattice through fractional coordinates (lanes over molecules), rebuilds its image vectors in the
+// reference's order and arithmetic and recomputes its full-box energy WITH THE EXISTING LISTS (atom_energy over the
+// slot-major list); wavefront 0 decides; on rejection every wavefront puts its lattice back the way the reference does
+// (positions mapped back through the NEW reciprocal matrix, :1413-1506).
+// Returns (every wavefront): 1 accepted, 0 rejected, -1 rejected because a cell needed more image vectors than ivcap.
+struct VolDecision { double old_eta, new_eta; };
+template <int NLAT, typename DecideFn>
+__device__ __forceinline__
+int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max, int wv, int lane,
+                   double* __restrict__ sx, int* __restrict__ sdec, DecideFn decide)
+{
+    constexpr int L = NLAT;
+    const int l = wv;                                                              // this wavefront's lattice
+    double old_h[9], recip_used[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { old_h[t] = c.shmat[l * 9 + t]; recip_used[t] = c.srecip[l * 9 + t]; }
+    const double old_vol_l = c.svol[l];
+    const int idim = (int)(U[0] * 3.0) + 1, jdim = (int)(U[1] * 3.0) + 1;                       // :1269-1272
+    const double dh = (2.0 * U[2] - 1.0) * dv_max;                                              // :1276
+    wg_sync<NLAT>();                                   // (everybody has read the old cells)
+    if (lane == 0) {                                                                            // :1281-1282
+        MW_HM(c.shmat + 9 * l, idim, jdim) = MW_HM(c.shmat + 9 * l, idim, jdim) + dh;
+        if (idim != jdim) MW_HM(c.shmat + 9 * l, jdim, idim) = MW_HM(c.shmat + 9 * l, jdim, idim) + dh;
+    }
+    wg_sync<NLAT>();
+    // The reference takes the lattices in turn and stops at the first whose new cell needs more image vectors than there
+    // is room for (:1285-1358; here: the move counts as rejected and is flagged): lattice 2 is then never touched.
+    bool bad0 = false;
+    if (L == 2 && l == 1) {
+        const double* h = c.shmat;
+        const double rc = kSmallA * kSigma;
+        const int im = (int)floor(rc / sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2])) + 1;
+        const int jm = (int)floor(rc / sqrt(h[3] * h[3] + h[4] * h[4] + h[5] * h[5])) + 1;
+        const int km = (int)floor(rc / sqrt(h[6] * h[6] + h[7] * h[7] + h[8] * h[8])) + 1;
+        bad0 = (2 * im + 1) * (2 * jm + 1) * (2 * km + 1) > c.ivcap;
+    }
+    double new_e = 0.0;
+    int bad = 0;
+    bool rescaled = false;
+    if (!bad0) {
+        dev_rescale(c, l, recip_used, c.shmat + 9 * l, lane);
+        rescaled = true;
+        wave_sync();
         const int niv = dev_compute_ivects(c.shmat + 9 * l, c.siv + (size_t)l * c.ivcap * 3,
                                            c.ivect_g + (size_t)l * c.ivcap * 3, c.ivcap, lane);
         if (lane == 0) {
@@ -294,258 +371,413 @@ int volume_move_wave(const VolCtx& c, const SweepParams& sp, const double* weigh
             for (int t = 0; t < 9; ++t) c.srecip[l * 9 + t] = rcp[t];
             if (niv >= 0) { c.sniv[l] = niv; c.nivect_g[l] = niv; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        // The new cell needs more image vectors than there is room for: the move counts as rejected (and is
-        // flagged); the lattices rescaled so far -- this one included, its reciprocal matrix is in place -- go back.
-        if (niv < 0) { bad = 1; break; }
-        new_e[l] = dev_wave_model_energy(c, l, lane);
+        wave_sync();
+        if (niv < 0) bad = 1;
+        else new_e = dev_wave_model_energy(c, l, lane);
     }
-    int ok = 0;
-    if (!bad) {
-        men[0] = new_e[0]; men[1] = new_e[1];
-        const double dE = (ls == 1 ? new_e[0] - backup_e[0] : new_e[1] - backup_e[1]);          // :1361
-        const double Vls = ls == 1 ? c.svol[0] : c.svol[1], Vold = ls == 1 ? old_vol[0] : old_vol[1];
-        double old_eta = 0.0, new_eta = 0.0;
-        if (L == 2) {                                                                            // :1363-1371
-            old_eta = dev_eta_weight(sp, weight, mu_bin, binwidth, ls_mu);
-            double mu = (men[0] + sp.pressure * c.svol[0]) - (men[1] + sp.pressure * c.svol[1]);
-            mu = mu - sp.dref;                                                                   // :1371 (leshift)
-            mu = mu * sp.beta - (double)N * log(c.svol[0] / c.svol[1]);
-            ls_mu = mu;
-            new_eta = dev_eta_weight(sp, weight, mu_bin, binwidth, ls_mu);
-        }
-        double diffkT = sp.beta * dE + new_eta - old_eta + sp.beta * sp.pressure * (Vls - Vold)
-                        - (double)N * log(Vls / Vold);                                           // :1381-1382
-        int minu_ls = ls;
-        if (sp.minu && L == 2)                                                                   // :1385-1401
-            minu_ls = dev_minu_branch(sp, ls, men[0], men[1], c.svol[0], c.svol[1], ls == 1 ? backup_e[0] : backup_e[1], Vold, true, N,
-                                      new_eta, old_eta, diffkT);
-        double cmp = exp(-diffkT);
-        cmp = cmp > 1.0 ? 1.0 : cmp;
-        ok = u3 < cmp ? 1 : 0;                                                                   // :1410
-        if (ok) ls = minu_ls;                                                                    // :1426-1429
+    if (lane == 0) { sx[l] = new_e; sdec[2 + l] = bad; }
+    wg_sync<NLAT>();
+    int ok = 0, anybad = 0;
+    if (wv == 0) {
+        anybad = sdec[2] | (L == 2 ? sdec[3] : 0);
+        ok = decide(sx[0], L == 2 ? sx[1] : 0.0, anybad);          // (updates the walker's state; energies in every lane)
+        if (lane == 0) { sdec[0] = ok; sdec[1] = anybad; }
     }
+    wg_sync<NLAT>();
+    ok = sdec[0]; anybad = sdec[1];
     if (!ok) {                                                                                   // :1426-1530
-        double recip_new[2][9];
+        double recip_new[9];
 #pragma unroll
-        for (int l = 0; l < 2; ++l)
-#pragma unroll
-            for (int t = 0; t < 9; ++t) recip_new[l][t] = c.srecip[l * 9 + t];
-        __builtin_amdgcn_wave_barrier();
+        for (int t = 0; t < 9; ++t) recip_new[t] = c.srecip[l * 9 + t];
+        wave_sync();
         if (lane == 0) {
-            for (int l = 0; l < L; ++l) {
-                c.svol[l] = old_vol[l];
-                for (int t = 0; t < 9; ++t) { c.shmat[l * 9 + t] = old_h[l][t]; c.srecip[l * 9 + t] = recip_used[l][t]; }
-            }
+            c.svol[l] = old_vol_l;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { c.shmat[l * 9 + t] = old_h[t]; c.srecip[l * 9 + t] = recip_used[t]; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        for (int l = 0; l < (bad ? nresc : L); ++l) {
-            dev_rescale(c, l, recip_new[l], c.shmat + 9 * l, lane);                              // back through the NEW recip
+        wave_sync();
+        if (rescaled) {
+            dev_rescale(c, l, recip_new, c.shmat + 9 * l, lane);                                 // back through the NEW recip
             const int niv = dev_compute_ivects(c.shmat + 9 * l, c.siv + (size_t)l * c.ivcap * 3,
                                                c.ivect_g + (size_t)l * c.ivcap * 3, c.ivcap, lane);   // :1510-1512
             if (lane == 0 && niv > 0) { c.sniv[l] = niv; c.nivect_g[l] = niv; }
         }
-        men[0] = backup_e[0]; men[1] = backup_e[1];                                              // :1514
-        if (L == 2) {                                                                            // :1516-1520
-            double mu = (men[0] + sp.pressure * c.svol[0]) - (men[1] + sp.pressure * c.svol[1]);
-            mu = mu - sp.dref;                                                                   // :1526 (leshift)
-            mu = mu * sp.beta - (double)N * log(c.svol[0] / c.svol[1]);
-            ls_mu = mu;
-        }
     }
     if (lane == 0) {                                   // global mirrors of the cell
-        for (int l = 0; l < L; ++l) {
-            for (int t = 0; t < 9; ++t) c.hmat_g[l * 9 + t] = c.shmat[l * 9 + t];
-            c.vol_g[l] = c.svol[l];
-        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) c.hmat_g[l * 9 + t] = c.shmat[l * 9 + t];
+        c.vol_g[l] = c.svol[l];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    return bad ? -1 : ok;
+    wg_sync<NLAT>();
+    return anybad ? -1 : ok;
 }
 
-// Per-walker tables (two lattices only): weight / histogram / unbiased_hist [walker][nbins]; every walker
-// reads its OWN weights in eta_weight, so Wang-Landau updates stay local until the host synchronises them
-// (comms_allreduce_eta/hist/uhist semantics, WalkerComms).
-// Two wavefronts per SIMD are the design point (one walker per wavefront, 512 VGPRs per SIMD lane): the build with volume
-// moves must stay within 256 VGPRs -- at 264 it ran ONE wavefront per SIMD and the NPT farm lost a third of its rate.
-template <bool LDSPOS, bool LDSLIST, bool WITHVOL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_sweep_translation(double* pos, double* hmat, double* ivect,
-                         int* nivect, const uint32_t* __restrict__ listm, const uint32_t* __restrict__ list,
-                         const int* __restrict__ nn, const int* __restrict__ order, const int* __restrict__ nns,
-                         const int* __restrict__ cmax, double* __restrict__ energy,
-                         int* __restrict__ wls, double* __restrict__ wmu, unsigned long long* __restrict__ wacc,
-                         unsigned long long* __restrict__ wswitch, double* __restrict__ wshift,
-                         SweepParams sp, double* wweight, double* whist, double* wuhist,
-                         const double* __restrict__ mu_bin_g, const double* __restrict__ binwidth_g,
-                         double* volume, unsigned long long* __restrict__ wvol, int* __restrict__ wflag,
-                         int N, int S, int ivcap, int nmoves, unsigned long long seed, unsigned long long move0,
-                         int walker0, double* __restrict__ mvlog, int rstride,
-                         const double* __restrict__ wwin, double* __restrict__ wfac, double* __restrict__ wsum,
-                         int* __restrict__ winflag, const double* __restrict__ wstep)
+// =====================================================================================
+// k_sweep: the device-resident Monte Carlo driver.  grid = walkers of the launch, block = 64 x NLAT.
+//
+// Per-walker tables (two lattices only): weight / histogram / unbiased_hist [walker][nbins]; every walker reads its OWN
+// weights in eta_weight, so Wang-Landau updates stay local until the host synchronises them (comms_allreduce_eta/hist/
+// uhist semantics, WalkerComms).  The three tables live in LDS for the launch and go back at its end.
+//
+// What bounds the kernel is vector-instruction issue of dependent chains (profiles/r03a_sweep_pmc_counters.txt), so the
+// design is about the LENGTH of a move's chain and the number of chains in flight per SIMD:
+//  * one wavefront per LATTICE, not per walker: the two local-energy evaluations of a move run side by side;
+//  * the move's scalar arithmetic is lane-parallel (lane_mu_to_bin / lane_eta above, one exp stream per move) and done by
+//    wavefront 0 only; bins are carried from move to move; the Wang-Landau minimum is tracked, not re-scanned;
+//  * the uniforms, molecule and displacement of kUB moves come from one Philox pass of the whole workgroup;
+//  * nothing but the current move's values stays in registers: ~128 VGPRs, four wavefronts per SIMD.
+// =====================================================================================
+template <int NLAT, bool LDSPOS, bool LDSLIST, bool WITHVOL>
+__global__ __launch_bounds__(64 * NLAT)
+void k_sweep(double* pos, double* hmat, double* ivect,
+             int* nivect, const uint32_t* __restrict__ listm, const uint32_t* __restrict__ list,
+             const int* __restrict__ nn, const int* __restrict__ order, const int* __restrict__ nns,
+             const int* __restrict__ cmax, double* __restrict__ energy,
+             int* __restrict__ wls, double* __restrict__ wmu, unsigned long long* __restrict__ wacc,
+             unsigned long long* __restrict__ wswitch, double* __restrict__ wshift,
+             SweepParams sp, double* wweight, double* whist, double* wuhist,
+             const double* __restrict__ mu_bin_g, const double* __restrict__ binwidth_g,
+             double* volume, unsigned long long* __restrict__ wvol, int* __restrict__ wflag,
+             int N, int S, int ivcap, int nmoves, unsigned long long seed, unsigned long long move0,
+             int walker0, double* __restrict__ mvlog, int rstride,
+             const double* __restrict__ wwin, double* __restrict__ wfac, double* __restrict__ wsum,
+             int* __restrict__ winflag, const double* __restrict__ wstep)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ WaveScratch ws;
-    __shared__ uint32_t squeue[WITHVOL ? (kQCap + 1) * 64 : 1];   // in-range queue of the volume move's full-box energy
-    __shared__ double shmat[2][9], svol[2];      // the walker's cells: volume moves change them in place
+    constexpr int L = NLAT, NTHR = 64 * NLAT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ double shmat[2][9], srecip[2][9], svol[2];      // the walker's cells: volume moves change them in place
     __shared__ int sniv[2];
-    const int lane = threadIdx.x;
+    __shared__ double sx[4];          // what wavefront 1 hands to the deciding wavefront: {e_old, e_new} / full-box energies
+    __shared__ int sdec[4];           // the decision: accepted, active lattice (volume moves: accepted, bad, bad per lattice)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = NLAT == 2 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
     const int wlk = walker0 + blockIdx.x;
-    const int L = sp.nlat;
     const int box0 = wlk * L;
+    const SweepLds lay = sweep_lds(L, ivcap, N, sp.nbins, LDSPOS, LDSLIST, rstride, WITHVOL);
+    double* siv = reinterpret_cast<double*>(smem_raw + lay.iv);
+    double* spos = reinterpret_cast<double*>(smem_raw + lay.pos);
+    double* sweight = reinterpret_cast<double*>(smem_raw + lay.tab);
+    double* smub = sweight + sp.nbins;
+    double* sbw = smub + sp.nbins;
+    double* shist = sbw + sp.nbins;
+    double* suhist = shist + sp.nbins;
+    double* suni = reinterpret_cast<double*>(smem_raw + lay.uni);
+    double* smv = reinterpret_cast<double*>(smem_raw + lay.mv);
+    WaveScratch* ws = reinterpret_cast<WaveScratch*>(smem_raw + lay.scr + (unsigned)wv * lay.scr_bytes);
+    unsigned short* srow = reinterpret_cast<unsigned short*>(smem_raw + lay.row);
+    unsigned char* snn = smem_raw + lay.nn;
+
     // per-walker pieces of the parameter block: its window of the overlap parameter ('dd': mc_moves.F90:659-709; else
-    // the whole range), whether it has reached that window, its Wang-Landau increment and Swetnam's visit total
+    // the whole range), whether it has reached that window, its step sizes, its Wang-Landau increment and Swetnam's visit total
+    MuGridDev mg;
+    mg.r_pos = sp.r_pos; mg.a_pos = sp.a_pos; mg.r_neg = sp.r_neg; mg.a_neg = sp.a_neg;
+    mg.lr_pos = log(sp.r_pos); mg.lr_neg = log(sp.r_neg);
+    mg.mu_lo = sp.mu_lo; mg.mu_hi = sp.mu_hi; mg.nbins = sp.nbins; mg.start_bin = sp.start_bin; mg.end_bin = sp.end_bin;
+    mg.eta_interp = sp.eta_interp;
     if (wwin) {
-        sp.start_bin = (int)wwin[4 * (size_t)wlk]; sp.end_bin = (int)wwin[4 * (size_t)wlk + 1];
-        sp.mu_lo = wwin[4 * (size_t)wlk + 2]; sp.mu_hi = wwin[4 * (size_t)wlk + 3];
+        mg.start_bin = (int)wwin[4 * (size_t)wlk]; mg.end_bin = (int)wwin[4 * (size_t)wlk + 1];
+        mg.mu_lo = wwin[4 * (size_t)wlk + 2]; mg.mu_hi = wwin[4 * (size_t)wlk + 3];
     }
-    sp.in_window = sp.dd ? winflag[wlk] : 1;                              // mc_moves.F90:112,872
-    if (wstep) { sp.max_trans = wstep[2 * (size_t)wlk]; sp.dv_max = wstep[2 * (size_t)wlk + 1]; }   // per-walker step sizes (equilibration tuning, :1729-1732)
+    mg.in_window = sp.dd ? winflag[wlk] : 1;                              // mc_moves.F90:112,872
+    double max_trans = sp.max_trans, dv_max = sp.dv_max;
+    if (wstep) { max_trans = wstep[2 * (size_t)wlk]; dv_max = wstep[2 * (size_t)wlk + 1]; }   // equilibration tuning, :1729-1732
     double wlf = L == 2 ? wfac[wlk] : 0.0;                                // wl_factor of this walker (:1615,1677)
     double sumh = L == 2 ? wsum[wlk] : 0.0;                               // sumhist (:94,1638)
     const double invPi = 1.0 / 3.141592653589793238462643383279502884197;
 
-    // image vectors of the walker's lattices in LDS: siv[l][ivcap][3]; with LDSPOS (small systems) the walker's
-    // positions live there too for the whole launch -- spos[l][N][3] -- and every gather is an LDS read
-    double* siv = smem;
-    double* spos = smem + (size_t)L * ivcap * 3;
+    // ---- staging: image vectors, (small systems) positions, list rows and row lengths, the walker's tables -------------
     for (int l = 0; l < L; ++l) {
         const int niv = nivect[box0 + l];
-        for (int t = lane; t < niv * 3; t += 64) siv[(size_t)l * ivcap * 3 + t] = ivect[(size_t)(box0 + l) * ivcap * 3 + t];
+        for (int t = tid; t < niv * 3; t += NTHR) siv[(size_t)l * ivcap * 3 + t] = ivect[(size_t)(box0 + l) * ivcap * 3 + t];
         if (LDSPOS) {
             const double* Pg = pos + (size_t)(box0 + l) * N * 3;
-            for (int t = lane; t < 3 * N; t += 64) spos[(size_t)l * N * 3 + t] = Pg[t];
+            for (int t = tid; t < 3 * N; t += NTHR) spos[(size_t)l * N * 3 + t] = Pg[t];
         }
-    }
-    // LDSLIST (the reference's own system sizes, ~48 molecules): list rows (`rstride` entries each: the longest row of
-    // any box, rounded up to 4, at most 32) and row lengths too, so that nothing in the move loop waits on global
-    // memory.  (A read of slots rstride..31 of a row lands in the next row or the row lengths: masked by the caller.)
-    uint32_t* srow = reinterpret_cast<uint32_t*>(spos + (LDSPOS ? (size_t)L * N * 3 : 0));
-    int* snn = reinterpret_cast<int*>(srow + (LDSLIST ? (size_t)L * N * rstride : 0));
-    if (LDSLIST) {
-        for (int l = 0; l < L; ++l) {
+        if (LDSLIST) {    // N <= 64: an entry (j, image) fits 16 bits.  (Slots past a row's end are never live.)
             const uint32_t* LMg = listm + (size_t)(box0 + l) * N * kRow;
-            for (int t = lane; t < N * rstride; t += 64) srow[(size_t)l * N * rstride + t] = LMg[(size_t)(t / rstride) * kRow + (t % rstride)];
-            for (int t = lane; t < N; t += 64) snn[l * N + t] = nn[(size_t)(box0 + l) * N + t];
+            for (int t = tid; t < N * rstride; t += NTHR) {
+                const uint32_t e = LMg[(size_t)(t / rstride) * kRow + (t % rstride)];
+                srow[(size_t)l * N * rstride + t] = (unsigned short)((e & 63u) | ((e >> kJBits) << 6));
+            }
+            for (int t = tid; t < N; t += NTHR) snn[l * N + t] = (unsigned char)nn[(size_t)(box0 + l) * N + t];
         }
     }
-    // two lattices: this walker's weight table and the (shared) bin centres / widths, so that eta_weight and the
-    // Wang-Landau update after every move are LDS arithmetic; the weights go back to the walker's table at the end
-    double* sweight = reinterpret_cast<double*>(snn + (LDSLIST ? (size_t)L * N : 0));
-    double* smub = sweight + sp.nbins;
-    double* sbw = smub + sp.nbins;
     if (L == 2) {
-        for (int t = lane; t < sp.nbins; t += 64) {
+        for (int t = tid; t < sp.nbins; t += NTHR) {
             sweight[t] = wweight[(size_t)wlk * sp.nbins + t];
             smub[t] = mu_bin_g[t];
             sbw[t] = binwidth_g[t];
+            shist[t] = whist[(size_t)wlk * sp.nbins + t];
+            suhist[t] = wuhist[(size_t)wlk * sp.nbins + t];
         }
     }
-    const double* mu_bin = smub;
-    const double* binwidth = sbw;
-    __shared__ double srecip[2][9];          // recip_matrix(:,:,ils) of the walker's lattices
-    if (lane == 0) {
-        for (int l = 0; l < L; ++l) {
-            double rcp[9];
-            dev_recipmatrix(hmat + (size_t)(box0 + l) * 9, rcp);
+    if (tid < L) {
+        const int l = tid;
+        double rcp[9];
+        dev_recipmatrix(hmat + (size_t)(box0 + l) * 9, rcp);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) { srecip[l][t] = rcp[t]; shmat[l][t] = hmat[(size_t)(box0 + l) * 9 + t]; }
-            svol[l] = volume[box0 + l];
-            sniv[l] = nivect[box0 + l];
-        }
+        for (int t = 0; t < 9; ++t) { srecip[l][t] = rcp[t]; shmat[l][t] = hmat[(size_t)(box0 + l) * 9 + t]; }
+        svol[l] = volume[box0 + l];
+        sniv[l] = nivect[box0 + l];
     }
     __syncthreads();
+
     VolCtx vc;
     vc.pos_g = pos + (size_t)box0 * N * 3; vc.spos = LDSPOS ? spos : nullptr;
     vc.shmat = &shmat[0][0]; vc.srecip = &srecip[0][0]; vc.svol = svol; vc.siv = siv; vc.sniv = sniv;
     vc.hmat_g = hmat + (size_t)box0 * 9; vc.vol_g = volume + box0; vc.ivect_g = ivect + (size_t)box0 * ivcap * 3;
     vc.nivect_g = nivect + box0; vc.list_g = list + (size_t)box0 * S * N;
     vc.order_g = order + (size_t)box0 * N; vc.nns_g = nns + (size_t)box0 * N; vc.cmax_g = cmax + (size_t)box0 * ((N + 63) >> 6);
-    vc.queue = squeue + lane; vc.N = N; vc.S = S; vc.ivcap = ivcap; vc.L = L;
-    unsigned long long nvol_try = 0, nvol_acc = 0;
+    vc.queue = reinterpret_cast<uint32_t*>(ws) + lane; vc.N = N; vc.S = S; vc.ivcap = ivcap; vc.L = L;
+
+    // ---- the walker's state (meaningful in wavefront 0, which decides; `ls` is followed by every wavefront) --------------
+    unsigned long long nvol_try = 0, nvol_acc = 0, nsw = 0, acc = 0;
     int flag = 0;
-
-    // this walker's weight table (read by eta_weight, updated by mc_update_wl_bins) and histograms
-    double* weight = sweight;                // (LDS copy; only two-lattice runs read or update it)
-    double* hist = whist + (size_t)wlk * sp.nbins;
-    double* uhist = wuhist + (size_t)wlk * sp.nbins;
-    unsigned long long nsw = 0;
     double gauge = 0.0;                      // total of the minima subtracted from this walker's weights (:1682-1685)
-
     int ls = wls[wlk];                       // active lattice, 1-based
     double ls_mu = wmu[wlk];
-    double men[2] = {energy[box0], L == 2 ? energy[box0 + 1] : 0.0};
-    unsigned long long acc = 0;
-
-    for (int mv = 0; mv < nmoves; ++mv) {
-        // six uniforms: lanes 0..2 run one Philox call each, the values are broadcast
-        double ua = 0.0, ub = 0.0;
-        if (lane < 4) {
-            const unsigned long long m = move0 + (unsigned long long)mv;
-            uint32_t c[4] = {(uint32_t)m, (uint32_t)(m >> 32), (uint32_t)wlk, (uint32_t)lane};
-            philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-            ua = u53(c[0], c[1]); ub = u53(c[2], c[3]);
+    double men0 = energy[box0], men1 = L == 2 ? energy[box0 + 1] : 0.0;
+    int k_cur = 0; bool k_valid = false;     // bin of ls_mu, carried from move to move
+    double lgv12 = 0.0, lgv21 = 0.0;         // log(V1/V2), log(V2/V1): change with volume moves only
+    double cur_min = 0.0;                    // minimum of the weights over the walker's window (0 after the first update)
+    const bool wl_on = L == 2 && sp.record && !sp.samplerun;
+    if (L == 2) {
+        lgv12 = log(svol[0] / svol[1]); lgv21 = log(svol[1] / svol[0]);
+        if (wl_on) {
+            double mn = 1.7976931348623157e308;
+            for (int b = mg.start_bin - 1 + lane; b < mg.end_bin; b += 64) { const double w = sweight[b]; mn = w < mn ? w : mn; }
+            cur_min = readlane_f64(dpp_wave_min(mn), 63);
         }
-        const double u0 = readlane_f64(ua, 0), u1 = readlane_f64(ub, 0), u2 = readlane_f64(ua, 1);
-        const double u3 = readlane_f64(ub, 1), u4 = readlane_f64(ua, 2), u5 = readlane_f64(ub, 2);
-        const double u6 = readlane_f64(ua, 3);          // lattice-switch variate (mc_moves.F90:1576)
-        const double u7 = readlane_f64(ub, 3);          // move type (mc_moves.F90:226)
-        int cyc = 0;                                                   // mc_cycle_num of this move ('dd' only)
-        if (sp.dd) {
-            const unsigned long long mg = move0 + (unsigned long long)mv;
-            cyc = (int)(mg / (unsigned long long)N) + 1;
-            if (mg % (unsigned long long)N == 0ull) {                  // top of a cycle: the equilibration check of mc_cycle (:181-210)
-                if (cyc < sp.eq_cycles) sp.in_window = (ls_mu > sp.mu_lo && ls_mu < sp.mu_hi) ? 1 : 0;
-                else if (cyc == sp.eq_cycles) { if (!sp.in_window) flag |= 2; }     // "Not all walkers have reached their designated window"
-                else sp.in_window = 1;                                 // a restart
+    }
+    // mc_cycle_num of the next move and its place inside the cycle ('dd' only: the equilibration rules, :181-210)
+    int cyc = 0, within = 0;
+    if (sp.dd) { cyc = (int)(move0 / (unsigned long long)N) + 1; within = (int)(move0 % (unsigned long long)N); }
+
+    // mc_lattice_switch's exponent for a walker in lattice lsx with energies E0, E1 (:1557-1572), less new_eta - old_eta
+    auto switch_dk = [&](double E0, double E1, int lsx) {
+        const double Els = lsx == 1 ? E0 : E1, Elsn = lsx == 1 ? E1 : E0;
+        const double V1 = svol[0], V2 = svol[1];
+        const double Vls = lsx == 1 ? V1 : V2, Vlsn = lsx == 1 ? V2 : V1;
+        double dk;
+        if (sp.npt) dk = sp.beta * Elsn - sp.beta * Els + sp.beta * sp.pressure * (Vlsn - Vls) - (double)N * (lsx == 1 ? lgv21 : lgv12);
+        else        dk = sp.beta * Elsn - sp.beta * Els;
+        return dk + (lsx == 1 ? sp.beta * sp.dref : -(sp.beta * sp.dref));   // leshift: - beta ref(lsn) + beta ref(ls), :1567,1572
+    };
+    // What follows EITHER move type (wavefront 0): mc_update_wl_bins (:1597-1689) on the walker's tables, then one
+    // mc_lattice_switch attempt (:1536-1594).  eta_fin = eta_weight(ls_mu) with the weights as the move found them,
+    // cmp_sw = exp(-dk) of the switch without its eta terms, ufac = exp(eta_fin - log_unbiased_norm); k_cur = bin of ls_mu.
+    auto post_move = [&](double eta_fin, double cmp_sw, double ufac, bool do_switch, double u6) -> int {
+        int sw = 0;
+        if (sp.record) {                                                          // mc_update_wl_bins, :1597-1689
+            const int k = k_cur;
+            if (k >= 1 && k <= sp.nbins) {
+                const double bwk = sbw[k - 1];
+                if (sp.samplerun) {
+                    if (lane == 0) {
+                        shist[k - 1] = shist[k - 1] + sp.av_binwidth / bwk;                       // :1621
+                        suhist[k - 1] = suhist[k - 1] + (sp.av_binwidth / bwk) * ufac;            // :1627-1629
+                    }
+                } else {
+                    if (sp.swetnam) {                                             // :1636-1653
+                        sumh = sumh + 1.0;
+                        double a2 = 0.0;
+                        const double span = sp.mu_max - sp.mu_min - 1.0;
+                        for (int b = lane; b < sp.nbins; b += 64) {
+                            const double hb = shist[b] + (b == k - 1 ? sp.av_binwidth / bwk : 0.0);    // this move's visit is already counted (:1621)
+                            const double dev = hb * sbw[b] / sumh - sbw[b] / span;
+                            a2 += dev * dev;
+                        }
+                        a2 = readlane_f64(dpp_wave_sum(a2), 63);
+                        double f = sqrt(a2 / (double)sp.nbins);
+                        f = log(f) * sp.wl_alpha * (double)sp.nbins;
+                        wlf = f < sp.orig_wl_factor ? f : sp.orig_wl_factor;
+                    }
+                    // weight(k) += av_binwidth*wl_factor/binwidth(k) -- whichever bin k is (:1680); then the minimum over the
+                    // walker's window is subtracted inside the window (:1682-1685; with 'dd' windows k may lie outside).
+                    // The minimum is TRACKED: it is 0 after the first update, and it only moves when the visited bin was
+                    // (one of) the lowest -- then, and only then, the window is scanned.
+                    const double inc = sp.av_binwidth * wlf / bwk;
+                    const double wk = sweight[k - 1];
+                    const bool k_in = k >= mg.start_bin && k <= mg.end_bin;
+                    double mn;
+                    bool scan = false;
+                    if (!k_in) mn = cur_min;
+                    else if (wk > cur_min) { const double wn = wk + inc; mn = wn < cur_min ? wn : cur_min; }
+                    else { scan = true; mn = 1.7976931348623157e308; }
+                    if (scan) {
+                        for (int b = mg.start_bin - 1 + lane; b < mg.end_bin; b += 64) {
+                            double w = sweight[b];
+                            if (b == k - 1) w = w + inc;
+                            mn = w < mn ? w : mn;
+                        }
+                        mn = readlane_f64(dpp_wave_min(mn), 63);
+                    }
+                    wave_sync();
+                    if (mn != 0.0) {
+                        for (int b = mg.start_bin - 1 + lane; b < mg.end_bin; b += 64) {
+                            double w = sweight[b];
+                            if (b == k - 1) w = w + inc;
+                            sweight[b] = w - mn;
+                        }
+                        if (lane == 0 && !k_in) sweight[k - 1] = sweight[k - 1] + inc;
+                    } else if (lane == 0) {
+                        sweight[k - 1] = k_in ? (wk + inc) - mn : wk + inc;
+                    }
+                    cur_min = 0.0;                                                // the lowest bin of the window is now exactly mn - mn
+                    gauge += mn;
+                    if (lane == 0) shist[k - 1] = shist[k - 1] + sp.av_binwidth / bwk;
+                }
+                wave_sync();
             }
         }
-        const bool is_volume = WITHVOL && !(u7 < sp.transP);    // WITHVOL = false: translation-only build, no call, lean registers
-        bool ok = false;
-        double eo[2] = {0.0, 0.0}, en[2] = {0.0, 0.0}, diffkT = 0.0;
-        int imol = 0;
-        if (is_volume) {                                                          // mc_moves.F90:232-235
-            int rv = 0;
-            if constexpr (WITHVOL) rv = volume_move_wave(vc, sp, weight, mu_bin, binwidth, u0, u1, u2, u3, ls, ls_mu, men, lane);
-            ++nvol_try;
-            if (rv == 1) ++nvol_acc;
-            if (rv < 0) flag |= 1;
-            ok = rv == 1;
-        } else {
-        const int lsn = L == 2 ? 3 - ls : 1;
-        imol = (int)(u0 * (double)N) + 1;                                        // mc_moves.F90:1001-1002
-        imol = imol > N ? N : imol;
-        const int i = imol - 1;
-        double x = 2.0 * u1 - 1.0, y = 2.0 * u2 - 1.0, z = 2.0 * u3 - 1.0;        // :1021-1027
-        const double norm = 1.0 / sqrt(x * x + y * y + z * z);                    // :1029
-        x *= norm; y *= norm; z *= norm;
-        const double r = u4 * 2.0 - 1.0;                                          // :1035
-        x = x * sp.max_trans * r; y = y * sp.max_trans * r; z = z * sp.max_trans * r;
-        const double* rc = srecip[ls - 1];
-        double sx = MW_HM(rc,1,1) * x + MW_HM(rc,2,1) * y + MW_HM(rc,3,1) * z;    // :1042-1050
-        double sy = MW_HM(rc,1,2) * x + MW_HM(rc,2,2) * y + MW_HM(rc,3,2) * z;
-        double sz = MW_HM(rc,1,3) * x + MW_HM(rc,2,3) * y + MW_HM(rc,3,3) * z;
-        sx = sx * 0.5 * invPi; sy = sy * 0.5 * invPi; sz = sz * 0.5 * invPi;      // :1052-1054
-        double tv[2][3] = {{x, y, z}, {x, y, z}};                                  // move in the active lattice
-        if (L == 2) {                                                             // :1061-1067
-            const double* hn = shmat[lsn - 1];
-            const double mx = MW_HM(hn,1,1) * sx + MW_HM(hn,1,2) * sy + MW_HM(hn,1,3) * sz;
-            const double my = MW_HM(hn,2,1) * sx + MW_HM(hn,2,2) * sy + MW_HM(hn,2,3) * sz;
-            const double mz = MW_HM(hn,3,1) * sx + MW_HM(hn,3,2) * sy + MW_HM(hn,3,3) * sz;
-            if (lsn == 1) { tv[0][0] = mx; tv[0][1] = my; tv[0][2] = mz; }         // static indices only
-            else          { tv[1][0] = mx; tv[1][1] = my; tv[1][2] = mz; }
+        if (do_switch) {
+            // new_eta - old_eta of the switch (:1557-1558) = eta_weight(ls_mu) - eta_weight(ls_mu) with the weights as they are
+            // NOW: 0 unless that weight is not finite
+            double deta;
+            if (sp.samplerun || !sp.record) deta = eta_fin - eta_fin;
+            else {
+                const int k = k_cur < 2 ? 2 : (k_cur > sp.nbins - 1 ? sp.nbins - 1 : k_cur);
+                const double wa = fabs(sweight[k - 2]), wb = fabs(sweight[k - 1]), wc = fabs(sweight[k]);
+                if (wa < 1.0e150 && wb < 1.0e150 && wc < 1.0e150) deta = 0.0;     // finite weights interpolate to a finite weight
+                else { const double ew = lane_eta(mg, sweight, smub, sbw, ls_mu, k_cur); deta = ew - ew; }
+            }
+            double cmp = deta == 0.0 ? cmp_sw : deta;                             // exp(-(dk + deta)), dk + 0 = dk
+            cmp = cmp > 1.0 ? 1.0 : cmp;
+            if (u6 < cmp) {
+                const double V1 = svol[0], V2 = svol[1];
+                double mu = (men0 + sp.pressure * V1) - (men1 + sp.pressure * V2);          // :1581-1583
+                mu = mu - sp.dref;                                                          // :1584 (leshift)
+                mu = mu * sp.beta - (double)N * lgv12;
+                ls_mu = mu; ls = 3 - ls; sw = 1; ++nsw; k_valid = false;
+            }
         }
+        return sw;
+    };
 
-        double pn[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-#pragma unroll
-        for (int l = 0; l < 2; ++l) if (l < L) {                                  // :1007-1018, 1076-1092
-            const double* P = pos + (size_t)(box0 + l) * N * 3;
+    for (int mv = 0; mv < nmoves; ++mv) {
+        const int ub = mv & (kUB - 1);
+        if (ub == 0) {
+            // the next kUB moves' random numbers: Philox call c of move m is thread 4 m + c (the same stream as the
+            // oracle's mwo_move_uniforms: counter (move lo, move hi, walker, call), key = seed), then per move its
+            // molecule (mc_moves.F90:1001-1002) and its displacement in the active lattice (:1021-1039)
+            wg_sync<NLAT>();                                       // (the previous batch has been consumed)
+            for (int c = tid; c < 4 * kUB; c += NTHR) {
+                const unsigned long long m = move0 + (unsigned long long)(mv + (c >> 2));
+                uint32_t ctr[4] = {(uint32_t)m, (uint32_t)(m >> 32), (uint32_t)wlk, (uint32_t)(c & 3)};
+                philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+                suni[(c >> 2) * 8 + 2 * (c & 3)] = u53(ctr[0], ctr[1]);
+                suni[(c >> 2) * 8 + 2 * (c & 3) + 1] = u53(ctr[2], ctr[3]);
+            }
+            wg_sync<NLAT>();
+            if (tid < kUB) {
+                const double* u = suni + tid * 8;
+                int im = (int)(u[0] * (double)N) + 1;                                     // :1001-1002
+                im = im > N ? N : im;
+                double x = 2.0 * u[1] - 1.0, y = 2.0 * u[2] - 1.0, z = 2.0 * u[3] - 1.0;  // :1021-1027
+                const double norm = 1.0 / sqrt(x * x + y * y + z * z);                    // :1029
+                x *= norm; y *= norm; z *= norm;
+                const double r = u[4] * 2.0 - 1.0;                                        // :1035
+                smv[tid * 4] = x * max_trans * r; smv[tid * 4 + 1] = y * max_trans * r; smv[tid * 4 + 2] = z * max_trans * r;
+                smv[tid * 4 + 3] = __longlong_as_double((long long)im);
+            }
+            wg_sync<NLAT>();
+        }
+        const double* U = suni + ub * 8;     // u0..u7: molecule, direction x3, length, acceptance, lattice switch (:1576), move type (:226)
+        if (sp.dd && wv == 0 && within == 0) {                     // top of a cycle: the equilibration check of mc_cycle (:181-210)
+            if (cyc < sp.eq_cycles) mg.in_window = (ls_mu > mg.mu_lo && ls_mu < mg.mu_hi) ? 1 : 0;
+            else if (cyc == sp.eq_cycles) { if (!mg.in_window) flag |= 2; }     // "Not all walkers have reached their designated window"
+            else mg.in_window = 1;                                 // a restart
+        }
+        const bool do_switch = L == 2 && sp.always_switch && !(sp.dd && cyc < sp.eq_cycles);   // (:243-248: not while a 'dd' run equilibrates)
+        const bool is_volume = WITHVOL && !(U[7] < sp.transP);    // WITHVOL = false: translation-only build
+        bool ok = false;
+        int sw = 0, imol = 0;
+        double eo0 = 0.0, en0 = 0.0, eo1 = 0.0, en1 = 0.0, diffkT = 0.0;     // (the move log's columns)
+
+        if (is_volume) {                                                          // mc_moves.F90:232-235
+            if constexpr (WITHVOL) {
+                const double Vo0 = svol[0], Vo1 = L == 2 ? svol[1] : 0.0;
+                auto decide = [&](double e0n, double e1n, int anybad) -> int {
+                    // wavefront 0: mc_volume's acceptance (:1361-1410) and, on rejection, the restored order parameter (:1514-1530)
+                    const double bk0 = men0, bk1 = men1;
+                    int okv = 0;
+                    if (!anybad) {
+                        men0 = e0n; men1 = e1n;
+                        const double Vn0 = svol[0], Vn1 = L == 2 ? svol[1] : 0.0;
+                        const double dE = (ls == 1 ? e0n - bk0 : e1n - bk1);                                 // :1361
+                        const double Vls = ls == 1 ? Vn0 : Vn1, Vold = ls == 1 ? Vo0 : Vo1;
+                        double old_eta = 0.0, new_eta = 0.0;
+                        if (L == 2) {                                                                        // :1363-1371
+                            double mu = (men0 + sp.pressure * Vn0) - (men1 + sp.pressure * Vn1);
+                            mu = mu - sp.dref;                                                               // :1371 (leshift)
+                            mu = mu * sp.beta - (double)N * log(Vn0 / Vn1);
+                            const double mul = lane == 0 ? ls_mu : mu;
+                            const double el = lane_eta(mg, sweight, smub, sbw, mul, lane_mu_to_bin(mg, mul));
+                            old_eta = readlane_f64(el, 0); new_eta = readlane_f64(el, 1);
+                            ls_mu = mu;
+                        }
+                        diffkT = sp.beta * dE + new_eta - old_eta + sp.beta * sp.pressure * (Vls - Vold)
+                                 - (double)N * log(Vls / Vold);                                              // :1381-1382
+                        int minu_ls = ls;
+                        if (sp.minu && L == 2)                                                               // :1385-1401
+                            minu_ls = dev_minu_branch(sp, ls, men0, men1, Vn0, Vn1, ls == 1 ? bk0 : bk1, Vold, true, N,
+                                                      new_eta, old_eta, diffkT);
+                        double cmp = exp(-diffkT);
+                        cmp = cmp > 1.0 ? 1.0 : cmp;
+                        okv = U[3] < cmp ? 1 : 0;                                                            // :1410
+                        if (okv) ls = minu_ls;                                                               // :1426-1429
+                    }
+                    if (!okv) {
+                        men0 = bk0; men1 = bk1;                                                              // :1514
+                        if (L == 2) {                                                                        // :1516-1520 (the OLD cells)
+                            double mu = (men0 + sp.pressure * Vo0) - (men1 + sp.pressure * Vo1);
+                            mu = mu - sp.dref;                                                               // :1526 (leshift)
+                            mu = mu * sp.beta - (double)N * log(Vo0 / Vo1);
+                            ls_mu = mu;
+                        }
+                    }
+                    return okv;
+                };
+                const int rv = volume_move_wg<NLAT>(vc, U, dv_max, wv, lane, sx, sdec, decide);
+                ++nvol_try;
+                if (rv == 1) ++nvol_acc;
+                if (rv < 0) flag |= 1;
+                ok = rv == 1;
+                k_valid = false;
+                if (L == 2 && wv == 0) {
+                    lgv12 = log(svol[0] / svol[1]); lgv21 = log(svol[1] / svol[0]);
+                    if (sp.record || do_switch) {                      // the same update and switch attempt as after a translation
+                        const int kl = lane_mu_to_bin(mg, ls_mu);
+                        k_cur = __builtin_amdgcn_readlane(kl, 0); k_valid = true;
+                        const double eta_fin = readlane_f64(lane_eta(mg, sweight, smub, sbw, ls_mu, k_cur), 0);
+                        const double dk = do_switch ? switch_dk(men0, men1, ls) : 0.0;
+                        const double ex = exp(lane == 0 ? -dk : eta_fin - sp.log_unbiased_norm);
+                        sw = post_move(eta_fin, readlane_f64(ex, 0), readlane_f64(ex, 1), do_switch, U[6]);
+                    }
+                    if (lane == 0) sdec[1] = ls;
+                }
+                if (L == 2) { wg_sync<NLAT>(); ls = sdec[1]; }     // (MINU may have changed the active lattice)
+            }
+        } else {
+            // ---- translation: this wavefront's lattice ------------------------------------------------------------
+            const double* MV = smv + ub * 4;
+            const double x = MV[0], y = MV[1], z = MV[2];
+            imol = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(MV[3]));
+            const int i = imol - 1;
+            const int l = wv;
+            double tx = x, ty = y, tz = z;                                            // the move in the active lattice
+            if (L == 2 && l != ls - 1) {                                              // mapped into the partner lattice, :1042-1067
+                const double* rc = srecip[ls - 1];
+                double sxf = MW_HM(rc,1,1) * x + MW_HM(rc,2,1) * y + MW_HM(rc,3,1) * z;    // :1042-1050
+                double syf = MW_HM(rc,1,2) * x + MW_HM(rc,2,2) * y + MW_HM(rc,3,2) * z;
+                double szf = MW_HM(rc,1,3) * x + MW_HM(rc,2,3) * y + MW_HM(rc,3,3) * z;
+                sxf = sxf * 0.5 * invPi; syf = syf * 0.5 * invPi; szf = szf * 0.5 * invPi;  // :1052-1054
+                const double* hn = shmat[l];
+                tx = MW_HM(hn,1,1) * sxf + MW_HM(hn,1,2) * syf + MW_HM(hn,1,3) * szf;
+                ty = MW_HM(hn,2,1) * sxf + MW_HM(hn,2,2) * syf + MW_HM(hn,2,3) * szf;
+                tz = MW_HM(hn,3,1) * sxf + MW_HM(hn,3,2) * syf + MW_HM(hn,3,3) * szf;
+            }
+            double* P = pos + (size_t)(box0 + l) * N * 3;                             // :1007-1018, 1076-1092
             const uint32_t* LM = listm + (size_t)(box0 + l) * N * kRow;
             const int* NN = nn + (size_t)(box0 + l) * N;
             const double* IVl = siv + (size_t)l * ivcap * 3;
@@ -554,151 +786,120 @@ void k_sweep_translation(double* pos, double* hmat, double* ivect,
             auto getpos = [&](int j, double& a, double& b, double& c) { const double* p = Pl + 3 * (size_t)j; a = p[0]; b = p[1]; c = p[2]; };
             double xo, yo, zo;
             getpos(i, xo, yo, zo);
-            pn[l][0] = xo + tv[l][0]; pn[l][1] = yo + tv[l][1]; pn[l][2] = zo + tv[l][2];   // :1079
-            const uint32_t* SR = srow + (size_t)l * N * rstride;
-            const int* SN = snn + l * N;
-            auto row = [&](int jx, int sl) { return LDSLIST ? SR[jx * rstride + sl] : LM[(size_t)jx * kRow + sl]; };
-            auto nnof = [&](int jx) { return LDSLIST ? SN[jx] : NN[jx]; };
+            const double pnx = xo + tx, pny = yo + ty, pnz = zo + tz;                 // :1079
+            const unsigned short* SR = srow + (size_t)l * N * rstride;
+            const unsigned char* SN = snn + l * N;
+            auto row = [&](int jx, int sl) -> uint32_t {
+                if constexpr (LDSLIST) { const uint32_t e = SR[jx * rstride + sl]; return (e & 63u) | ((e >> 6) << kJBits); }
+                else return LM[(size_t)jx * kRow + sl];
+            };
+            auto nnof = [&](int jx) { return LDSLIST ? (int)SN[jx] : NN[jx]; };
             MoveRes res;
-            const bool fast = move_energy_wave(getpos, getiv, row, nnof, &ws, sniv[l], i, nnof(i), row(i, lane & 31), xo, yo, zo,
-                                               pn[l][0], pn[l][1], pn[l][2], lane, res);
+            const bool fast = move_energy_wave(getpos, getiv, row, nnof, ws, sniv[l], i, nnof(i), row(i, lane & 31), xo, yo, zo,
+                                               pnx, pny, pnz, lane, res);
             if (!fast) {
                 Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
-                Override tr; tr.idx = i; tr.x = pn[l][0]; tr.y = pn[l][1]; tr.z = pn[l][2];
+                Override tr; tr.idx = i; tr.x = pnx; tr.y = pny; tr.z = pnz;
                 res.eo = local_energy_wave(P, ivect + (size_t)(box0 + l) * ivcap * 3, LM, NN, i, none, none, lane, res.io, res.so);
                 res.en = local_energy_wave(P, ivect + (size_t)(box0 + l) * ivcap * 3, LM, NN, i, tr, none, lane, res.in_, res.sn);
             }
-            eo[l] = res.eo; en[l] = res.en;
-        }
-        const double dE0 = en[0] - eo[0], dE1 = en[1] - eo[1];                    // :1090
-        const double bk0 = men[0], bk1 = men[1];                                  // :1013
-        men[0] = (men[0] - eo[0]) + en[0];                                        // :1016,1087
-        men[1] = (men[1] - eo[1]) + en[1];
-        int minu_ls = ls;
-        if (L == 1) {
-            diffkT = sp.beta * dE0;                                               // :1106
-        } else {
-            const double eta_old = dev_eta_weight(sp, weight, mu_bin, binwidth, ls_mu);   // :1112-1116
-            ls_mu = ls_mu + (dE0 - dE1) * sp.beta;
-            const double eta_new = dev_eta_weight(sp, weight, mu_bin, binwidth, ls_mu);
-            diffkT = (ls == 1 ? dE0 : dE1) * sp.beta + eta_new - eta_old;
-            if (sp.minu)                                                          // :1119-1140
-                minu_ls = dev_minu_branch(sp, ls, men[0], men[1], svol[0], svol[1], ls == 1 ? bk0 : bk1, ls == 1 ? svol[0] : svol[1],
-                                          sp.npt != 0, N, eta_new, eta_old, diffkT);
-        }
-        double pacc = exp(-diffkT);
-        pacc = pacc > 1.0 ? 1.0 : pacc;
-        ok = u5 < pacc;                                                           // :1145-1146 (false for NaN)
-        if (ok) {
-            ++acc;
-            ls = minu_ls;                                                         // :1168-1170
-            if (lane == 0) {
-#pragma unroll
-                for (int l = 0; l < 2; ++l) if (l < L) {
-                    double* P = pos + ((size_t)(box0 + l) * N + i) * 3;
-                    P[0] = pn[l][0]; P[1] = pn[l][1]; P[2] = pn[l][2];
-                    if (LDSPOS) {
-                        double* S = spos + ((size_t)l * N + i) * 3;
-                        S[0] = pn[l][0]; S[1] = pn[l][1]; S[2] = pn[l][2];
-                    }
-                }
+            if (L == 2) {
+                if (wv == 1 && lane == 0) { sx[0] = res.eo; sx[1] = res.en; }
+                __syncthreads();
             }
-        } else {                                                                  // :1182-1195
-            men[0] = bk0; men[1] = bk1;
-            if (L == 2) ls_mu = ls_mu - (dE0 - dE1) * sp.beta;
-        }
-        }   // translation
-        // the next move of this wavefront must see the committed position (and the weights written below)
-        int sw = 0;
-        if (L == 2 && sp.record) {                                                // mc_update_wl_bins, :1597-1689
-            const int k = dev_mu_to_bin(sp, ls_mu);
-            if (k >= 1 && k <= sp.nbins) {
-                const double bwk = binwidth[k - 1];
-                if (sp.samplerun) {
-                    const double etaw = dev_eta_weight(sp, weight, mu_bin, binwidth, ls_mu);
-                    if (lane == 0) {
-                        hist[k - 1] = hist[k - 1] + sp.av_binwidth / bwk;                        // :1621
-                        uhist[k - 1] = uhist[k - 1] + (sp.av_binwidth / bwk) * exp(etaw - sp.log_unbiased_norm);   // :1627-1629
-                    }
+            if (wv == 0) {
+                // ---- the decision (wavefront 0), :1090-1209 ---------------------------------------------------------
+                eo0 = res.eo; en0 = res.en;
+                if (L == 2) { eo1 = sx[0]; en1 = sx[1]; }
+                const double dE0 = en0 - eo0, dE1 = en1 - eo1;                            // :1090
+                const double bk0 = men0, bk1 = men1;                                      // :1013
+                const double mn0 = (men0 - eo0) + en0, mn1 = (men1 - eo1) + en1;          // :1016,1087
+                int minu_ls = ls;
+                double mu_new = 0.0, mu_rev = 0.0, eta_new = 0.0, eta_rev = 0.0;
+                int k_new = 0, k_rev = 0;
+                if (L == 1) {
+                    diffkT = sp.beta * dE0;                                               // :1106
                 } else {
-                    if (sp.swetnam) {                                             // :1636-1653
-                        sumh = sumh + 1.0;
-                        double acc = 0.0;
-                        const double span = sp.mu_max - sp.mu_min - 1.0;
-                        for (int b = lane; b < sp.nbins; b += 64) {
-                            const double hb = hist[b] + (b == k - 1 ? sp.av_binwidth / bwk : 0.0);    // this move's visit is already counted (:1621)
-                            const double dev = hb * binwidth[b] / sumh - binwidth[b] / span;
-                            acc += dev * dev;
-                        }
-                        acc = readlane_f64(dpp_wave_sum(acc), 63);
-                        double f = sqrt(acc / (double)sp.nbins);
-                        f = log(f) * sp.wl_alpha * (double)sp.nbins;
-                        wlf = f < sp.orig_wl_factor ? f : sp.orig_wl_factor;
+                    {
+#pragma clang fp contract(off)
+                        const double d = (dE0 - dE1) * sp.beta;                           // :1114 ... and what :1192 takes off again
+                        mu_new = ls_mu + d;
+                        mu_rev = mu_new - d;
                     }
-                    // weight(k) += av_binwidth*wl_factor/binwidth(k) -- whichever bin k is (:1680); then the minimum over the
-                    // walker's window is subtracted inside the window (:1682-1685; with 'dd' windows k may lie outside)
-                    const double inc = sp.av_binwidth * wlf / bwk;
-                    double mn = 1.7976931348623157e308;
-                    for (int b = sp.start_bin - 1 + lane; b < sp.end_bin; b += 64) {
-                        double w = weight[b];
-                        if (b == k - 1) w = w + inc;
-                        mn = w < mn ? w : mn;
-                    }
-                    mn = readlane_f64(dpp_wave_min(mn), 63);
-                    for (int b = sp.start_bin - 1 + lane; b < sp.end_bin; b += 64) {
-                        double w = weight[b];
-                        if (b == k - 1) w = w + inc;
-                        weight[b] = w - mn;
-                    }
-                    if (lane == 0 && (k < sp.start_bin || k > sp.end_bin)) weight[k - 1] = weight[k - 1] + inc;
-                    gauge += mn;
-                    if (lane == 0) hist[k - 1] = hist[k - 1] + sp.av_binwidth / bwk;
+                    // lanes 0, 1, 2: the trial value, the value a rejection restores, the current one (its bin is carried)
+                    const double mul = lane == 0 ? mu_new : (lane == 1 ? mu_rev : ls_mu);
+                    int kl = lane_mu_to_bin(mg, mul);
+                    if (k_valid && lane >= 2) kl = k_cur;
+                    const double el = lane_eta(mg, sweight, smub, sbw, mul, kl);          // :1112-1116
+                    eta_new = readlane_f64(el, 0); eta_rev = readlane_f64(el, 1);
+                    const double eta_old = readlane_f64(el, 2);
+                    k_new = __builtin_amdgcn_readlane(kl, 0); k_rev = __builtin_amdgcn_readlane(kl, 1);
+                    diffkT = (ls == 1 ? dE0 : dE1) * sp.beta + eta_new - eta_old;
+                    if (sp.minu)                                                          // :1119-1140
+                        minu_ls = dev_minu_branch(sp, ls, mn0, mn1, svol[0], svol[1], ls == 1 ? bk0 : bk1, ls == 1 ? svol[0] : svol[1],
+                                                  sp.npt != 0, N, eta_new, eta_old, diffkT);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                // the move's exponentials in one stream: lane 0 the acceptance; lanes 1, 2 the lattice switch that follows an
+                // accepted / a rejected move (mc_lattice_switch, :1536-1594); lanes 3, 4 the unbiased histogram's factor (:1627-1629)
+                double dkA = 0.0, dkR = 0.0;
+                if (do_switch) {
+                    dkA = switch_dk(mn0, mn1, minu_ls);
+                    dkR = switch_dk(bk0, bk1, ls);
+                }
+                const double xarg = lane == 0 ? -diffkT : (lane == 1 ? -dkA : (lane == 2 ? -dkR
+                                    : (lane == 3 ? eta_new - sp.log_unbiased_norm : eta_rev - sp.log_unbiased_norm)));
+                const double ex = exp(xarg);
+                double pacc = readlane_f64(ex, 0);
+                pacc = pacc > 1.0 ? 1.0 : pacc;
+                ok = U[5] < pacc;                                                         // :1145-1146 (false for NaN)
+                double eta_fin, cmp_sw, ufac;
+                if (ok) {
+                    ++acc;
+                    ls = minu_ls;                                                         // :1168-1170
+                    men0 = mn0; men1 = mn1;
+                    if (L == 2) { ls_mu = mu_new; k_cur = k_new; k_valid = true; }
+                    eta_fin = eta_new; cmp_sw = readlane_f64(ex, 1); ufac = readlane_f64(ex, 3);
+                } else {                                                                  // :1182-1195
+                    if (L == 2) { ls_mu = mu_rev; k_cur = k_rev; k_valid = true; }
+                    eta_fin = eta_rev; cmp_sw = readlane_f64(ex, 2); ufac = readlane_f64(ex, 4);
+                }
+                if (L == 2) sw = post_move(eta_fin, cmp_sw, ufac, do_switch, U[6]);
+                if (L == 2 && lane == 0) { sdec[0] = ok ? 1 : 0; sdec[1] = ls; }
             }
-        }
-        if (L == 2 && sp.always_switch && !(sp.dd && cyc < sp.eq_cycles)) {      // mc_lattice_switch, :1536-1594 (:243-248: not while a 'dd' run equilibrates)
-            const int lsw = 3 - ls;
-            const double eta_w = dev_eta_weight(sp, weight, mu_bin, binwidth, ls_mu);
-            const double deta = eta_w - eta_w;                                    // new_eta - old_eta, :1557-1558
-            const double Els = ls == 1 ? men[0] : men[1], Elsn = ls == 1 ? men[1] : men[0];
-            const double V1 = svol[0], V2 = svol[1];
-            const double Vls = ls == 1 ? V1 : V2, Vlsn = ls == 1 ? V2 : V1;
-            double dk;
-            if (sp.npt) dk = sp.beta * Elsn - sp.beta * Els + sp.beta * sp.pressure * (Vlsn - Vls) - (double)N * log(Vlsn / Vls) + deta;
-            else        dk = sp.beta * Elsn - sp.beta * Els + deta;
-            dk = dk + (ls == 1 ? sp.beta * sp.dref : -(sp.beta * sp.dref));       // leshift: - beta ref(lsn) + beta ref(ls), :1567,1572
-            double cmp = exp(-dk);
-            cmp = cmp > 1.0 ? 1.0 : cmp;
-            if (u6 < cmp) {
-                double mu = (men[0] + sp.pressure * V1) - (men[1] + sp.pressure * V2);          // :1581-1583
-                mu = mu - sp.dref;                                                              // :1584 (leshift)
-                mu = mu * sp.beta - (double)N * log(V1 / V2);
-                ls_mu = mu; ls = lsw; sw = 1; ++nsw;
+            if (L == 2) {
+                __syncthreads();
+                ok = sdec[0] != 0; ls = sdec[1];
             }
-        }
-        if (mvlog && lane == 0) {
+            if (ok && lane == 0) {                                                        // :1150-1170: this wavefront's lattice
+                P[3 * i] = pnx; P[3 * i + 1] = pny; P[3 * i + 2] = pnz;
+                if (LDSPOS) { double* Sp = spos + ((size_t)l * N + i) * 3; Sp[0] = pnx; Sp[1] = pny; Sp[2] = pnz; }
+            }
+        }   // translation
+        if (mvlog && wv == 0 && lane == 0) {
             double* q = mvlog + ((size_t)blockIdx.x * nmoves + mv) * 8;
-            if (is_volume) { eo[0] = men[0]; en[0] = svol[0]; eo[1] = L == 2 ? men[1] : 0.0; en[1] = L == 2 ? svol[1] : 0.0; }
-            q[0] = (double)imol; q[1] = (ok ? 1.0 : 0.0) + 2.0 * sw + (is_volume ? 4.0 : 0.0); q[2] = eo[0]; q[3] = en[0]; q[4] = eo[1]; q[5] = en[1]; q[6] = ls_mu; q[7] = diffkT;
+            if (is_volume) { eo0 = men0; en0 = svol[0]; eo1 = L == 2 ? men1 : 0.0; en1 = L == 2 ? svol[1] : 0.0; }
+            q[0] = (double)imol; q[1] = (ok ? 1.0 : 0.0) + 2.0 * sw + (is_volume ? 4.0 : 0.0); q[2] = eo0; q[3] = en0; q[4] = eo1; q[5] = en1; q[6] = ls_mu; q[7] = diffkT;
         }
+        if (sp.dd) { if (++within == N) { within = 0; ++cyc; } }
         // the next move of this wavefront must see the committed position
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wave_sync();
     }
-    if (L == 2 && sp.record && !sp.samplerun)
-        for (int t = lane; t < sp.nbins; t += 64) wweight[(size_t)wlk * sp.nbins + t] = sweight[t];
-    if (lane == 0) {
+    __syncthreads();
+    if (L == 2 && sp.record) {
+        for (int t = tid; t < sp.nbins; t += NTHR) {
+            if (!sp.samplerun) wweight[(size_t)wlk * sp.nbins + t] = sweight[t];
+            whist[(size_t)wlk * sp.nbins + t] = shist[t];
+            if (sp.samplerun) wuhist[(size_t)wlk * sp.nbins + t] = suhist[t];
+        }
+    }
+    if (tid == 0) {
         wls[wlk] = ls; wmu[wlk] = ls_mu; wacc[wlk] += acc; wswitch[wlk] += nsw; wshift[wlk] += gauge;
         wvol[2 * wlk] += nvol_try; wvol[2 * wlk + 1] += nvol_acc;
         if (flag) wflag[wlk] |= flag;                       // bit 0: image-vector table outgrown, bit 1: 'dd' walker not in its window at eq_mc_cycles
         if (L == 2) { wfac[wlk] = wlf; wsum[wlk] = sumh; }
-        if (sp.dd) winflag[wlk] = sp.in_window;
-        energy[box0] = men[0];
-        if (L == 2) energy[box0 + 1] = men[1];
+        if (sp.dd) winflag[wlk] = mg.in_window;
+        energy[box0] = men0;
+        if (L == 2) energy[box0 + 1] = men1;
     }
 }
 
