@@ -109,6 +109,17 @@ __device__ __forceinline__ double fast_exp_neg(double x)
     return fast_exp_neg_bounded(__builtin_fmax(x, -800.0));         // exp(-800) == 0 in double anyway
 }
 
+// exp(x) for any x (the Monte Carlo driver's acceptance tests: arguments of either sign and any size): the same reduction
+// and polynomial as above -- 4.5e-16 relative -- with the result's exponent applied by ldexp, which overflows to +inf and
+// underflows through the denormals to 0 as exp itself does; NaN stays NaN.  (The library exp costs the driver ~20 vector
+// registers at its call site -- the difference between three and four wavefronts per SIMD.)
+__device__ __forceinline__ double exp_any(double x)
+{
+    const double xc = __builtin_fmin(__builtin_fmax(x, -746.0), 710.0);
+    const double r = fast_exp_neg_bounded(xc);
+    return x != x ? x : r;
+}
+
 // The two exponentials of an in-range pair from one: with t = exp(0.2 sigma/(r - a sigma)),
 // exp(sigma/(r - a sigma)) = t^5 (molint.F90:291,459) and g = exp(gamma sigma/(r - a sigma)) = t^6 (:292,462).
 // r2 < rc^2 but r rounded onto (or within 1.2e-3 bohr of) rc: both are exactly 0 in double (t < 1e-300), which

@@ -70,7 +70,9 @@ __device__ __forceinline__ uint32_t list_load(ListRsrc rs, uint32_t column_bytes
 // slots at a time and ONE CHUNK AHEAD: `cur` arrives holding this column's first eight entries; while a chunk is
 // being tested the next one -- of this column, or the first of the thread's next column `col_next` -- is already
 // in flight, so the HBM latency of the list stream hides behind the LDS gathers and distance tests.
-template <int BLOCK, bool BATCH4, typename PosFn, typename IvFn>
+// LEAN = true (the Monte Carlo driver's volume moves, where this routine is a guest in a kernel sized for something else):
+// no chunk-ahead list prefetch and no double-buffered gathers -- twenty vector registers fewer, `cur` / `col_next` unused.
+template <int BLOCK, bool BATCH4, bool LEAN = false, typename PosFn, typename IvFn>
 __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32_t col_next, int mol, int n, int nmax, int c0min,
                                                int N, int S, uint32_t* __restrict__ queue, PosFn getpos, IvFn getiv,
                                                uint32_t (&cur)[8])
@@ -82,11 +84,16 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
     int cnt = 0;
     for (int s0 = 0; s0 < nmax || s0 == 0; s0 += 8) {
         uint32_t nxt[8];
-        const bool last = s0 + 8 >= nmax;                     // wave-uniform
-        const uint32_t pc = last ? col_next : col;            // whose chunk comes next
-        const int ps = last ? 0 : s0 + 8;
+        if constexpr (LEAN) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) nxt[u] = list_load(rs, pc, ps + u, N, S);
+            for (int u = 0; u < 8; ++u) cur[u] = list_load(rs, col, s0 + u, N, S);
+        } else {
+            const bool last = s0 + 8 >= nmax;                 // wave-uniform
+            const uint32_t pc = last ? col_next : col;        // whose chunk comes next
+            const int ps = last ? 0 : s0 + 8;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) nxt[u] = list_load(rs, pc, ps + u, N, S);
+        }
         if constexpr (BATCH4) {
         // four slots at a time: their gathers are issued together, then the four tests (a slot past the longest
         // row holds whatever the prefetch brought -- never live, and an LDS gather cannot fault)
@@ -145,8 +152,10 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
             }
         }
         }
+        if constexpr (!LEAN) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+            for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+        }
     }
 
     // phase 2: pair term and moments over the in-range entries only
@@ -173,7 +182,9 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
         Sxy = __builtin_fma(hx, dy, Sxy); Sxz = __builtin_fma(hx, dz, Sxz); Syz = __builtin_fma(hy, dz, Syz);
     };
     const int nq = cnt < kQCap ? cnt : kQCap;
-    if (nq > 0) {
+    if constexpr (LEAN) {
+        for (int q = 0; q < nq; ++q) { double v[6]; gather(queue[q * BLOCK], v); accumulate(v); }
+    } else if (nq > 0) {
         double va[6], vb[6];
         gather(queue[0], va);
         for (int q = 0; q < nq; ++q) {

@@ -42,26 +42,6 @@ struct SweepParams {
     double ref1, ref2;
 };
 
-// The MINU branch of both move types: the lattice the move would end in; diffkT rewritten with the switch's terms if it differs.
-// E = trial energies, V = trial volumes, Eb / Vb = energy and volume of the CURRENT lattice before the move.
-__device__ __forceinline__ int dev_minu_branch(const SweepParams& sp, int ls, double E1, double E2, double V1, double V2,
-                                               double Eb, double Vb, bool vol_terms, int N, double new_eta, double old_eta,
-                                               double& diffkT)
-{
-    const double h1 = E1 + sp.pressure * V1 - sp.ref1, h2 = E2 + sp.pressure * V2 - sp.ref2;   // minloc, :1122-1126
-    const int lsn = h2 < h1 ? 2 : 1;
-    if (lsn != ls) {
-        const double En = lsn == 1 ? E1 : E2, Vn = lsn == 1 ? V1 : V2;
-        double d;
-        if (vol_terms) d = sp.beta * En - sp.beta * Eb + sp.beta * sp.pressure * (Vn - Vb) - (double)N * log(Vn / Vb) + new_eta - old_eta;   // :1131-1133,1396-1397
-        else           d = sp.beta * En - sp.beta * Eb + new_eta - old_eta;                                                                  // :1135
-        if (sp.ref1 != 0.0 || sp.ref2 != 0.0)                                                                                               // leshift, :1134,1136,1398
-            d = d - sp.beta * (lsn == 1 ? sp.ref1 : sp.ref2) + sp.beta * (ls == 1 ? sp.ref1 : sp.ref2);
-        diffkT = d;
-    }
-    return lsn;
-}
-
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
 {
 #pragma unroll
@@ -155,6 +135,7 @@ struct VolCtx {
     double* shmat;            // LDS hmatrix   [2][9]
     double* srecip;           // LDS recip     [2][9]
     double* svol;             // LDS volume    [2]
+    double* sbk;              // LDS backup of a volume move's old cells [2][27]
     double* siv;              // LDS image vectors [L][ivcap][3]
     int* sniv;                // LDS nivect    [2]
     double* hmat_g;           // global mirrors of the above, walker's first box
@@ -250,8 +231,6 @@ __device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, 
     int n_cur = 0, mol = 0;
     uint32_t col = kNoColumn;
     if (lane < c.N) { col = (uint32_t)lane * 4u; n_cur = NNS[lane]; mol = ORD[lane]; }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) cur[u] = list_load(rs, col, u, c.N, c.S);
     for (int base = 0; base < c.N; base += 64) {                 // wave-uniform: one group of 64 list columns per pass
         const bool act = col != kNoColumn;
         const int tn = base + 64 + lane;
@@ -259,7 +238,7 @@ __device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, 
         int n_next = 0, mol_next = 0;
         if (tn < c.N) { col_next = (uint32_t)tn * 4u; n_next = NNS[tn]; mol_next = ORD[tn]; }
         const int cm = __builtin_amdgcn_readfirstlane(CM[base >> 6]);
-        AtomSum a = atom_energy<64, false>(rs, col, col_next, mol, act ? (n_cur & 0xff) : 0, cm & 0xff, cm >> 8, c.N, c.S, c.queue, getpos, getiv, cur);
+        AtomSum a = atom_energy<64, false, true>(rs, col, col_next, mol, act ? (n_cur & 0xff) : 0, cm & 0xff, cm >> 8, c.N, c.S, c.queue, getpos, getiv, cur);
         if (act) esum += a.e;
         n_cur = n_next; mol = mol_next; col = col_next;
     }
@@ -331,9 +310,12 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
 {
     constexpr int L = NLAT;
     const int l = wv;                                                              // this wavefront's lattice
-    double old_h[9], recip_used[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) { old_h[t] = c.shmat[l * 9 + t]; recip_used[t] = c.srecip[l * 9 + t]; }
+    // the old cell of this lattice, kept in LDS (c.sbk: [lattice][hmatrix 9 | recip 9 | new recip 9]): eighteen wave-uniform
+    // doubles are thirty-six vector registers, held across the full-box energy evaluation
+    double* bk_h = c.sbk + 27 * l;
+    double* bk_r = bk_h + 9;
+    double* bk_n = bk_h + 18;
+    if (lane < 9) { bk_h[lane] = c.shmat[l * 9 + lane]; bk_r[lane] = c.srecip[l * 9 + lane]; }
     const double old_vol_l = c.svol[l];
     const int idim = (int)(U[0] * 3.0) + 1, jdim = (int)(U[1] * 3.0) + 1;                       // :1269-1272
     const double dh = (2.0 * U[2] - 1.0) * dv_max;                                              // :1276
@@ -358,7 +340,7 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
     int bad = 0;
     bool rescaled = false;
     if (!bad0) {
-        dev_rescale(c, l, recip_used, c.shmat + 9 * l, lane);
+        dev_rescale(c, l, bk_r, c.shmat + 9 * l, lane);
         rescaled = true;
         wave_sync();
         const int niv = dev_compute_ivects(c.shmat + 9 * l, c.siv + (size_t)l * c.ivcap * 3,
@@ -386,18 +368,13 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
     wg_sync<NLAT>();
     ok = sdec[0]; anybad = sdec[1];
     if (!ok) {                                                                                   // :1426-1530
-        double recip_new[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) recip_new[t] = c.srecip[l * 9 + t];
+        if (lane < 9) bk_n[lane] = c.srecip[l * 9 + lane];
         wave_sync();
-        if (lane == 0) {
-            c.svol[l] = old_vol_l;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) { c.shmat[l * 9 + t] = old_h[t]; c.srecip[l * 9 + t] = recip_used[t]; }
-        }
+        if (lane < 9) { c.shmat[l * 9 + lane] = bk_h[lane]; c.srecip[l * 9 + lane] = bk_r[lane]; }
+        if (lane == 0) c.svol[l] = old_vol_l;
         wave_sync();
         if (rescaled) {
-            dev_rescale(c, l, recip_new, c.shmat + 9 * l, lane);                                 // back through the NEW recip
+            dev_rescale(c, l, bk_n, c.shmat + 9 * l, lane);                                 // back through the NEW recip
             const int niv = dev_compute_ivects(c.shmat + 9 * l, c.siv + (size_t)l * c.ivcap * 3,
                                                c.ivect_g + (size_t)l * c.ivcap * 3, c.ivcap, lane);   // :1510-1512
             if (lane == 0 && niv > 0) { c.sniv[l] = niv; c.nivect_g[l] = niv; }
@@ -425,10 +402,46 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
 //  * the move's scalar arithmetic is lane-parallel (lane_mu_to_bin / lane_eta above, one exp stream per move) and done by
 //    wavefront 0 only; bins are carried from move to move; the Wang-Landau minimum is tracked, not re-scanned;
 //  * the uniforms, molecule and displacement of kUB moves come from one Philox pass of the whole workgroup;
-//  * nothing but the current move's values stays in registers: ~128 VGPRs, four wavefronts per SIMD.
+//  * the walker's parameters and its state between moves (energies, order parameter, counters) live in LDS (WalkerCtl),
+//    not in registers: a wave-uniform double costs two VECTOR registers, and thirty of them held across the energy
+//    evaluation were the difference between two and four wavefronts per SIMD.
 // =====================================================================================
+struct WalkerCtl {
+    // the launch's parameters as this walker sees them (its own window, step sizes, increment)
+    double beta, pressure, dref, av_binwidth, log_unbiased_norm, transP, ref1, ref2, wl_alpha, orig_wl_factor, mu_min, mu_max;
+    double max_trans, dv_max;
+    MuGridDev mg;                            // (mg.in_window changes at the top of a 'dd' cycle)
+    int record, samplerun, always_switch, npt, swetnam, dd, minu, eq_cycles, nbins, pad0;
+    // the walker's state between moves
+    double men0, men1, ls_mu, gauge, wlf, sumh, cur_min, lgv12, lgv21;
+    unsigned long long acc, nsw, nvol_try, nvol_acc;
+    int ls, k_cur, k_valid, flag, cyc, within;
+};
+
+// The MINU branch of both move types: the lattice the move would end in; diffkT rewritten with the switch's terms if it differs.
+// E = trial energies, V = trial volumes, Eb / Vb = energy and volume of the CURRENT lattice before the move.
+__device__ __forceinline__ int dev_minu_branch(const WalkerCtl& sp, int ls, double E1, double E2, double V1, double V2,
+                                               double Eb, double Vb, bool vol_terms, int N, double new_eta, double old_eta,
+                                               double& diffkT)
+{
+    const double h1 = E1 + sp.pressure * V1 - sp.ref1, h2 = E2 + sp.pressure * V2 - sp.ref2;   // minloc, :1122-1126
+    const int lsn = h2 < h1 ? 2 : 1;
+    if (lsn != ls) {
+        const double En = lsn == 1 ? E1 : E2, Vn = lsn == 1 ? V1 : V2;
+        double d;
+        if (vol_terms) d = sp.beta * En - sp.beta * Eb + sp.beta * sp.pressure * (Vn - Vb) - (double)N * log(Vn / Vb) + new_eta - old_eta;   // :1131-1133,1396-1397
+        else           d = sp.beta * En - sp.beta * Eb + new_eta - old_eta;                                                                  // :1135
+        if (sp.ref1 != 0.0 || sp.ref2 != 0.0)                                                                                               // leshift, :1134,1136,1398
+            d = d - sp.beta * (lsn == 1 ? sp.ref1 : sp.ref2) + sp.beta * (ls == 1 ? sp.ref1 : sp.ref2);
+        diffkT = d;
+    }
+    return lsn;
+}
+
 template <int NLAT, bool LDSPOS, bool LDSLIST, bool WITHVOL>
-__global__ __launch_bounds__(64 * NLAT)
+// Four wavefronts per SIMD are the design point (128 VGPRs; the translation-only build needs 127-136 left to itself, and
+// which side of 128 it lands on depends on what else is compiled with it); the build that carries mc_volume gets three.
+__global__ __launch_bounds__(64 * NLAT) __attribute__((amdgpu_waves_per_eu(WITHVOL ? 3 : 4, WITHVOL ? 3 : 4)))
 void k_sweep(double* pos, double* hmat, double* ivect,
              int* nivect, const uint32_t* __restrict__ listm, const uint32_t* __restrict__ list,
              const int* __restrict__ nn, const int* __restrict__ order, const int* __restrict__ nns,
@@ -447,42 +460,29 @@ void k_sweep(double* pos, double* hmat, double* ivect,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double shmat[2][9], srecip[2][9], svol[2];      // the walker's cells: volume moves change them in place
     __shared__ int sniv[2];
+    __shared__ double sbk[2][27];     // a volume move's old hmatrix / recip and new recip per lattice
     __shared__ double sx[4];          // what wavefront 1 hands to the deciding wavefront: {e_old, e_new} / full-box energies
     __shared__ int sdec[4];           // the decision: accepted, active lattice (volume moves: accepted, bad, bad per lattice)
+    __shared__ WalkerCtl ctl;
+    WalkerCtl& C = ctl;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = NLAT == 2 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
     const int wlk = walker0 + blockIdx.x;
     const int box0 = wlk * L;
-    const SweepLds lay = sweep_lds(L, ivcap, N, sp.nbins, LDSPOS, LDSLIST, rstride, WITHVOL);
+    const int nbins = sp.nbins;
+    const SweepLds lay = sweep_lds(L, ivcap, N, nbins, LDSPOS, LDSLIST, rstride, WITHVOL);
     double* siv = reinterpret_cast<double*>(smem_raw + lay.iv);
     double* spos = reinterpret_cast<double*>(smem_raw + lay.pos);
     double* sweight = reinterpret_cast<double*>(smem_raw + lay.tab);
-    double* smub = sweight + sp.nbins;
-    double* sbw = smub + sp.nbins;
-    double* shist = sbw + sp.nbins;
-    double* suhist = shist + sp.nbins;
+    double* smub = sweight + nbins;
+    double* sbw = smub + nbins;
+    double* shist = sbw + nbins;
+    double* suhist = shist + nbins;
     double* suni = reinterpret_cast<double*>(smem_raw + lay.uni);
     double* smv = reinterpret_cast<double*>(smem_raw + lay.mv);
     WaveScratch* ws = reinterpret_cast<WaveScratch*>(smem_raw + lay.scr + (unsigned)wv * lay.scr_bytes);
     unsigned short* srow = reinterpret_cast<unsigned short*>(smem_raw + lay.row);
     unsigned char* snn = smem_raw + lay.nn;
-
-    // per-walker pieces of the parameter block: its window of the overlap parameter ('dd': mc_moves.F90:659-709; else
-    // the whole range), whether it has reached that window, its step sizes, its Wang-Landau increment and Swetnam's visit total
-    MuGridDev mg;
-    mg.r_pos = sp.r_pos; mg.a_pos = sp.a_pos; mg.r_neg = sp.r_neg; mg.a_neg = sp.a_neg;
-    mg.lr_pos = log(sp.r_pos); mg.lr_neg = log(sp.r_neg);
-    mg.mu_lo = sp.mu_lo; mg.mu_hi = sp.mu_hi; mg.nbins = sp.nbins; mg.start_bin = sp.start_bin; mg.end_bin = sp.end_bin;
-    mg.eta_interp = sp.eta_interp;
-    if (wwin) {
-        mg.start_bin = (int)wwin[4 * (size_t)wlk]; mg.end_bin = (int)wwin[4 * (size_t)wlk + 1];
-        mg.mu_lo = wwin[4 * (size_t)wlk + 2]; mg.mu_hi = wwin[4 * (size_t)wlk + 3];
-    }
-    mg.in_window = sp.dd ? winflag[wlk] : 1;                              // mc_moves.F90:112,872
-    double max_trans = sp.max_trans, dv_max = sp.dv_max;
-    if (wstep) { max_trans = wstep[2 * (size_t)wlk]; dv_max = wstep[2 * (size_t)wlk + 1]; }   // equilibration tuning, :1729-1732
-    double wlf = L == 2 ? wfac[wlk] : 0.0;                                // wl_factor of this walker (:1615,1677)
-    double sumh = L == 2 ? wsum[wlk] : 0.0;                               // sumhist (:94,1638)
     const double invPi = 1.0 / 3.141592653589793238462643383279502884197;
 
     // ---- staging: image vectors, (small systems) positions, list rows and row lengths, the walker's tables -------------
@@ -503,12 +503,12 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         }
     }
     if (L == 2) {
-        for (int t = tid; t < sp.nbins; t += NTHR) {
-            sweight[t] = wweight[(size_t)wlk * sp.nbins + t];
+        for (int t = tid; t < nbins; t += NTHR) {
+            sweight[t] = wweight[(size_t)wlk * nbins + t];
             smub[t] = mu_bin_g[t];
             sbw[t] = binwidth_g[t];
-            shist[t] = whist[(size_t)wlk * sp.nbins + t];
-            suhist[t] = wuhist[(size_t)wlk * sp.nbins + t];
+            shist[t] = whist[(size_t)wlk * nbins + t];
+            suhist[t] = wuhist[(size_t)wlk * nbins + t];
         }
     }
     if (tid < L) {
@@ -520,38 +520,60 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         svol[l] = volume[box0 + l];
         sniv[l] = nivect[box0 + l];
     }
+    if (tid == 0) {
+        // per-walker pieces of the parameter block: its window of the overlap parameter ('dd': mc_moves.F90:659-709; else the
+        // whole range), whether it has reached that window, its step sizes, its Wang-Landau increment and Swetnam's visit total
+        C.beta = sp.beta; C.pressure = sp.pressure; C.dref = sp.dref; C.av_binwidth = sp.av_binwidth;
+        C.log_unbiased_norm = sp.log_unbiased_norm; C.transP = sp.transP; C.ref1 = sp.ref1; C.ref2 = sp.ref2;
+        C.wl_alpha = sp.wl_alpha; C.orig_wl_factor = sp.orig_wl_factor; C.mu_min = sp.mu_min; C.mu_max = sp.mu_max;
+        C.max_trans = sp.max_trans; C.dv_max = sp.dv_max;
+        if (wstep) { C.max_trans = wstep[2 * (size_t)wlk]; C.dv_max = wstep[2 * (size_t)wlk + 1]; }   // equilibration tuning, :1729-1732
+        C.mg.r_pos = sp.r_pos; C.mg.a_pos = sp.a_pos; C.mg.r_neg = sp.r_neg; C.mg.a_neg = sp.a_neg;
+        C.mg.lr_pos = log(sp.r_pos); C.mg.lr_neg = log(sp.r_neg);
+        C.mg.mu_lo = sp.mu_lo; C.mg.mu_hi = sp.mu_hi; C.mg.nbins = nbins; C.mg.start_bin = sp.start_bin; C.mg.end_bin = sp.end_bin;
+        C.mg.eta_interp = sp.eta_interp;
+        if (wwin) {
+            C.mg.start_bin = (int)wwin[4 * (size_t)wlk]; C.mg.end_bin = (int)wwin[4 * (size_t)wlk + 1];
+            C.mg.mu_lo = wwin[4 * (size_t)wlk + 2]; C.mg.mu_hi = wwin[4 * (size_t)wlk + 3];
+        }
+        C.mg.in_window = sp.dd ? winflag[wlk] : 1;                            // mc_moves.F90:112,872
+        C.record = sp.record; C.samplerun = sp.samplerun; C.always_switch = sp.always_switch; C.npt = sp.npt;
+        C.swetnam = sp.swetnam; C.dd = sp.dd; C.minu = sp.minu; C.eq_cycles = sp.eq_cycles; C.nbins = nbins;
+        C.men0 = energy[box0]; C.men1 = L == 2 ? energy[box0 + 1] : 0.0;
+        C.ls_mu = wmu[wlk]; C.ls = wls[wlk];                                  // active lattice, 1-based
+        C.gauge = 0.0;                                                        // total of the minima subtracted from this walker's weights (:1682-1685)
+        C.wlf = L == 2 ? wfac[wlk] : 0.0;                                     // wl_factor of this walker (:1615,1677)
+        C.sumh = L == 2 ? wsum[wlk] : 0.0;                                    // sumhist (:94,1638)
+        C.acc = 0; C.nsw = 0; C.nvol_try = 0; C.nvol_acc = 0; C.flag = 0;
+        C.k_cur = 0; C.k_valid = 0;                                           // bin of ls_mu, carried from move to move
+        // mc_cycle_num of the next move and its place inside the cycle ('dd' only: the equilibration rules, :181-210)
+        C.cyc = sp.dd ? (int)(move0 / (unsigned long long)N) + 1 : 0;
+        C.within = sp.dd ? (int)(move0 % (unsigned long long)N) : 0;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        // log(V1/V2), log(V2/V1): change with volume moves only; the minimum of the weights over the walker's window (0
+        // after the first update)
+        double l12 = 0.0, l21 = 0.0, cmin = 0.0;
+        if (L == 2) {
+            l12 = log(svol[0] / svol[1]); l21 = log(svol[1] / svol[0]);
+            if (C.record && !C.samplerun) {
+                double mn = 1.7976931348623157e308;
+                for (int b = C.mg.start_bin - 1 + lane; b < C.mg.end_bin; b += 64) { const double w = sweight[b]; mn = w < mn ? w : mn; }
+                cmin = readlane_f64(dpp_wave_min(mn), 63);
+            }
+        }
+        if (lane == 0) { C.lgv12 = l12; C.lgv21 = l21; C.cur_min = cmin; }
+    }
     __syncthreads();
 
     VolCtx vc;
     vc.pos_g = pos + (size_t)box0 * N * 3; vc.spos = LDSPOS ? spos : nullptr;
-    vc.shmat = &shmat[0][0]; vc.srecip = &srecip[0][0]; vc.svol = svol; vc.siv = siv; vc.sniv = sniv;
+    vc.shmat = &shmat[0][0]; vc.srecip = &srecip[0][0]; vc.svol = svol; vc.sbk = &sbk[0][0]; vc.siv = siv; vc.sniv = sniv;
     vc.hmat_g = hmat + (size_t)box0 * 9; vc.vol_g = volume + box0; vc.ivect_g = ivect + (size_t)box0 * ivcap * 3;
     vc.nivect_g = nivect + box0; vc.list_g = list + (size_t)box0 * S * N;
     vc.order_g = order + (size_t)box0 * N; vc.nns_g = nns + (size_t)box0 * N; vc.cmax_g = cmax + (size_t)box0 * ((N + 63) >> 6);
     vc.queue = reinterpret_cast<uint32_t*>(ws) + lane; vc.N = N; vc.S = S; vc.ivcap = ivcap; vc.L = L;
-
-    // ---- the walker's state (meaningful in wavefront 0, which decides; `ls` is followed by every wavefront) --------------
-    unsigned long long nvol_try = 0, nvol_acc = 0, nsw = 0, acc = 0;
-    int flag = 0;
-    double gauge = 0.0;                      // total of the minima subtracted from this walker's weights (:1682-1685)
-    int ls = wls[wlk];                       // active lattice, 1-based
-    double ls_mu = wmu[wlk];
-    double men0 = energy[box0], men1 = L == 2 ? energy[box0 + 1] : 0.0;
-    int k_cur = 0; bool k_valid = false;     // bin of ls_mu, carried from move to move
-    double lgv12 = 0.0, lgv21 = 0.0;         // log(V1/V2), log(V2/V1): change with volume moves only
-    double cur_min = 0.0;                    // minimum of the weights over the walker's window (0 after the first update)
-    const bool wl_on = L == 2 && sp.record && !sp.samplerun;
-    if (L == 2) {
-        lgv12 = log(svol[0] / svol[1]); lgv21 = log(svol[1] / svol[0]);
-        if (wl_on) {
-            double mn = 1.7976931348623157e308;
-            for (int b = mg.start_bin - 1 + lane; b < mg.end_bin; b += 64) { const double w = sweight[b]; mn = w < mn ? w : mn; }
-            cur_min = readlane_f64(dpp_wave_min(mn), 63);
-        }
-    }
-    // mc_cycle_num of the next move and its place inside the cycle ('dd' only: the equilibration rules, :181-210)
-    int cyc = 0, within = 0;
-    if (sp.dd) { cyc = (int)(move0 / (unsigned long long)N) + 1; within = (int)(move0 % (unsigned long long)N); }
 
     // mc_lattice_switch's exponent for a walker in lattice lsx with energies E0, E1 (:1557-1572), less new_eta - old_eta
     auto switch_dk = [&](double E0, double E1, int lsx) {
@@ -559,53 +581,59 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         const double V1 = svol[0], V2 = svol[1];
         const double Vls = lsx == 1 ? V1 : V2, Vlsn = lsx == 1 ? V2 : V1;
         double dk;
-        if (sp.npt) dk = sp.beta * Elsn - sp.beta * Els + sp.beta * sp.pressure * (Vlsn - Vls) - (double)N * (lsx == 1 ? lgv21 : lgv12);
-        else        dk = sp.beta * Elsn - sp.beta * Els;
-        return dk + (lsx == 1 ? sp.beta * sp.dref : -(sp.beta * sp.dref));   // leshift: - beta ref(lsn) + beta ref(ls), :1567,1572
+        if (C.npt) dk = C.beta * Elsn - C.beta * Els + C.beta * C.pressure * (Vlsn - Vls) - (double)N * (lsx == 1 ? C.lgv21 : C.lgv12);
+        else       dk = C.beta * Elsn - C.beta * Els;
+        return dk + (lsx == 1 ? C.beta * C.dref : -(C.beta * C.dref));        // leshift: - beta ref(lsn) + beta ref(ls), :1567,1572
     };
     // What follows EITHER move type (wavefront 0): mc_update_wl_bins (:1597-1689) on the walker's tables, then one
     // mc_lattice_switch attempt (:1536-1594).  eta_fin = eta_weight(ls_mu) with the weights as the move found them,
-    // cmp_sw = exp(-dk) of the switch without its eta terms, ufac = exp(eta_fin - log_unbiased_norm); k_cur = bin of ls_mu.
+    // cmp_sw = exp(-dk) of the switch without its eta terms, ufac = exp(eta_fin - log_unbiased_norm); C.k_cur = bin of ls_mu.
     auto post_move = [&](double eta_fin, double cmp_sw, double ufac, bool do_switch, double u6) -> int {
         int sw = 0;
-        if (sp.record) {                                                          // mc_update_wl_bins, :1597-1689
-            const int k = k_cur;
-            if (k >= 1 && k <= sp.nbins) {
+        const int kc = C.k_cur;
+        if (C.record) {                                                           // mc_update_wl_bins, :1597-1689
+            const int k = kc;
+            if (k >= 1 && k <= nbins) {
                 const double bwk = sbw[k - 1];
-                if (sp.samplerun) {
+                const double visit = C.av_binwidth / bwk;
+                if (C.samplerun) {
                     if (lane == 0) {
-                        shist[k - 1] = shist[k - 1] + sp.av_binwidth / bwk;                       // :1621
-                        suhist[k - 1] = suhist[k - 1] + (sp.av_binwidth / bwk) * ufac;            // :1627-1629
+                        shist[k - 1] = shist[k - 1] + visit;                                  // :1621
+                        suhist[k - 1] = suhist[k - 1] + visit * ufac;                         // :1627-1629
                     }
                 } else {
-                    if (sp.swetnam) {                                             // :1636-1653
-                        sumh = sumh + 1.0;
+                    double wlf = C.wlf;
+                    if (C.swetnam) {                                              // :1636-1653
+                        const double sumh = C.sumh + 1.0;
                         double a2 = 0.0;
-                        const double span = sp.mu_max - sp.mu_min - 1.0;
-                        for (int b = lane; b < sp.nbins; b += 64) {
-                            const double hb = shist[b] + (b == k - 1 ? sp.av_binwidth / bwk : 0.0);    // this move's visit is already counted (:1621)
+                        const double span = C.mu_max - C.mu_min - 1.0;
+                        for (int b = lane; b < nbins; b += 64) {
+                            const double hb = shist[b] + (b == k - 1 ? visit : 0.0);          // this move's visit is already counted (:1621)
                             const double dev = hb * sbw[b] / sumh - sbw[b] / span;
                             a2 += dev * dev;
                         }
                         a2 = readlane_f64(dpp_wave_sum(a2), 63);
-                        double f = sqrt(a2 / (double)sp.nbins);
-                        f = log(f) * sp.wl_alpha * (double)sp.nbins;
-                        wlf = f < sp.orig_wl_factor ? f : sp.orig_wl_factor;
+                        double f = sqrt(a2 / (double)nbins);
+                        f = log(f) * C.wl_alpha * (double)nbins;
+                        wlf = f < C.orig_wl_factor ? f : C.orig_wl_factor;
+                        if (lane == 0) { C.sumh = sumh; C.wlf = wlf; }
                     }
                     // weight(k) += av_binwidth*wl_factor/binwidth(k) -- whichever bin k is (:1680); then the minimum over the
                     // walker's window is subtracted inside the window (:1682-1685; with 'dd' windows k may lie outside).
                     // The minimum is TRACKED: it is 0 after the first update, and it only moves when the visited bin was
                     // (one of) the lowest -- then, and only then, the window is scanned.
-                    const double inc = sp.av_binwidth * wlf / bwk;
+                    const double inc = C.av_binwidth * wlf / bwk;
                     const double wk = sweight[k - 1];
-                    const bool k_in = k >= mg.start_bin && k <= mg.end_bin;
+                    const double cur_min = C.cur_min;
+                    const int sb = C.mg.start_bin, eb = C.mg.end_bin;
+                    const bool k_in = k >= sb && k <= eb;
                     double mn;
                     bool scan = false;
                     if (!k_in) mn = cur_min;
                     else if (wk > cur_min) { const double wn = wk + inc; mn = wn < cur_min ? wn : cur_min; }
                     else { scan = true; mn = 1.7976931348623157e308; }
                     if (scan) {
-                        for (int b = mg.start_bin - 1 + lane; b < mg.end_bin; b += 64) {
+                        for (int b = sb - 1 + lane; b < eb; b += 64) {
                             double w = sweight[b];
                             if (b == k - 1) w = w + inc;
                             mn = w < mn ? w : mn;
@@ -614,7 +642,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                     }
                     wave_sync();
                     if (mn != 0.0) {
-                        for (int b = mg.start_bin - 1 + lane; b < mg.end_bin; b += 64) {
+                        for (int b = sb - 1 + lane; b < eb; b += 64) {
                             double w = sweight[b];
                             if (b == k - 1) w = w + inc;
                             sweight[b] = w - mn;
@@ -623,9 +651,11 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                     } else if (lane == 0) {
                         sweight[k - 1] = k_in ? (wk + inc) - mn : wk + inc;
                     }
-                    cur_min = 0.0;                                                // the lowest bin of the window is now exactly mn - mn
-                    gauge += mn;
-                    if (lane == 0) shist[k - 1] = shist[k - 1] + sp.av_binwidth / bwk;
+                    if (lane == 0) {
+                        C.cur_min = 0.0;                                          // the lowest bin of the window is now exactly mn - mn
+                        C.gauge = C.gauge + mn;
+                        shist[k - 1] = shist[k - 1] + visit;
+                    }
                 }
                 wave_sync();
             }
@@ -634,26 +664,29 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             // new_eta - old_eta of the switch (:1557-1558) = eta_weight(ls_mu) - eta_weight(ls_mu) with the weights as they are
             // NOW: 0 unless that weight is not finite
             double deta;
-            if (sp.samplerun || !sp.record) deta = eta_fin - eta_fin;
+            if (C.samplerun || !C.record) deta = eta_fin - eta_fin;
             else {
-                const int k = k_cur < 2 ? 2 : (k_cur > sp.nbins - 1 ? sp.nbins - 1 : k_cur);
+                const int k = kc < 2 ? 2 : (kc > nbins - 1 ? nbins - 1 : kc);
                 const double wa = fabs(sweight[k - 2]), wb = fabs(sweight[k - 1]), wc = fabs(sweight[k]);
                 if (wa < 1.0e150 && wb < 1.0e150 && wc < 1.0e150) deta = 0.0;     // finite weights interpolate to a finite weight
-                else { const double ew = lane_eta(mg, sweight, smub, sbw, ls_mu, k_cur); deta = ew - ew; }
+                else { const double ew = lane_eta(C.mg, sweight, smub, sbw, C.ls_mu, kc); deta = ew - ew; }
             }
             double cmp = deta == 0.0 ? cmp_sw : deta;                             // exp(-(dk + deta)), dk + 0 = dk
             cmp = cmp > 1.0 ? 1.0 : cmp;
             if (u6 < cmp) {
                 const double V1 = svol[0], V2 = svol[1];
-                double mu = (men0 + sp.pressure * V1) - (men1 + sp.pressure * V2);          // :1581-1583
-                mu = mu - sp.dref;                                                          // :1584 (leshift)
-                mu = mu * sp.beta - (double)N * lgv12;
-                ls_mu = mu; ls = 3 - ls; sw = 1; ++nsw; k_valid = false;
+                double mu = (C.men0 + C.pressure * V1) - (C.men1 + C.pressure * V2);            // :1581-1583
+                mu = mu - C.dref;                                                               // :1584 (leshift)
+                mu = mu * C.beta - (double)N * C.lgv12;
+                sw = 1;
+                if (lane == 0) { C.ls_mu = mu; C.ls = 3 - C.ls; C.nsw = C.nsw + 1; C.k_valid = 0; }
+                wave_sync();
             }
         }
         return sw;
     };
 
+    int ls = C.ls;                               // the active lattice, followed by every wavefront
     for (int mv = 0; mv < nmoves; ++mv) {
         const int ub = mv & (kUB - 1);
         if (ub == 0) {
@@ -671,6 +704,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             wg_sync<NLAT>();
             if (tid < kUB) {
                 const double* u = suni + tid * 8;
+                const double max_trans = C.max_trans;
                 int im = (int)(u[0] * (double)N) + 1;                                     // :1001-1002
                 im = im > N ? N : im;
                 double x = 2.0 * u[1] - 1.0, y = 2.0 * u[2] - 1.0, z = 2.0 * u[3] - 1.0;  // :1021-1027
@@ -683,80 +717,97 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             wg_sync<NLAT>();
         }
         const double* U = suni + ub * 8;     // u0..u7: molecule, direction x3, length, acceptance, lattice switch (:1576), move type (:226)
-        if (sp.dd && wv == 0 && within == 0) {                     // top of a cycle: the equilibration check of mc_cycle (:181-210)
-            if (cyc < sp.eq_cycles) mg.in_window = (ls_mu > mg.mu_lo && ls_mu < mg.mu_hi) ? 1 : 0;
-            else if (cyc == sp.eq_cycles) { if (!mg.in_window) flag |= 2; }     // "Not all walkers have reached their designated window"
-            else mg.in_window = 1;                                 // a restart
-        }
-        const bool do_switch = L == 2 && sp.always_switch && !(sp.dd && cyc < sp.eq_cycles);   // (:243-248: not while a 'dd' run equilibrates)
-        const bool is_volume = WITHVOL && !(U[7] < sp.transP);    // WITHVOL = false: translation-only build
+        const bool is_volume = WITHVOL && !(U[7] < C.transP);     // WITHVOL = false: translation-only build
         bool ok = false;
         int sw = 0, imol = 0;
         double eo0 = 0.0, en0 = 0.0, eo1 = 0.0, en1 = 0.0, diffkT = 0.0;     // (the move log's columns)
+        bool do_switch = false;
+        if (wv == 0) {
+            if (C.dd && C.within == 0) {                           // top of a cycle: the equilibration check of mc_cycle (:181-210)
+                const int cyc = C.cyc;
+                if (lane == 0) {
+                    if (cyc < C.eq_cycles) C.mg.in_window = (C.ls_mu > C.mg.mu_lo && C.ls_mu < C.mg.mu_hi) ? 1 : 0;
+                    else if (cyc == C.eq_cycles) { if (!C.mg.in_window) C.flag = C.flag | 2; }   // "Not all walkers have reached their designated window"
+                    else C.mg.in_window = 1;                       // a restart
+                }
+                wave_sync();
+            }
+            do_switch = L == 2 && C.always_switch && !(C.dd && C.cyc < C.eq_cycles);   // (:243-248: not while a 'dd' run equilibrates)
+        }
 
         if (is_volume) {                                                          // mc_moves.F90:232-235
             if constexpr (WITHVOL) {
                 const double Vo0 = svol[0], Vo1 = L == 2 ? svol[1] : 0.0;
                 auto decide = [&](double e0n, double e1n, int anybad) -> int {
                     // wavefront 0: mc_volume's acceptance (:1361-1410) and, on rejection, the restored order parameter (:1514-1530)
-                    const double bk0 = men0, bk1 = men1;
-                    int okv = 0;
+                    const double bk0 = C.men0, bk1 = C.men1;
+                    const int ls0 = C.ls;
+                    double ls_mu = C.ls_mu;
+                    int okv = 0, lsn = ls0;
                     if (!anybad) {
-                        men0 = e0n; men1 = e1n;
                         const double Vn0 = svol[0], Vn1 = L == 2 ? svol[1] : 0.0;
-                        const double dE = (ls == 1 ? e0n - bk0 : e1n - bk1);                                 // :1361
-                        const double Vls = ls == 1 ? Vn0 : Vn1, Vold = ls == 1 ? Vo0 : Vo1;
+                        const double dE = (ls0 == 1 ? e0n - bk0 : e1n - bk1);                                // :1361
+                        const double Vls = ls0 == 1 ? Vn0 : Vn1, Vold = ls0 == 1 ? Vo0 : Vo1;
                         double old_eta = 0.0, new_eta = 0.0;
                         if (L == 2) {                                                                        // :1363-1371
-                            double mu = (men0 + sp.pressure * Vn0) - (men1 + sp.pressure * Vn1);
-                            mu = mu - sp.dref;                                                               // :1371 (leshift)
-                            mu = mu * sp.beta - (double)N * log(Vn0 / Vn1);
+                            double mu = (e0n + C.pressure * Vn0) - (e1n + C.pressure * Vn1);
+                            mu = mu - C.dref;                                                                // :1371 (leshift)
+                            mu = mu * C.beta - (double)N * log(Vn0 / Vn1);
                             const double mul = lane == 0 ? ls_mu : mu;
-                            const double el = lane_eta(mg, sweight, smub, sbw, mul, lane_mu_to_bin(mg, mul));
+                            const double el = lane_eta(C.mg, sweight, smub, sbw, mul, lane_mu_to_bin(C.mg, mul));
                             old_eta = readlane_f64(el, 0); new_eta = readlane_f64(el, 1);
                             ls_mu = mu;
                         }
-                        diffkT = sp.beta * dE + new_eta - old_eta + sp.beta * sp.pressure * (Vls - Vold)
+                        diffkT = C.beta * dE + new_eta - old_eta + C.beta * C.pressure * (Vls - Vold)
                                  - (double)N * log(Vls / Vold);                                              // :1381-1382
-                        int minu_ls = ls;
-                        if (sp.minu && L == 2)                                                               // :1385-1401
-                            minu_ls = dev_minu_branch(sp, ls, men0, men1, Vn0, Vn1, ls == 1 ? bk0 : bk1, Vold, true, N,
+                        int minu_ls = ls0;
+                        if (C.minu && L == 2)                                                                // :1385-1401
+                            minu_ls = dev_minu_branch(C, ls0, e0n, e1n, Vn0, Vn1, ls0 == 1 ? bk0 : bk1, Vold, true, N,
                                                       new_eta, old_eta, diffkT);
-                        double cmp = exp(-diffkT);
+                        double cmp = exp_any(-diffkT);
                         cmp = cmp > 1.0 ? 1.0 : cmp;
                         okv = U[3] < cmp ? 1 : 0;                                                            // :1410
-                        if (okv) ls = minu_ls;                                                               // :1426-1429
+                        if (okv) lsn = minu_ls;                                                              // :1426-1429
                     }
+                    double m0 = e0n, m1 = e1n;
                     if (!okv) {
-                        men0 = bk0; men1 = bk1;                                                              // :1514
+                        m0 = bk0; m1 = bk1;                                                                  // :1514
                         if (L == 2) {                                                                        // :1516-1520 (the OLD cells)
-                            double mu = (men0 + sp.pressure * Vo0) - (men1 + sp.pressure * Vo1);
-                            mu = mu - sp.dref;                                                               // :1526 (leshift)
-                            mu = mu * sp.beta - (double)N * log(Vo0 / Vo1);
+                            double mu = (m0 + C.pressure * Vo0) - (m1 + C.pressure * Vo1);
+                            mu = mu - C.dref;                                                                // :1526 (leshift)
+                            mu = mu * C.beta - (double)N * log(Vo0 / Vo1);
                             ls_mu = mu;
                         }
                     }
+                    if (lane == 0) { C.men0 = m0; C.men1 = m1; C.ls_mu = ls_mu; C.ls = lsn; }
+                    wave_sync();
                     return okv;
                 };
-                const int rv = volume_move_wg<NLAT>(vc, U, dv_max, wv, lane, sx, sdec, decide);
-                ++nvol_try;
-                if (rv == 1) ++nvol_acc;
-                if (rv < 0) flag |= 1;
+                const int rv = volume_move_wg<NLAT>(vc, U, C.dv_max, wv, lane, sx, sdec, decide);
                 ok = rv == 1;
-                k_valid = false;
-                if (L == 2 && wv == 0) {
-                    lgv12 = log(svol[0] / svol[1]); lgv21 = log(svol[1] / svol[0]);
-                    if (sp.record || do_switch) {                      // the same update and switch attempt as after a translation
-                        const int kl = lane_mu_to_bin(mg, ls_mu);
-                        k_cur = __builtin_amdgcn_readlane(kl, 0); k_valid = true;
-                        const double eta_fin = readlane_f64(lane_eta(mg, sweight, smub, sbw, ls_mu, k_cur), 0);
-                        const double dk = do_switch ? switch_dk(men0, men1, ls) : 0.0;
-                        const double ex = exp(lane == 0 ? -dk : eta_fin - sp.log_unbiased_norm);
+                if (wv == 0) {
+                    double l12 = 0.0, l21 = 0.0;
+                    if (L == 2) { l12 = log(svol[0] / svol[1]); l21 = log(svol[1] / svol[0]); }
+                    if (lane == 0) {
+                        C.nvol_try = C.nvol_try + 1;
+                        if (rv == 1) C.nvol_acc = C.nvol_acc + 1;
+                        if (rv < 0) C.flag = C.flag | 1;
+                        C.k_valid = 0; C.lgv12 = l12; C.lgv21 = l21;
+                    }
+                    wave_sync();
+                    if (L == 2 && (C.record || do_switch)) {           // the same update and switch attempt as after a translation
+                        const double mu = C.ls_mu;
+                        const int kl = __builtin_amdgcn_readlane(lane_mu_to_bin(C.mg, mu), 0);
+                        if (lane == 0) { C.k_cur = kl; C.k_valid = 1; }
+                        wave_sync();
+                        const double eta_fin = readlane_f64(lane_eta(C.mg, sweight, smub, sbw, mu, kl), 0);
+                        const double dk = do_switch ? switch_dk(C.men0, C.men1, C.ls) : 0.0;
+                        const double ex = exp_any(lane == 0 ? -dk : eta_fin - C.log_unbiased_norm);
                         sw = post_move(eta_fin, readlane_f64(ex, 0), readlane_f64(ex, 1), do_switch, U[6]);
                     }
-                    if (lane == 0) sdec[1] = ls;
+                    if (L == 2 && lane == 0) sdec[1] = C.ls;
                 }
-                if (L == 2) { wg_sync<NLAT>(); ls = sdec[1]; }     // (MINU may have changed the active lattice)
+                if (L == 2) { wg_sync<NLAT>(); ls = sdec[1]; }     // (MINU or the switch may have changed the active lattice)
             }
         } else {
             // ---- translation: this wavefront's lattice ------------------------------------------------------------
@@ -806,65 +857,71 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             if (L == 2) {
                 if (wv == 1 && lane == 0) { sx[0] = res.eo; sx[1] = res.en; }
                 __syncthreads();
+            } else {
+                wave_sync();                       // (nothing of the walker's state is read ahead of the evaluation)
             }
             if (wv == 0) {
                 // ---- the decision (wavefront 0), :1090-1209 ---------------------------------------------------------
                 eo0 = res.eo; en0 = res.en;
                 if (L == 2) { eo1 = sx[0]; en1 = sx[1]; }
+                const int ls0 = C.ls;
+                const double beta = C.beta;
                 const double dE0 = en0 - eo0, dE1 = en1 - eo1;                            // :1090
-                const double bk0 = men0, bk1 = men1;                                      // :1013
-                const double mn0 = (men0 - eo0) + en0, mn1 = (men1 - eo1) + en1;          // :1016,1087
-                int minu_ls = ls;
+                const double bk0 = C.men0, bk1 = C.men1;                                  // :1013
+                const double mn0 = (bk0 - eo0) + en0, mn1 = (bk1 - eo1) + en1;            // :1016,1087
+                int minu_ls = ls0;
                 double mu_new = 0.0, mu_rev = 0.0, eta_new = 0.0, eta_rev = 0.0;
                 int k_new = 0, k_rev = 0;
                 if (L == 1) {
-                    diffkT = sp.beta * dE0;                                               // :1106
+                    diffkT = beta * dE0;                                                  // :1106
                 } else {
+                    const double mu_cur = C.ls_mu;
                     {
 #pragma clang fp contract(off)
-                        const double d = (dE0 - dE1) * sp.beta;                           // :1114 ... and what :1192 takes off again
-                        mu_new = ls_mu + d;
+                        const double d = (dE0 - dE1) * beta;                              // :1114 ... and what :1192 takes off again
+                        mu_new = mu_cur + d;
                         mu_rev = mu_new - d;
                     }
                     // lanes 0, 1, 2: the trial value, the value a rejection restores, the current one (its bin is carried)
-                    const double mul = lane == 0 ? mu_new : (lane == 1 ? mu_rev : ls_mu);
-                    int kl = lane_mu_to_bin(mg, mul);
-                    if (k_valid && lane >= 2) kl = k_cur;
-                    const double el = lane_eta(mg, sweight, smub, sbw, mul, kl);          // :1112-1116
+                    const double mul = lane == 0 ? mu_new : (lane == 1 ? mu_rev : mu_cur);
+                    int kl = lane_mu_to_bin(C.mg, mul);
+                    if (C.k_valid && lane >= 2) kl = C.k_cur;
+                    const double el = lane_eta(C.mg, sweight, smub, sbw, mul, kl);        // :1112-1116
                     eta_new = readlane_f64(el, 0); eta_rev = readlane_f64(el, 1);
                     const double eta_old = readlane_f64(el, 2);
                     k_new = __builtin_amdgcn_readlane(kl, 0); k_rev = __builtin_amdgcn_readlane(kl, 1);
-                    diffkT = (ls == 1 ? dE0 : dE1) * sp.beta + eta_new - eta_old;
-                    if (sp.minu)                                                          // :1119-1140
-                        minu_ls = dev_minu_branch(sp, ls, mn0, mn1, svol[0], svol[1], ls == 1 ? bk0 : bk1, ls == 1 ? svol[0] : svol[1],
-                                                  sp.npt != 0, N, eta_new, eta_old, diffkT);
+                    diffkT = (ls0 == 1 ? dE0 : dE1) * beta + eta_new - eta_old;
+                    if (C.minu)                                                           // :1119-1140
+                        minu_ls = dev_minu_branch(C, ls0, mn0, mn1, svol[0], svol[1], ls0 == 1 ? bk0 : bk1, ls0 == 1 ? svol[0] : svol[1],
+                                                  C.npt != 0, N, eta_new, eta_old, diffkT);
                 }
                 // the move's exponentials in one stream: lane 0 the acceptance; lanes 1, 2 the lattice switch that follows an
                 // accepted / a rejected move (mc_lattice_switch, :1536-1594); lanes 3, 4 the unbiased histogram's factor (:1627-1629)
                 double dkA = 0.0, dkR = 0.0;
                 if (do_switch) {
                     dkA = switch_dk(mn0, mn1, minu_ls);
-                    dkR = switch_dk(bk0, bk1, ls);
+                    dkR = switch_dk(bk0, bk1, ls0);
                 }
-                const double xarg = lane == 0 ? -diffkT : (lane == 1 ? -dkA : (lane == 2 ? -dkR
-                                    : (lane == 3 ? eta_new - sp.log_unbiased_norm : eta_rev - sp.log_unbiased_norm)));
-                const double ex = exp(xarg);
+                const double lun = L == 2 ? C.log_unbiased_norm : 0.0;
+                const double xarg = lane == 0 ? -diffkT : (lane == 1 ? -dkA : (lane == 2 ? -dkR : (lane == 3 ? eta_new - lun : eta_rev - lun)));
+                const double ex = exp_any(xarg);
                 double pacc = readlane_f64(ex, 0);
                 pacc = pacc > 1.0 ? 1.0 : pacc;
                 ok = U[5] < pacc;                                                         // :1145-1146 (false for NaN)
                 double eta_fin, cmp_sw, ufac;
-                if (ok) {
-                    ++acc;
-                    ls = minu_ls;                                                         // :1168-1170
-                    men0 = mn0; men1 = mn1;
-                    if (L == 2) { ls_mu = mu_new; k_cur = k_new; k_valid = true; }
+                if (ok) {                                                                 // :1150-1170
+                    if (lane == 0) {
+                        C.acc = C.acc + 1; C.ls = minu_ls; C.men0 = mn0; C.men1 = mn1;
+                        if (L == 2) { C.ls_mu = mu_new; C.k_cur = k_new; C.k_valid = 1; }
+                    }
                     eta_fin = eta_new; cmp_sw = readlane_f64(ex, 1); ufac = readlane_f64(ex, 3);
                 } else {                                                                  // :1182-1195
-                    if (L == 2) { ls_mu = mu_rev; k_cur = k_rev; k_valid = true; }
+                    if (L == 2 && lane == 0) { C.ls_mu = mu_rev; C.k_cur = k_rev; C.k_valid = 1; }
                     eta_fin = eta_rev; cmp_sw = readlane_f64(ex, 2); ufac = readlane_f64(ex, 4);
                 }
+                wave_sync();
                 if (L == 2) sw = post_move(eta_fin, cmp_sw, ufac, do_switch, U[6]);
-                if (L == 2 && lane == 0) { sdec[0] = ok ? 1 : 0; sdec[1] = ls; }
+                if (L == 2 && lane == 0) { sdec[0] = ok ? 1 : 0; sdec[1] = C.ls; }
             }
             if (L == 2) {
                 __syncthreads();
@@ -875,31 +932,33 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 if (LDSPOS) { double* Sp = spos + ((size_t)l * N + i) * 3; Sp[0] = pnx; Sp[1] = pny; Sp[2] = pnz; }
             }
         }   // translation
-        if (mvlog && wv == 0 && lane == 0) {
-            double* q = mvlog + ((size_t)blockIdx.x * nmoves + mv) * 8;
-            if (is_volume) { eo0 = men0; en0 = svol[0]; eo1 = L == 2 ? men1 : 0.0; en1 = L == 2 ? svol[1] : 0.0; }
-            q[0] = (double)imol; q[1] = (ok ? 1.0 : 0.0) + 2.0 * sw + (is_volume ? 4.0 : 0.0); q[2] = eo0; q[3] = en0; q[4] = eo1; q[5] = en1; q[6] = ls_mu; q[7] = diffkT;
+        if (wv == 0) {
+            if (mvlog && lane == 0) {
+                double* q = mvlog + ((size_t)blockIdx.x * nmoves + mv) * 8;
+                if (is_volume) { eo0 = C.men0; en0 = svol[0]; eo1 = L == 2 ? C.men1 : 0.0; en1 = L == 2 ? svol[1] : 0.0; }
+                q[0] = (double)imol; q[1] = (ok ? 1.0 : 0.0) + 2.0 * sw + (is_volume ? 4.0 : 0.0); q[2] = eo0; q[3] = en0; q[4] = eo1; q[5] = en1; q[6] = C.ls_mu; q[7] = diffkT;
+            }
+            if (lane == 0 && C.dd) { const int w = C.within + 1; if (w == N) { C.within = 0; C.cyc = C.cyc + 1; } else C.within = w; }
         }
-        if (sp.dd) { if (++within == N) { within = 0; ++cyc; } }
-        // the next move of this wavefront must see the committed position
+        // the next move of this wavefront must see the committed position (and wavefront 0 its own state)
         wave_sync();
     }
     __syncthreads();
-    if (L == 2 && sp.record) {
-        for (int t = tid; t < sp.nbins; t += NTHR) {
-            if (!sp.samplerun) wweight[(size_t)wlk * sp.nbins + t] = sweight[t];
-            whist[(size_t)wlk * sp.nbins + t] = shist[t];
-            if (sp.samplerun) wuhist[(size_t)wlk * sp.nbins + t] = suhist[t];
+    if (L == 2 && C.record) {
+        for (int t = tid; t < nbins; t += NTHR) {
+            if (!C.samplerun) wweight[(size_t)wlk * nbins + t] = sweight[t];
+            whist[(size_t)wlk * nbins + t] = shist[t];
+            if (C.samplerun) wuhist[(size_t)wlk * nbins + t] = suhist[t];
         }
     }
     if (tid == 0) {
-        wls[wlk] = ls; wmu[wlk] = ls_mu; wacc[wlk] += acc; wswitch[wlk] += nsw; wshift[wlk] += gauge;
-        wvol[2 * wlk] += nvol_try; wvol[2 * wlk + 1] += nvol_acc;
-        if (flag) wflag[wlk] |= flag;                       // bit 0: image-vector table outgrown, bit 1: 'dd' walker not in its window at eq_mc_cycles
-        if (L == 2) { wfac[wlk] = wlf; wsum[wlk] = sumh; }
-        if (sp.dd) winflag[wlk] = mg.in_window;
-        energy[box0] = men0;
-        if (L == 2) energy[box0 + 1] = men1;
+        wls[wlk] = C.ls; wmu[wlk] = C.ls_mu; wacc[wlk] += C.acc; wswitch[wlk] += C.nsw; wshift[wlk] += C.gauge;
+        wvol[2 * wlk] += C.nvol_try; wvol[2 * wlk + 1] += C.nvol_acc;
+        if (C.flag) wflag[wlk] |= C.flag;                   // bit 0: image-vector table outgrown, bit 1: 'dd' walker not in its window at eq_mc_cycles
+        if (L == 2) { wfac[wlk] = C.wlf; wsum[wlk] = C.sumh; }
+        if (C.dd) winflag[wlk] = C.mg.in_window;
+        energy[box0] = C.men0;
+        if (L == 2) energy[box0 + 1] = C.men1;
     }
 }
 

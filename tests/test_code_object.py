@@ -1,0 +1,52 @@
+"""CPU: what the compiler made of the Monte Carlo driver (k_sweep).  Its design point is a register budget -- four
+wavefronts per SIMD for the translation-only builds (<= 128 VGPRs), three for the builds that carry mc_volume (<= 168) --
+and NO register spills to scratch: a build of this kernel that spilled vector registers faulted on the GPU (round 3), and
+which side of the budget the allocator lands on moves with unrelated code in the same translation unit."""
+import os
+import re
+import struct
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def _gfx950_code_object(tmp_path):
+    lib = os.path.join(ROOT, "mc_water_ls_mw_amd", "libmw_hip.so")
+    data = open(lib, "rb").read()
+    i = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    assert i >= 0, "no offload bundle in libmw_hip.so"
+    n = struct.unpack_from("<Q", data, i + 24)[0]
+    off = i + 32
+    for _ in range(n):
+        o, s, tl = struct.unpack_from("<QQQ", data, off)
+        off += 24
+        triple = data[off:off + tl]
+        off += tl
+        if b"gfx950" in triple:
+            p = tmp_path / "dev.co"
+            p.write_bytes(data[i + o:i + o + s])
+            return str(p)
+    raise AssertionError("libmw_hip.so holds no gfx950 code object")
+
+
+@pytest.mark.skipif(not os.path.exists(READELF), reason="llvm-readelf not in this image")
+def test_sweep_kernels_keep_their_register_budget(tmp_path):
+    from mc_water_ls_mw_amd import build as mwbuild
+    mwbuild.build()
+    notes = subprocess.run([READELF, "--notes", _gfx950_code_object(tmp_path)], capture_output=True, text=True, check=True).stdout
+    seen = 0
+    for blk in notes.split("- .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        m = re.match(r"_ZN2mw7k_sweepILi([12])ELb([01])ELb([01])ELb([01])E", name)
+        if not m:
+            continue
+        seen += 1
+        get = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1))     # noqa: E731
+        withvol = m.group(4) == "1"
+        assert get("vgpr_spill_count") == 0 and get("private_segment_fixed_size") == 0, name
+        assert get("vgpr_count") <= (168 if withvol else 128), (name, get("vgpr_count"))
+    assert seen == 12          # lattices x residency x with / without volume moves
