@@ -113,6 +113,7 @@ struct Ctx {
     int* d_winflag = nullptr;                    // [walker] walker_in_window
     double* d_wstep = nullptr;                   // [walker][2] max_trans, dv_max (bohr) when the walkers' step sizes differ (mw_sweep_steps)
     bool has_steps = false;
+    int sweep_log_ahead = 4;                     // look-ahead allowed when the move log is on (tests pin it to compare builds)
     bool has_windows = false;
     double* d_volume = nullptr;                  // [box] |det hmatrix|
     int* d_wls = nullptr;
@@ -517,19 +518,26 @@ int mw_constants(double out[8])
     return 0;
 }
 
-// The instantiations of the Monte Carlo driver: lattices per walker (= wavefronts per workgroup) x residency (0: positions and
-// rows from global memory / L2, 1: positions in LDS, 2: positions and list rows in LDS) x with / without volume moves.
-static const void* sweep_kernel(int nlat, int residency, bool withvol)
+// The instantiations of the Monte Carlo driver: lattices per walker x residency (0: positions and rows from global memory /
+// L2, 1: positions in LDS, 2: positions and list rows in LDS) x with / without volume moves; and, for walkers whose data
+// stay in global memory, look-ahead over 2 or 4 moves (wavefronts per workgroup = lattices x look-ahead).
+static const void* sweep_kernel(int nlat, int residency, bool withvol, int spec)
 {
-#define MW_SWEEP_K(L, P, R, V) reinterpret_cast<const void*>(&mw::k_sweep<L, P, R, V>)
+#define MW_SWEEP_K(L, SP, P, R, V) reinterpret_cast<const void*>(&mw::k_sweep<L, SP, P, R, V>)
     static const void* const tab[2][3][2] = {
-        {{MW_SWEEP_K(1, false, false, false), MW_SWEEP_K(1, false, false, true)},
-         {MW_SWEEP_K(1, true, false, false),  MW_SWEEP_K(1, true, false, true)},
-         {MW_SWEEP_K(1, true, true, false),   MW_SWEEP_K(1, true, true, true)}},
-        {{MW_SWEEP_K(2, false, false, false), MW_SWEEP_K(2, false, false, true)},
-         {MW_SWEEP_K(2, true, false, false),  MW_SWEEP_K(2, true, false, true)},
-         {MW_SWEEP_K(2, true, true, false),   MW_SWEEP_K(2, true, true, true)}}};
+        {{MW_SWEEP_K(1, 1, false, false, false), MW_SWEEP_K(1, 1, false, false, true)},
+         {MW_SWEEP_K(1, 1, true, false, false),  MW_SWEEP_K(1, 1, true, false, true)},
+         {MW_SWEEP_K(1, 1, true, true, false),   MW_SWEEP_K(1, 1, true, true, true)}},
+        {{MW_SWEEP_K(2, 1, false, false, false), MW_SWEEP_K(2, 1, false, false, true)},
+         {MW_SWEEP_K(2, 1, true, false, false),  MW_SWEEP_K(2, 1, true, false, true)},
+         {MW_SWEEP_K(2, 1, true, true, false),   MW_SWEEP_K(2, 1, true, true, true)}}};
+    static const void* const ahead[2][2][2] = {       // [lattices][look-ahead 2 / 4][volume moves], residency 0
+        {{MW_SWEEP_K(1, 2, false, false, false), MW_SWEEP_K(1, 2, false, false, true)},
+         {MW_SWEEP_K(1, 4, false, false, false), MW_SWEEP_K(1, 4, false, false, true)}},
+        {{MW_SWEEP_K(2, 2, false, false, false), MW_SWEEP_K(2, 2, false, false, true)},
+         {MW_SWEEP_K(2, 4, false, false, false), MW_SWEEP_K(2, 4, false, false, true)}}};
 #undef MW_SWEEP_K
+    if (spec > 1 && residency == 0) return ahead[nlat - 1][spec == 4 ? 1 : 0][withvol ? 1 : 0];
     return tab[nlat - 1][residency][withvol ? 1 : 0];
 }
 
@@ -709,7 +717,9 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_move_energy<true, mw::kLayoutSoA, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
     for (int v = 0; v < 12; ++v)   // the sweep driver's dynamic LDS (image vectors of small or sheared cells, staged positions and rows) can pass 64 KiB
-        HIPCHK(hipFuncSetAttribute(sweep_kernel(1 + (v & 1), (v >> 1) % 3, v >= 6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+        HIPCHK(hipFuncSetAttribute(sweep_kernel(1 + (v & 1), (v >> 1) % 3, v >= 6, 1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+    for (int v = 0; v < 8; ++v)
+        HIPCHK(hipFuncSetAttribute(sweep_kernel(1 + (v & 1), 0, (v & 2) != 0, v >= 4 ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
     g.live = true;
     return 0;
 }
@@ -1801,15 +1811,25 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
         }
         if (g.nnmax_cached <= 32) {                  // rows as short as the lists allow: LDS per walker sets the occupancy
             rstride = std::max(4, (g.nnmax_cached + 3) & ~3);
-            ldslist = mw::sweep_lds(L, g.ivcap, g.N, g.sp.nbins, true, true, rstride, withvol).total <= 24 * 1024;
+            ldslist = mw::sweep_lds(L, L, g.ivcap, g.N, g.sp.nbins, true, true, rstride, withvol).total <= 24 * 1024;
         }
     }
-    const mw::SweepLds lay = mw::sweep_lds(L, g.ivcap, g.N, g.sp.nbins, ldspos, ldslist, rstride, withvol);
-    const size_t static_lds = 512;                   // cells, hand-over words (generous bound)
+    // Look-ahead (walkers whose data stay in global memory): as many moves at once as it takes to put ~4 wavefronts on every
+    // SIMD, at most 4; MW_SWEEP_AHEAD=1|2|4 overrides.  (Small systems: a move touches most of the box -- no look-ahead.)
+    int spec = 1;
+    if (!ldspos) {
+        const long long waves = (long long)count * L;
+        const long long slots = (long long)g.cu * 16;      // 4 SIMDs x 4 wavefronts of <= 128 VGPRs
+        spec = waves * 4 <= slots ? 4 : (waves * 2 <= slots ? 2 : 1);
+        if (const char* e = getenv("MW_SWEEP_AHEAD")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) spec = v; }
+        if (want_log) spec = std::min(spec, g.sweep_log_ahead);
+    }
+    const mw::SweepLds lay = mw::sweep_lds(L, L * spec, g.ivcap, g.N, g.sp.nbins, ldspos, ldslist, rstride, withvol);
+    const size_t static_lds = 1536;                  // cells and their backups, hand-over words, the walker's control block (generous bound)
     if (lay.total + static_lds > (size_t)160 * 1024 - 8 * 1024)
         return fail("mw_sweep: %u bytes of LDS per walker (image vectors %u, positions %u, list rows %u) exceed what a workgroup may have",
                     lay.total, lay.pos - lay.iv, lay.tab - lay.pos, lay.nn - lay.row);
-    const void* kern = sweep_kernel(L, ldslist ? 2 : (ldspos ? 1 : 0), withvol);
+    const void* kern = sweep_kernel(L, ldslist ? 2 : (ldspos ? 1 : 0), withvol, spec);
     const double* wwin = g.has_windows ? (const double*)g.d_wwin : (const double*)nullptr;
     const double* wstep = g.has_steps ? (const double*)g.d_wstep : (const double*)nullptr;
     int w0 = first_walker - 1;
@@ -1817,7 +1837,7 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
                     &g.d_energy, &g.d_wls, &g.d_wmu, &g.d_wacc, &g.d_wswitch, &g.d_wshift, &g.sp, &g.d_wweight, &g.d_whist, &g.d_wuhist,
                     &g.d_sw_mubin, &g.d_sw_binwidth, &g.d_volume, &g.d_wvol, &g.d_wflag, &g.N, &g.S, &g.ivcap, &nmoves, &seed, &move0,
                     &w0, &dlog, &rstride, &wwin, &g.d_wfac, &g.d_wsum, &g.d_winflag, &wstep};
-    HIPCHK(hipLaunchKernel(kern, dim3(count), dim3(64 * L), args, lay.total, g.stream));
+    HIPCHK(hipLaunchKernel(kern, dim3(count), dim3(64 * L * spec), args, lay.total, g.stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

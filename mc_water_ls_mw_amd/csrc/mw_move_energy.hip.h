@@ -263,13 +263,18 @@ __device__ unsigned long long g_lat_stamps[16];
 #define MW_STAMP(k) do { } while (0)
 #endif
 
-template <bool SELFIMG = true, typename PosFn, typename IvFn, typename RowFn, typename NnFn>
+// NOTH > 0 (the Monte Carlo driver's look-ahead, mw_sweep.hip.h): `oth` holds the molecules that moves EARLIER in the chain
+// are trying to move at the same time (-1: none); bit o of `cmask` comes back set when this evaluation read the position of
+// oth[o] -- it is then only valid if that earlier move is rejected.  (The molecule's own index is the caller's to compare.)
+template <bool SELFIMG = true, int NOTH = 0, typename PosFn, typename IvFn, typename RowFn, typename NnFn>
 __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn row, NnFn nnof,
                                                  WaveScratch* __restrict__ ws, int niv,
                                                  int i, int n_i, uint32_t e,
                                                  double xo, double yo, double zo,
-                                                 double xn, double yn, double zn, int lane, MoveRes& res)
+                                                 double xn, double yn, double zn, int lane, MoveRes& res,
+                                                 const int* oth = nullptr, unsigned* cmask = nullptr)
 {
+    unsigned cm = 0u;
     // ---- pass 0: imol's own row; lanes 0..31 take slot l against the OLD position, lanes 32..63 the same
     // slot against the TRIAL position, so that one rsqrt/reciprocal/exp sequence serves both evaluations.
     // `e` arrives as entry (lane & 31) of imol's row, fetched by the caller ahead of time (whatever the row
@@ -281,6 +286,10 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     const bool has = sl < n_i;
     const int j = has ? (int)(e & kJMask) : 0, kimg = has ? (int)(e >> kJBits) : 0;
     if (SELFIMG && __ballot(has && j == i) != 0ull) return false;
+    if constexpr (NOTH > 0) {
+#pragma unroll
+        for (int o = 0; o < NOTH; ++o) if (__ballot(has && j == oth[o]) != 0ull) cm |= 1u << o;
+    }
     double xj, yj, zj, jvx, jvy, jvz;
     getpos(j, xj, yj, zj);
     getiv(kimg, jvx, jvy, jvz);
@@ -460,6 +469,10 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         own_a = own_b; w_a = w_b; ent_a = ent_b;
         if (t0 + 128 < T) fetch(t + 128, own_b, w_b, ent_b);
         const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
+        if constexpr (NOTH > 0) {
+#pragma unroll
+            for (int o = 0; o < NOTH; ++o) if (__ballot(valid && kk == oth[o]) != 0ull) cm |= 1u << o;
+        }
         double xk, yk, zk, kvx, kvy, kvz;
         getpos(kk, xk, yk, zk);
         getiv(k2, kvx, kvy, kvz);
@@ -517,6 +530,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     res.eo = eo; res.en = en;
     res.io = (unsigned int)__popc(mo_) + nto; res.in_ = (unsigned int)__popc(mn_) + ntn;
     res.so = so; res.sn = sn;
+    if constexpr (NOTH > 0) *cmask = cm;
     MW_STAMP(7);
     return true;
 }

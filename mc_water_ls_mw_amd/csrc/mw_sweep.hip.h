@@ -253,10 +253,10 @@ __device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, 
 // parameter, weights, Metropolis test, Wang-Landau update, lattice switch -- and hands {accepted, active lattice} back.
 // Two workgroup barriers per move for two lattices, none for one.
 // -------------------------------------------------------------------------------------
-template <int NLAT>
+template <int NW>                                           // NW = wavefronts in the workgroup
 __device__ __forceinline__ void wg_sync()
 {
-    if constexpr (NLAT == 1) {
+    if constexpr (NW == 1) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -277,7 +277,7 @@ constexpr unsigned kSweepScratchVol = (unsigned)(((kQCap + 1) * 64 * sizeof(uint
 
 // Dynamic LDS of a walker's workgroup (byte offsets), the same arithmetic on the host (launch size) and on the device.
 struct SweepLds { unsigned iv, pos, tab, uni, mv, scr, row, nn, total, scr_bytes; };
-__host__ __device__ inline SweepLds sweep_lds(int L, int ivcap, int N, int nbins, bool ldspos, bool ldslist, int rstride, bool withvol)
+__host__ __device__ inline SweepLds sweep_lds(int L, int nw, int ivcap, int N, int nbins, bool ldspos, bool ldslist, int rstride, bool withvol)
 {
     SweepLds o;
     unsigned p = 0;
@@ -288,7 +288,7 @@ __host__ __device__ inline SweepLds sweep_lds(int L, int ivcap, int N, int nbins
     o.mv = p;  p += kUB * 32u;                                         // their molecule + displacement [kUB]{x, y, z, imol}
     p = (p + 15u) & ~15u;
     o.scr_bytes = withvol ? kSweepScratchVol : kSweepScratch;          // per wavefront: WaveScratch / the full-box energy's queue
-    o.scr = p; p += (unsigned)L * o.scr_bytes;
+    o.scr = p; p += (unsigned)nw * o.scr_bytes;
     o.row = p; p += ldslist ? (unsigned)L * N * rstride * 2u : 0u;     // list rows, 16-bit entries (j | image << 6; N <= 64)
     o.nn = p;  p += ldslist ? (unsigned)L * N : 0u;                    // row lengths, one byte each
     o.total = (p + 15u) & ~15u;
@@ -302,29 +302,31 @@ __host__ __device__ inline SweepLds sweep_lds(int L, int ivcap, int N, int nbins
 // slot-major list); wavefront 0 decides; on rejection every wavefront puts its lattice back the way the reference does
 // (positions mapped back through the NEW reciprocal matrix, :1413-1506).
 // Returns (every wavefront): 1 accepted, 0 rejected, -1 rejected because a cell needed more image vectors than ivcap.
-struct VolDecision { double old_eta, new_eta; };
-template <int NLAT, typename DecideFn>
+// With look-ahead (NW > NLAT wavefronts) the wavefronts beyond the first NLAT have no lattice of their own here: they keep
+// the workgroup's barriers company.
+template <int NLAT, int NW, typename DecideFn>
 __device__ __forceinline__
 int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max, int wv, int lane,
                    double* __restrict__ sx, int* __restrict__ sdec, DecideFn decide)
 {
     constexpr int L = NLAT;
-    const int l = wv;                                                              // this wavefront's lattice
+    const bool active = wv < NLAT;
+    const int l = active ? wv : 0;                                                 // this wavefront's lattice
     // the old cell of this lattice, kept in LDS (c.sbk: [lattice][hmatrix 9 | recip 9 | new recip 9]): eighteen wave-uniform
     // doubles are thirty-six vector registers, held across the full-box energy evaluation
     double* bk_h = c.sbk + 27 * l;
     double* bk_r = bk_h + 9;
     double* bk_n = bk_h + 18;
-    if (lane < 9) { bk_h[lane] = c.shmat[l * 9 + lane]; bk_r[lane] = c.srecip[l * 9 + lane]; }
+    if (active && lane < 9) { bk_h[lane] = c.shmat[l * 9 + lane]; bk_r[lane] = c.srecip[l * 9 + lane]; }
     const double old_vol_l = c.svol[l];
     const int idim = (int)(U[0] * 3.0) + 1, jdim = (int)(U[1] * 3.0) + 1;                       // :1269-1272
     const double dh = (2.0 * U[2] - 1.0) * dv_max;                                              // :1276
-    wg_sync<NLAT>();                                   // (everybody has read the old cells)
-    if (lane == 0) {                                                                            // :1281-1282
+    wg_sync<NW>();                                     // (everybody has read the old cells)
+    if (active && lane == 0) {                                                                  // :1281-1282
         MW_HM(c.shmat + 9 * l, idim, jdim) = MW_HM(c.shmat + 9 * l, idim, jdim) + dh;
         if (idim != jdim) MW_HM(c.shmat + 9 * l, jdim, idim) = MW_HM(c.shmat + 9 * l, jdim, idim) + dh;
     }
-    wg_sync<NLAT>();
+    wg_sync<NW>();
     // The reference takes the lattices in turn and stops at the first whose new cell needs more image vectors than there
     // is room for (:1285-1358; here: the move counts as rejected and is flagged): lattice 2 is then never touched.
     bool bad0 = false;
@@ -339,7 +341,7 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
     double new_e = 0.0;
     int bad = 0;
     bool rescaled = false;
-    if (!bad0) {
+    if (active && !bad0) {
         dev_rescale(c, l, bk_r, c.shmat + 9 * l, lane);
         rescaled = true;
         wave_sync();
@@ -357,35 +359,35 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
         if (niv < 0) bad = 1;
         else new_e = dev_wave_model_energy(c, l, lane);
     }
-    if (lane == 0) { sx[l] = new_e; sdec[2 + l] = bad; }
-    wg_sync<NLAT>();
+    if (active && lane == 0) { sx[l] = new_e; sdec[2 + l] = bad; }
+    wg_sync<NW>();
     int ok = 0, anybad = 0;
     if (wv == 0) {
         anybad = sdec[2] | (L == 2 ? sdec[3] : 0);
         ok = decide(sx[0], L == 2 ? sx[1] : 0.0, anybad);          // (updates the walker's state; energies in every lane)
         if (lane == 0) { sdec[0] = ok; sdec[1] = anybad; }
     }
-    wg_sync<NLAT>();
+    wg_sync<NW>();
     ok = sdec[0]; anybad = sdec[1];
-    if (!ok) {                                                                                   // :1426-1530
+    if (active && !ok) {                                                                         // :1426-1530
         if (lane < 9) bk_n[lane] = c.srecip[l * 9 + lane];
         wave_sync();
         if (lane < 9) { c.shmat[l * 9 + lane] = bk_h[lane]; c.srecip[l * 9 + lane] = bk_r[lane]; }
         if (lane == 0) c.svol[l] = old_vol_l;
         wave_sync();
         if (rescaled) {
-            dev_rescale(c, l, bk_n, c.shmat + 9 * l, lane);                                 // back through the NEW recip
+            dev_rescale(c, l, bk_n, c.shmat + 9 * l, lane);                                      // back through the NEW recip
             const int niv = dev_compute_ivects(c.shmat + 9 * l, c.siv + (size_t)l * c.ivcap * 3,
                                                c.ivect_g + (size_t)l * c.ivcap * 3, c.ivcap, lane);   // :1510-1512
             if (lane == 0 && niv > 0) { c.sniv[l] = niv; c.nivect_g[l] = niv; }
         }
     }
-    if (lane == 0) {                                   // global mirrors of the cell
+    if (active && lane == 0) {                         // global mirrors of the cell
 #pragma unroll
         for (int t = 0; t < 9; ++t) c.hmat_g[l * 9 + t] = c.shmat[l * 9 + t];
         c.vol_g[l] = c.svol[l];
     }
-    wg_sync<NLAT>();
+    wg_sync<NW>();
     return anybad ? -1 : ok;
 }
 
@@ -438,10 +440,19 @@ __device__ __forceinline__ int dev_minu_branch(const WalkerCtl& sp, int ls, doub
     return lsn;
 }
 
-template <int NLAT, bool LDSPOS, bool LDSLIST, bool WITHVOL>
+// SPEC > 1: LOOK-AHEAD for walkers that cannot fill the chip by their number (a few thousand 4096-molecule boxes leave two
+// wavefronts per SIMD; a few dozen leave almost all of it idle).  The workgroup holds SPEC wavefronts per lattice and
+// evaluates SPEC consecutive translations of the chain AT ONCE, all from the configuration the round starts with: the
+// random stream is counter-based, so move m + s knows its molecule and displacement without waiting for move m.  The
+// decisions are then taken in order by wavefront 0.  An evaluation is exactly the one the sequential chain would have made
+// unless an EARLIER move of the round was accepted and moved a molecule whose position this one read (move_energy_wave
+// reports which, bit per earlier slot), or changed the active lattice (the partner lattice's displacement depends on it):
+// the round then ends before that move, and the next round starts with it.  Nothing is approximated -- the chain is the
+// sequential one, move for move and bit for bit -- and a round costs one barrier more than a move did.
+template <int NLAT, int SPEC, bool LDSPOS, bool LDSLIST, bool WITHVOL>
 // Four wavefronts per SIMD are the design point (128 VGPRs; the translation-only build needs 127-136 left to itself, and
 // which side of 128 it lands on depends on what else is compiled with it); the build that carries mc_volume gets three.
-__global__ __launch_bounds__(64 * NLAT) __attribute__((amdgpu_waves_per_eu(WITHVOL ? 3 : 4, WITHVOL ? 3 : 4)))
+__global__ __launch_bounds__(64 * NLAT * SPEC) __attribute__((amdgpu_waves_per_eu(WITHVOL ? 3 : 4, WITHVOL ? 3 : 4)))
 void k_sweep(double* pos, double* hmat, double* ivect,
              int* nivect, const uint32_t* __restrict__ listm, const uint32_t* __restrict__ list,
              const int* __restrict__ nn, const int* __restrict__ order, const int* __restrict__ nns,
@@ -456,21 +467,23 @@ void k_sweep(double* pos, double* hmat, double* ivect,
              const double* __restrict__ wwin, double* __restrict__ wfac, double* __restrict__ wsum,
              int* __restrict__ winflag, const double* __restrict__ wstep)
 {
-    constexpr int L = NLAT, NTHR = 64 * NLAT;
+    constexpr int L = NLAT, NW = NLAT * SPEC, NTHR = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double shmat[2][9], srecip[2][9], svol[2];      // the walker's cells: volume moves change them in place
     __shared__ int sniv[2];
     __shared__ double sbk[2][27];     // a volume move's old hmatrix / recip and new recip per lattice
-    __shared__ double sx[4];          // what wavefront 1 hands to the deciding wavefront: {e_old, e_new} / full-box energies
-    __shared__ int sdec[4];           // the decision: accepted, active lattice (volume moves: accepted, bad, bad per lattice)
+    __shared__ double sx[2 * NW < 4 ? 4 : 2 * NW];   // what every wavefront hands to the deciding one: its {e_old, e_new} (volume moves: full-box energies)
+    __shared__ unsigned scm[NW];      // ... and which earlier moves of the round its evaluation depends on
+    __shared__ int sdec[4 + SPEC];    // the decisions: moves decided this round, active lattice, (volume moves: accepted, bad, bad per lattice), accepted per slot
     __shared__ WalkerCtl ctl;
     WalkerCtl& C = ctl;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = NLAT == 2 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
+    const int wv = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
+    const int slot = wv / NLAT, lat = wv % NLAT;          // this wavefront's move of the round, its lattice
     const int wlk = walker0 + blockIdx.x;
     const int box0 = wlk * L;
     const int nbins = sp.nbins;
-    const SweepLds lay = sweep_lds(L, ivcap, N, nbins, LDSPOS, LDSLIST, rstride, WITHVOL);
+    const SweepLds lay = sweep_lds(L, NW, ivcap, N, nbins, LDSPOS, LDSLIST, rstride, WITHVOL);
     double* siv = reinterpret_cast<double*>(smem_raw + lay.iv);
     double* spos = reinterpret_cast<double*>(smem_raw + lay.pos);
     double* sweight = reinterpret_cast<double*>(smem_raw + lay.tab);
@@ -687,13 +700,99 @@ void k_sweep(double* pos, double* hmat, double* ivect,
     };
 
     int ls = C.ls;                               // the active lattice, followed by every wavefront
-    for (int mv = 0; mv < nmoves; ++mv) {
-        const int ub = mv & (kUB - 1);
-        if (ub == 0) {
+
+    // ---- the decision on a translation (wavefront 0), mc_moves.F90:1090-1209, for the move in slot s of the round ---------
+    // U: the move's uniforms; imol: its molecule; the energies come from the wavefronts of that slot through `sx`.
+    auto decide_trans = [&](int s, const double* U, int imol, unsigned long long movenum) -> bool {
+        if (C.dd && C.within == 0) {                               // top of a cycle: the equilibration check of mc_cycle (:181-210)
+            const int cyc = C.cyc;
+            if (lane == 0) {
+                if (cyc < C.eq_cycles) C.mg.in_window = (C.ls_mu > C.mg.mu_lo && C.ls_mu < C.mg.mu_hi) ? 1 : 0;
+                else if (cyc == C.eq_cycles) { if (!C.mg.in_window) C.flag = C.flag | 2; }   // "Not all walkers have reached their designated window"
+                else C.mg.in_window = 1;                           // a restart
+            }
+            wave_sync();
+        }
+        const bool do_switch = L == 2 && C.always_switch && !(C.dd && C.cyc < C.eq_cycles);   // (:243-248: not while a 'dd' run equilibrates)
+        const double eo0 = sx[2 * (s * NLAT)], en0 = sx[2 * (s * NLAT) + 1];
+        const double eo1 = L == 2 ? sx[2 * (s * NLAT + 1)] : 0.0, en1 = L == 2 ? sx[2 * (s * NLAT + 1) + 1] : 0.0;
+        const int ls0 = C.ls;
+        const double beta = C.beta;
+        const double dE0 = en0 - eo0, dE1 = en1 - eo1;                            // :1090
+        const double bk0 = C.men0, bk1 = C.men1;                                  // :1013
+        const double mn0 = (bk0 - eo0) + en0, mn1 = (bk1 - eo1) + en1;            // :1016,1087
+        int minu_ls = ls0;
+        double mu_new = 0.0, mu_rev = 0.0, eta_new = 0.0, eta_rev = 0.0, diffkT;
+        int k_new = 0, k_rev = 0;
+        if (L == 1) {
+            diffkT = beta * dE0;                                                  // :1106
+        } else {
+            const double mu_cur = C.ls_mu;
+            {
+#pragma clang fp contract(off)
+                const double d = (dE0 - dE1) * beta;                              // :1114 ... and what :1192 takes off again
+                mu_new = mu_cur + d;
+                mu_rev = mu_new - d;
+            }
+            // lanes 0, 1, 2: the trial value, the value a rejection restores, the current one (its bin is carried)
+            const double mul = lane == 0 ? mu_new : (lane == 1 ? mu_rev : mu_cur);
+            int kl = lane_mu_to_bin(C.mg, mul);
+            if (C.k_valid && lane >= 2) kl = C.k_cur;
+            const double el = lane_eta(C.mg, sweight, smub, sbw, mul, kl);        // :1112-1116
+            eta_new = readlane_f64(el, 0); eta_rev = readlane_f64(el, 1);
+            const double eta_old = readlane_f64(el, 2);
+            k_new = __builtin_amdgcn_readlane(kl, 0); k_rev = __builtin_amdgcn_readlane(kl, 1);
+            diffkT = (ls0 == 1 ? dE0 : dE1) * beta + eta_new - eta_old;
+            if (C.minu)                                                           // :1119-1140
+                minu_ls = dev_minu_branch(C, ls0, mn0, mn1, svol[0], svol[1], ls0 == 1 ? bk0 : bk1, ls0 == 1 ? svol[0] : svol[1],
+                                          C.npt != 0, N, eta_new, eta_old, diffkT);
+        }
+        // the move's exponentials in one stream: lane 0 the acceptance; lanes 1, 2 the lattice switch that follows an
+        // accepted / a rejected move (mc_lattice_switch, :1536-1594); lanes 3, 4 the unbiased histogram's factor (:1627-1629)
+        double dkA = 0.0, dkR = 0.0;
+        if (do_switch) {
+            dkA = switch_dk(mn0, mn1, minu_ls);
+            dkR = switch_dk(bk0, bk1, ls0);
+        }
+        const double lun = L == 2 ? C.log_unbiased_norm : 0.0;
+        const double xarg = lane == 0 ? -diffkT : (lane == 1 ? -dkA : (lane == 2 ? -dkR : (lane == 3 ? eta_new - lun : eta_rev - lun)));
+        const double ex = exp_any(xarg);
+        double pacc = readlane_f64(ex, 0);
+        pacc = pacc > 1.0 ? 1.0 : pacc;
+        const bool ok = U[5] < pacc;                                              // :1145-1146 (false for NaN)
+        double eta_fin, cmp_sw, ufac;
+        if (ok) {                                                                 // :1150-1170
+            if (lane == 0) {
+                C.acc = C.acc + 1; C.ls = minu_ls; C.men0 = mn0; C.men1 = mn1;
+                if (L == 2) { C.ls_mu = mu_new; C.k_cur = k_new; C.k_valid = 1; }
+            }
+            eta_fin = eta_new; cmp_sw = readlane_f64(ex, 1); ufac = readlane_f64(ex, 3);
+        } else {                                                                  // :1182-1195
+            if (L == 2 && lane == 0) { C.ls_mu = mu_rev; C.k_cur = k_rev; C.k_valid = 1; }
+            eta_fin = eta_rev; cmp_sw = readlane_f64(ex, 2); ufac = readlane_f64(ex, 4);
+        }
+        wave_sync();
+        int sw = 0;
+        if (L == 2) sw = post_move(eta_fin, cmp_sw, ufac, do_switch, U[6]);
+        if (lane == 0) {
+            if (mvlog) {
+                double* q = mvlog + ((size_t)blockIdx.x * nmoves + movenum) * 8;
+                q[0] = (double)imol; q[1] = (ok ? 1.0 : 0.0) + 2.0 * sw; q[2] = eo0; q[3] = en0; q[4] = eo1; q[5] = en1; q[6] = C.ls_mu; q[7] = diffkT;
+            }
+            if (C.dd) { const int w = C.within + 1; if (w == N) { C.within = 0; C.cyc = C.cyc + 1; } else C.within = w; }
+        }
+        wave_sync();
+        return ok;
+    };
+
+    int mv = 0, ubase = -kUB;                    // next move of the chain (counted within the launch); first move of the uniforms' window
+    while (mv < nmoves) {
+        if (mv + SPEC > ubase + kUB) {
             // the next kUB moves' random numbers: Philox call c of move m is thread 4 m + c (the same stream as the
             // oracle's mwo_move_uniforms: counter (move lo, move hi, walker, call), key = seed), then per move its
             // molecule (mc_moves.F90:1001-1002) and its displacement in the active lattice (:1021-1039)
-            wg_sync<NLAT>();                                       // (the previous batch has been consumed)
+            wg_sync<NW>();                                         // (the previous window has been consumed)
+            ubase = mv;
             for (int c = tid; c < 4 * kUB; c += NTHR) {
                 const unsigned long long m = move0 + (unsigned long long)(mv + (c >> 2));
                 uint32_t ctr[4] = {(uint32_t)m, (uint32_t)(m >> 32), (uint32_t)wlk, (uint32_t)(c & 3)};
@@ -701,7 +800,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 suni[(c >> 2) * 8 + 2 * (c & 3)] = u53(ctr[0], ctr[1]);
                 suni[(c >> 2) * 8 + 2 * (c & 3) + 1] = u53(ctr[2], ctr[3]);
             }
-            wg_sync<NLAT>();
+            wg_sync<NW>();
             if (tid < kUB) {
                 const double* u = suni + tid * 8;
                 const double max_trans = C.max_trans;
@@ -714,29 +813,33 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 smv[tid * 4] = x * max_trans * r; smv[tid * 4 + 1] = y * max_trans * r; smv[tid * 4 + 2] = z * max_trans * r;
                 smv[tid * 4 + 3] = __longlong_as_double((long long)im);
             }
-            wg_sync<NLAT>();
+            wg_sync<NW>();
         }
-        const double* U = suni + ub * 8;     // u0..u7: molecule, direction x3, length, acceptance, lattice switch (:1576), move type (:226)
-        const bool is_volume = WITHVOL && !(U[7] < C.transP);     // WITHVOL = false: translation-only build
-        bool ok = false;
-        int sw = 0, imol = 0;
-        double eo0 = 0.0, en0 = 0.0, eo1 = 0.0, en1 = 0.0, diffkT = 0.0;     // (the move log's columns)
-        bool do_switch = false;
-        if (wv == 0) {
-            if (C.dd && C.within == 0) {                           // top of a cycle: the equilibration check of mc_cycle (:181-210)
-                const int cyc = C.cyc;
-                if (lane == 0) {
-                    if (cyc < C.eq_cycles) C.mg.in_window = (C.ls_mu > C.mg.mu_lo && C.ls_mu < C.mg.mu_hi) ? 1 : 0;
-                    else if (cyc == C.eq_cycles) { if (!C.mg.in_window) C.flag = C.flag | 2; }   // "Not all walkers have reached their designated window"
-                    else C.mg.in_window = 1;                       // a restart
-                }
-                wave_sync();
-            }
-            do_switch = L == 2 && C.always_switch && !(C.dd && C.cyc < C.eq_cycles);   // (:243-248: not while a 'dd' run equilibrates)
-        }
+        const int ub = mv - ubase;                // the round's first move inside the window
+        const double* U0 = suni + ub * 8;         // u0..u7 per move: molecule, direction x3, length, acceptance, lattice switch (:1576), move type (:226)
+        // the round: the run of translations that starts here, at most one per slot (a volume move is a round of its own)
+        int ntr = 0;
+#pragma unroll
+        for (int s = 0; s < SPEC; ++s)
+            if (ntr == s && mv + s < nmoves && !(WITHVOL && !(U0[8 * s + 7] < C.transP))) ++ntr;
 
-        if (is_volume) {                                                          // mc_moves.F90:232-235
+        if (ntr == 0) {                                                           // mc_moves.F90:232-235: a volume move
             if constexpr (WITHVOL) {
+                const double* U = U0;
+                double diffkT = 0.0;
+                bool do_switch = false;
+                if (wv == 0) {
+                    if (C.dd && C.within == 0) {                   // top of a cycle (:181-210), as in decide_trans
+                        const int cyc = C.cyc;
+                        if (lane == 0) {
+                            if (cyc < C.eq_cycles) C.mg.in_window = (C.ls_mu > C.mg.mu_lo && C.ls_mu < C.mg.mu_hi) ? 1 : 0;
+                            else if (cyc == C.eq_cycles) { if (!C.mg.in_window) C.flag = C.flag | 2; }
+                            else C.mg.in_window = 1;
+                        }
+                        wave_sync();
+                    }
+                    do_switch = L == 2 && C.always_switch && !(C.dd && C.cyc < C.eq_cycles);
+                }
                 const double Vo0 = svol[0], Vo1 = L == 2 ? svol[1] : 0.0;
                 auto decide = [&](double e0n, double e1n, int anybad) -> int {
                     // wavefront 0: mc_volume's acceptance (:1361-1410) and, on rejection, the restored order parameter (:1514-1530)
@@ -783,9 +886,9 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                     wave_sync();
                     return okv;
                 };
-                const int rv = volume_move_wg<NLAT>(vc, U, C.dv_max, wv, lane, sx, sdec, decide);
-                ok = rv == 1;
+                const int rv = volume_move_wg<NLAT, NW>(vc, U, C.dv_max, wv, lane, sx, sdec, decide);
                 if (wv == 0) {
+                    int sw = 0;
                     double l12 = 0.0, l21 = 0.0;
                     if (L == 2) { l12 = log(svol[0] / svol[1]); l21 = log(svol[1] / svol[0]); }
                     if (lane == 0) {
@@ -805,17 +908,33 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                         const double ex = exp_any(lane == 0 ? -dk : eta_fin - C.log_unbiased_norm);
                         sw = post_move(eta_fin, readlane_f64(ex, 0), readlane_f64(ex, 1), do_switch, U[6]);
                     }
-                    if (L == 2 && lane == 0) sdec[1] = C.ls;
+                    if (lane == 0) {
+                        if (L == 2) sdec[1] = C.ls;
+                        if (mvlog) {
+                            double* q = mvlog + ((size_t)blockIdx.x * nmoves + mv) * 8;
+                            q[0] = 0.0; q[1] = (rv == 1 ? 1.0 : 0.0) + 2.0 * sw + 4.0; q[2] = C.men0; q[3] = svol[0];
+                            q[4] = L == 2 ? C.men1 : 0.0; q[5] = L == 2 ? svol[1] : 0.0; q[6] = C.ls_mu; q[7] = diffkT;
+                        }
+                        if (C.dd) { const int w = C.within + 1; if (w == N) { C.within = 0; C.cyc = C.cyc + 1; } else C.within = w; }
+                    }
                 }
-                if (L == 2) { wg_sync<NLAT>(); ls = sdec[1]; }     // (MINU or the switch may have changed the active lattice)
+                if (L == 2) { wg_sync<NW>(); ls = sdec[1]; }       // (MINU or the switch may have changed the active lattice)
+                else wave_sync();
             }
-        } else {
-            // ---- translation: this wavefront's lattice ------------------------------------------------------------
-            const double* MV = smv + ub * 4;
-            const double x = MV[0], y = MV[1], z = MV[2];
-            imol = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(MV[3]));
-            const int i = imol - 1;
-            const int l = wv;
+            mv += 1;
+            continue;
+        }
+
+        // ---- translations: slot s of the round is move mv + s, this wavefront's lattice of it ---------------------------
+        const bool mine = slot < ntr;
+        const int l = lat;
+        const double* MV = smv + (ub + (mine ? slot : 0)) * 4;
+        const double x = MV[0], y = MV[1], z = MV[2];
+        const int imol = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(MV[3]));
+        const int i = imol - 1;
+        double* P = pos + (size_t)(box0 + l) * N * 3;                                 // :1007-1018, 1076-1092
+        double pnx = 0.0, pny = 0.0, pnz = 0.0;
+        if (mine) {
             double tx = x, ty = y, tz = z;                                            // the move in the active lattice
             if (L == 2 && l != ls - 1) {                                              // mapped into the partner lattice, :1042-1067
                 const double* rc = srecip[ls - 1];
@@ -828,7 +947,6 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 ty = MW_HM(hn,2,1) * sxf + MW_HM(hn,2,2) * syf + MW_HM(hn,2,3) * szf;
                 tz = MW_HM(hn,3,1) * sxf + MW_HM(hn,3,2) * syf + MW_HM(hn,3,3) * szf;
             }
-            double* P = pos + (size_t)(box0 + l) * N * 3;                             // :1007-1018, 1076-1092
             const uint32_t* LM = listm + (size_t)(box0 + l) * N * kRow;
             const int* NN = nn + (size_t)(box0 + l) * N;
             const double* IVl = siv + (size_t)l * ivcap * 3;
@@ -837,7 +955,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             auto getpos = [&](int j, double& a, double& b, double& c) { const double* p = Pl + 3 * (size_t)j; a = p[0]; b = p[1]; c = p[2]; };
             double xo, yo, zo;
             getpos(i, xo, yo, zo);
-            const double pnx = xo + tx, pny = yo + ty, pnz = zo + tz;                 // :1079
+            pnx = xo + tx; pny = yo + ty; pnz = zo + tz;                              // :1079
             const unsigned short* SR = srow + (size_t)l * N * rstride;
             const unsigned char* SN = snn + l * N;
             auto row = [&](int jx, int sl) -> uint32_t {
@@ -845,103 +963,63 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 else return LM[(size_t)jx * kRow + sl];
             };
             auto nnof = [&](int jx) { return LDSLIST ? (int)SN[jx] : NN[jx]; };
+            // the molecules the EARLIER moves of the round are trying to move: this evaluation is only good if none of those it
+            // reads gets moved (slot o < slot; -1: no such move)
+            int oth[SPEC > 1 ? SPEC - 1 : 1];
+            unsigned cm = 0u;
+            if constexpr (SPEC > 1) {
+#pragma unroll
+                for (int o = 0; o < SPEC - 1; ++o) {
+                    const int io = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(smv[(ub + o) * 4 + 3])) - 1;
+                    oth[o] = o < slot ? io : -1;
+                    if (o < slot && io == i) cm |= 1u << o;
+                }
+            }
             MoveRes res;
-            const bool fast = move_energy_wave(getpos, getiv, row, nnof, ws, sniv[l], i, nnof(i), row(i, lane & 31), xo, yo, zo,
-                                               pnx, pny, pnz, lane, res);
+            unsigned cme = 0u;
+            const bool fast = move_energy_wave<true, SPEC - 1>(getpos, getiv, row, nnof, ws, sniv[l], i, nnof(i), row(i, lane & 31), xo, yo, zo,
+                                                               pnx, pny, pnz, lane, res, oth, &cme);
+            cm |= cme;
             if (!fast) {
                 Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
                 Override tr; tr.idx = i; tr.x = pnx; tr.y = pny; tr.z = pnz;
                 res.eo = local_energy_wave(P, ivect + (size_t)(box0 + l) * ivcap * 3, LM, NN, i, none, none, lane, res.io, res.so);
                 res.en = local_energy_wave(P, ivect + (size_t)(box0 + l) * ivcap * 3, LM, NN, i, tr, none, lane, res.in_, res.sn);
+                cm = (1u << slot) - 1u;                            // (the plain routine keeps no account of what it read)
             }
-            if (L == 2) {
-                if (wv == 1 && lane == 0) { sx[0] = res.eo; sx[1] = res.en; }
-                __syncthreads();
-            } else {
-                wave_sync();                       // (nothing of the walker's state is read ahead of the evaluation)
-            }
-            if (wv == 0) {
-                // ---- the decision (wavefront 0), :1090-1209 ---------------------------------------------------------
-                eo0 = res.eo; en0 = res.en;
-                if (L == 2) { eo1 = sx[0]; en1 = sx[1]; }
-                const int ls0 = C.ls;
-                const double beta = C.beta;
-                const double dE0 = en0 - eo0, dE1 = en1 - eo1;                            // :1090
-                const double bk0 = C.men0, bk1 = C.men1;                                  // :1013
-                const double mn0 = (bk0 - eo0) + en0, mn1 = (bk1 - eo1) + en1;            // :1016,1087
-                int minu_ls = ls0;
-                double mu_new = 0.0, mu_rev = 0.0, eta_new = 0.0, eta_rev = 0.0;
-                int k_new = 0, k_rev = 0;
-                if (L == 1) {
-                    diffkT = beta * dE0;                                                  // :1106
-                } else {
-                    const double mu_cur = C.ls_mu;
-                    {
-#pragma clang fp contract(off)
-                        const double d = (dE0 - dE1) * beta;                              // :1114 ... and what :1192 takes off again
-                        mu_new = mu_cur + d;
-                        mu_rev = mu_new - d;
-                    }
-                    // lanes 0, 1, 2: the trial value, the value a rejection restores, the current one (its bin is carried)
-                    const double mul = lane == 0 ? mu_new : (lane == 1 ? mu_rev : mu_cur);
-                    int kl = lane_mu_to_bin(C.mg, mul);
-                    if (C.k_valid && lane >= 2) kl = C.k_cur;
-                    const double el = lane_eta(C.mg, sweight, smub, sbw, mul, kl);        // :1112-1116
-                    eta_new = readlane_f64(el, 0); eta_rev = readlane_f64(el, 1);
-                    const double eta_old = readlane_f64(el, 2);
-                    k_new = __builtin_amdgcn_readlane(kl, 0); k_rev = __builtin_amdgcn_readlane(kl, 1);
-                    diffkT = (ls0 == 1 ? dE0 : dE1) * beta + eta_new - eta_old;
-                    if (C.minu)                                                           // :1119-1140
-                        minu_ls = dev_minu_branch(C, ls0, mn0, mn1, svol[0], svol[1], ls0 == 1 ? bk0 : bk1, ls0 == 1 ? svol[0] : svol[1],
-                                                  C.npt != 0, N, eta_new, eta_old, diffkT);
-                }
-                // the move's exponentials in one stream: lane 0 the acceptance; lanes 1, 2 the lattice switch that follows an
-                // accepted / a rejected move (mc_lattice_switch, :1536-1594); lanes 3, 4 the unbiased histogram's factor (:1627-1629)
-                double dkA = 0.0, dkR = 0.0;
-                if (do_switch) {
-                    dkA = switch_dk(mn0, mn1, minu_ls);
-                    dkR = switch_dk(bk0, bk1, ls0);
-                }
-                const double lun = L == 2 ? C.log_unbiased_norm : 0.0;
-                const double xarg = lane == 0 ? -diffkT : (lane == 1 ? -dkA : (lane == 2 ? -dkR : (lane == 3 ? eta_new - lun : eta_rev - lun)));
-                const double ex = exp_any(xarg);
-                double pacc = readlane_f64(ex, 0);
-                pacc = pacc > 1.0 ? 1.0 : pacc;
-                ok = U[5] < pacc;                                                         // :1145-1146 (false for NaN)
-                double eta_fin, cmp_sw, ufac;
-                if (ok) {                                                                 // :1150-1170
-                    if (lane == 0) {
-                        C.acc = C.acc + 1; C.ls = minu_ls; C.men0 = mn0; C.men1 = mn1;
-                        if (L == 2) { C.ls_mu = mu_new; C.k_cur = k_new; C.k_valid = 1; }
-                    }
-                    eta_fin = eta_new; cmp_sw = readlane_f64(ex, 1); ufac = readlane_f64(ex, 3);
-                } else {                                                                  // :1182-1195
-                    if (L == 2 && lane == 0) { C.ls_mu = mu_rev; C.k_cur = k_rev; C.k_valid = 1; }
-                    eta_fin = eta_rev; cmp_sw = readlane_f64(ex, 2); ufac = readlane_f64(ex, 4);
-                }
-                wave_sync();
-                if (L == 2) sw = post_move(eta_fin, cmp_sw, ufac, do_switch, U[6]);
-                if (L == 2 && lane == 0) { sdec[0] = ok ? 1 : 0; sdec[1] = C.ls; }
-            }
-            if (L == 2) {
-                __syncthreads();
-                ok = sdec[0] != 0; ls = sdec[1];
-            }
-            if (ok && lane == 0) {                                                        // :1150-1170: this wavefront's lattice
-                P[3 * i] = pnx; P[3 * i + 1] = pny; P[3 * i + 2] = pnz;
-                if (LDSPOS) { double* Sp = spos + ((size_t)l * N + i) * 3; Sp[0] = pnx; Sp[1] = pny; Sp[2] = pnz; }
-            }
-        }   // translation
-        if (wv == 0) {
-            if (mvlog && lane == 0) {
-                double* q = mvlog + ((size_t)blockIdx.x * nmoves + mv) * 8;
-                if (is_volume) { eo0 = C.men0; en0 = svol[0]; eo1 = L == 2 ? C.men1 : 0.0; en1 = L == 2 ? svol[1] : 0.0; }
-                q[0] = (double)imol; q[1] = (ok ? 1.0 : 0.0) + 2.0 * sw + (is_volume ? 4.0 : 0.0); q[2] = eo0; q[3] = en0; q[4] = eo1; q[5] = en1; q[6] = C.ls_mu; q[7] = diffkT;
-            }
-            if (lane == 0 && C.dd) { const int w = C.within + 1; if (w == N) { C.within = 0; C.cyc = C.cyc + 1; } else C.within = w; }
+            if (lane == 0) { sx[2 * wv] = res.eo; sx[2 * wv + 1] = res.en; scm[wv] = cm; }
         }
-        // the next move of this wavefront must see the committed position (and wavefront 0 its own state)
-        wave_sync();
+        wg_sync<NW>();                                 // every evaluation of the round is in (one wavefront: nothing of the walker's state is read ahead of it)
+        if (wv == 0) {
+            unsigned accmask = 0u;
+            int nvalid = 0;
+            for (int s = 0; s < ntr; ++s) {            // the decisions, in the chain's order
+                if (s > 0) {
+                    const unsigned dep = scm[s * NLAT] | (L == 2 ? scm[s * NLAT + (L - 1)] : 0u);
+                    if ((dep & accmask) != 0u || C.ls != ls) break;     // that evaluation no longer stands: the next round starts with it
+                }
+                const int im = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(smv[(ub + s) * 4 + 3]));
+                const bool ok = decide_trans(s, U0 + 8 * s, im, (unsigned long long)(mv + s));
+                if (ok) accmask |= 1u << s;
+                ++nvalid;
+            }
+            if (lane == 0) {
+                sdec[0] = nvalid; sdec[1] = C.ls;
+#pragma unroll
+                for (int s = 0; s < SPEC; ++s) sdec[4 + s] = (int)((accmask >> s) & 1u);
+            }
+        }
+        if (NW > 1) wg_sync<NW>(); else wave_sync();
+        const int nvalid = sdec[0];
+        ls = sdec[1];
+        const bool okm = mine && slot < nvalid && sdec[4 + slot] != 0;
+        if (okm && lane == 0) {                                                       // :1150-1170: this wavefront's lattice
+            P[3 * i] = pnx; P[3 * i + 1] = pny; P[3 * i + 2] = pnz;
+            if (LDSPOS) { double* Sp = spos + ((size_t)l * N + i) * 3; Sp[0] = pnx; Sp[1] = pny; Sp[2] = pnz; }
+        }
+        mv += nvalid;
+        // the next round must see the committed positions: with look-ahead, the other slots' of the same lattice too
+        if (SPEC > 1) wg_sync<NW>(); else wave_sync();
     }
     __syncthreads();
     if (L == 2 && C.record) {

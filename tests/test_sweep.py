@@ -477,3 +477,58 @@ def test_random_single_box_walkers_follow_the_oracle(seed, so):
             _compare(log[w], ref, farm.state(w + 1), [farm.positions(w + 1)])
     finally:
         em.energy_deinit()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["ih1000", "pair1536_wl", "ih1000_npt"])
+def test_lookahead_is_the_sequential_chain(case, monkeypatch):
+    """Look-ahead (several moves of a walker evaluated at once, decided in order; mw_sweep.hip.h) changes nothing: the move
+    log, the final positions and the tables of a run with 2 or 4 moves in flight are BITWISE those of the one-move-at-a-time
+    run -- on boxes small enough that consecutive moves do collide (1000 molecules: a move reads ~150; positions stay in global memory from 683 molecules up), with lattice
+    switches and Wang-Landau updates in between, and with volume moves cutting the rounds short."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.sweep import MuGrid
+
+    def run(ahead):
+        monkeypatch.setenv("MW_SWEEP_AHEAD", str(ahead))
+        if case.startswith("ih1000"):
+            h, x0 = lat.ice_box("ih", (5, 5, 5), 0.0)
+            boxes = [(h, lat.thermalise(x0, 0.12, 300 + w)) for w in range(3)]
+            em, farm = _farm(boxes, 1, 230.0, 1.1)
+            nlat = 1
+        else:
+            z1, z2 = load_golden("ic1536"), load_golden("ih1536")
+            grid = MuGrid(101, -8000.0, 8000.0)
+            boxes = []
+            for w in range(2):
+                boxes += [(z1["h"], lat.thermalise(z1["xyz"], 0.1, 7 + w)), (z2["h"], lat.thermalise(z2["xyz"], 0.1, 18 + w))]
+            em, farm = _farm(boxes, 2, 200.0, 1.1, grid=grid)
+            farm.options(record=True, samplerun=False, always_switch=True, npt=False, wl_factor=0.05)
+            nlat = 2
+        try:
+            if case == "ih1000_npt":
+                em._chk(em.L.mw_sweep_options(0, 1, 0, 1, __import__("ctypes").c_double(1.0), __import__("ctypes").c_double(0.0),
+                                              __import__("ctypes").c_double(0.0), __import__("ctypes").c_double(1.0 / 2.90363081e8)))
+                farm.moves(trans_prob=0.5, vol_prob=0.05, dv_max_ang=0.3)
+            nw = len(boxes) // nlat
+            for w in range(1, nw + 1):
+                farm.set_state(w, 1, farm.initial_mu(w))
+            log = farm.sweep(400, seed=31, move0=5, log=True)
+            pos = [farm.positions(b) for b in range(1, len(boxes) + 1)]
+            st = [farm.state(w) for w in range(1, nw + 1)]
+            tabs = [farm.tables(w) for w in range(1, nw + 1)] if nlat == 2 else []
+            return log, pos, st, tabs
+        finally:
+            em.energy_deinit()
+
+    ref = run(1)
+    assert 20 < ref[0][0][:, 1].astype(int).__and__(1).sum() < 380         # moves are accepted and rejected
+    for ahead in (2, 4):
+        got = run(ahead)
+        assert np.array_equal(got[0], ref[0])
+        for a, b in zip(got[1], ref[1]):
+            assert np.array_equal(a, b)
+        assert got[2] == ref[2]
+        for ta, tb in zip(got[3], ref[3]):
+            for a, b in zip(ta, tb):
+                assert np.array_equal(a, b)
