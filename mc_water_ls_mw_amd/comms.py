@@ -181,6 +181,14 @@ class WalkerComms:
         dist.broadcast(t, src=0, group=self.group)
         return bool(int(t.item()))
 
+    def bcast_int(self, value, root=0):
+        """comms_bcastint (comms_mpi.f90): root's integer for everybody (e.g. mc_cycle_num after a restart, mc_moves.F90:441)."""
+        if not dist.is_initialized():
+            return int(value)
+        t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)
+        dist.broadcast(t, src=root, group=self.group)
+        return int(t.item())
+
     def barrier(self):                                # comms_barrier, comms_mpi.f90:601-618
         if dist.is_initialized():
             dist.barrier(group=self.group)

@@ -74,32 +74,74 @@ int check_live(const char* who)
     return 0;
 }
 
-// the RCCL unique id through a file: rank 0 writes <file>.tmp and renames it, the others wait for <file>
+// The RCCL unique id travels through a file: rank 0 writes <file>.tmp and renames it, the others wait for <file>.
+// The file says WHOSE id it holds -- world size, rank 0's pid and that process's start time (/proc/<pid>/stat) -- and a
+// reader only takes an id whose writer is alive: a file left behind by a job that failed or was killed (its rank 0 never
+// reached mw_comms_finalize) is skipped until this job's rank 0 has replaced it, instead of sending the ranks into
+// ncclCommInitRank with a dead job's id, where they would wait for each other for ever while holding their GPUs.
+// One node by construction (the farm is 8 GPUs of one node; the reference's MPI ranks map to them one to one).
+struct IdRecord {
+    char magic[8];
+    int world, pid;
+    unsigned long long start;
+    ncclUniqueId id;
+};
+
+unsigned long long proc_start_time(int pid)
+{
+    char path[64], buf[1024];
+    snprintf(path, sizeof path, "/proc/%d/stat", pid);
+    FILE* fh = fopen(path, "r");
+    if (!fh) return 0ull;
+    const size_t n = fread(buf, 1, sizeof buf - 1, fh);
+    fclose(fh);
+    buf[n] = 0;
+    const char* p = strrchr(buf, ')');                    // the command name may hold spaces and parentheses
+    if (!p) return 0ull;
+    unsigned long long v = 0ull;
+    int field = 2;                                        // p points at the end of field 2; starttime is field 22
+    for (++p; *p; ++p) {
+        if (*p == ' ') { if (++field == 22) { v = strtoull(p + 1, nullptr, 10); break; } }
+    }
+    return v;
+}
+
 int exchange_id(ncclUniqueId* id)
 {
     if (c.rank == 0) {
-        NCCLOK(ncclGetUniqueId(id));
+        (void)unlink(c.id_file.c_str());                  // whatever an earlier job left here is not ours
+        IdRecord rec;
+        std::memset(&rec, 0, sizeof rec);
+        std::memcpy(rec.magic, "MWCOMMS1", 8);
+        rec.world = c.size; rec.pid = (int)getpid(); rec.start = proc_start_time(rec.pid);
+        NCCLOK(ncclGetUniqueId(&rec.id));
+        *id = rec.id;
         const std::string tmp = c.id_file + ".tmp";
         FILE* fh = fopen(tmp.c_str(), "wb");
         if (!fh) return fail("mw_comms_init: cannot write %s", tmp.c_str());
-        const size_t w = fwrite(id, 1, sizeof *id, fh);
+        const size_t w = fwrite(&rec, 1, sizeof rec, fh);
         fclose(fh);
-        if (w != sizeof *id) return fail("mw_comms_init: short write to %s", tmp.c_str());
+        if (w != sizeof rec) return fail("mw_comms_init: short write to %s", tmp.c_str());
         if (rename(tmp.c_str(), c.id_file.c_str()) != 0) return fail("mw_comms_init: cannot rename %s", tmp.c_str());
         c.own_id_file = true;
         return 0;
     }
     const int timeout_s = env_int("MW_COMMS_TIMEOUT", nullptr, 120);
     const auto t0 = std::chrono::steady_clock::now();
+    const char* why = "no such file";
     for (;;) {
         FILE* fh = fopen(c.id_file.c_str(), "rb");
         if (fh) {
-            const size_t r = fread(id, 1, sizeof *id, fh);
+            IdRecord rec;
+            const size_t r = fread(&rec, 1, sizeof rec, fh);
             fclose(fh);
-            if (r == sizeof *id) return 0;
+            if (r != sizeof rec || std::memcmp(rec.magic, "MWCOMMS1", 8) != 0) why = "not an id record (yet)";
+            else if (rec.world != c.size) why = "written for another world size";
+            else if (rec.start == 0ull || proc_start_time(rec.pid) != rec.start) why = "its writer is gone (left by an earlier job)";
+            else { *id = rec.id; return 0; }
         }
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s))
-            return fail("mw_comms_init: rank %d waited %d s for %s", c.rank, timeout_s, c.id_file.c_str());
+            return fail("mw_comms_init: rank %d waited %d s for %s (%s)", c.rank, timeout_s, c.id_file.c_str(), why);
         std::this_thread::sleep_for(std::chrono::milliseconds(20));
     }
 }
@@ -135,7 +177,13 @@ int mw_comms_init(int* rank_out, int* size_out)
     if (f && *f) c.id_file = f;
     else {
         const char* port = getenv("MASTER_PORT");
-        c.id_file = std::string("/tmp/mw_comms_id.") + ((port && *port) ? port : "0");
+        if (!(port && *port)) {
+            // two jobs on one host would meet at the same default path: a job of more than one rank has to say which it is
+            if (c.size > 1) return fail("mw_comms_init: %d ranks need MASTER_PORT or MW_COMMS_ID_FILE to find each other", c.size);
+            c.id_file = std::string("/tmp/mw_comms_id.solo.") + std::to_string((long long)getpid());
+        } else {
+            c.id_file = std::string("/tmp/mw_comms_id.") + port;
+        }
     }
     ncclUniqueId id;
     if (exchange_id(&id)) return 1;                       // before anything touches the GPU
@@ -148,6 +196,10 @@ int mw_comms_init(int* rank_out, int* size_out)
     HIPOK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     if (reserve(4096, 4096)) return 1;
     NCCLOK(ncclCommInitRank(&c.comm, c.size, id, c.rank));
+    if (c.own_id_file) {                                  // every rank has read it (they are all in the communicator now)
+        (void)unlink(c.id_file.c_str());
+        c.own_id_file = false;
+    }
     c.live = true;
     if (rank_out) *rank_out = c.rank;
     if (size_out) *size_out = c.size;

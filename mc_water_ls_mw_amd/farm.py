@@ -66,11 +66,18 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             em.hmatrix[2 * w + l] = h_pair[l]
             em.ljr[2 * w + l] = (lat.thermalise(x_pair[l], sigma_ang, 7919 * (rank * walkers + w) + l)
                                  if thermalise else np.asarray(x_pair[l], dtype=np.float64))
-    start_cycle, chk = 0, None
+    start_cycle, chk, restart_factors = 0, None, None
     if restart:                                                            # mc_checkpoint_load
         from . import io as mwio
         chk = [mwio.latest_checkpoint(outdir, rank * walkers + w)[1] for w in range(walkers)]
-        start_cycle = chk[0]["cycle"]                                      # (rank 0's, broadcast: :441)
+        start_cycle = chk[0]["cycle"]
+        if any(c["cycle"] != start_cycle for c in chk):
+            raise ValueError("the walkers' checkpoint files are not of the same cycle: "
+                             + ", ".join(str(c["cycle"]) for c in chk[:8]))
+        if comms is not None and comms.world_size > 1:                     # mc_cycle_num is rank 0's, broadcast (:441): ranks that picked
+            agreed = comms.bcast_int(start_cycle, 0)                       # files of different cycles would pair their collectives wrongly
+            if agreed != start_cycle:
+                raise ValueError(f"rank {rank} restarts from cycle {start_cycle}, rank 0 from {agreed}: checkpoint files out of step")
         for w, c in enumerate(chk):
             if c["nwater"] != n or len(c["hmatrix"]) != 2:
                 raise ValueError("checkpoint does not match this run")
@@ -137,11 +144,19 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             if samplerun:
                 comms.set_uhistogram(chk[0]["unbiased_hist"])
             step_t0 = np.array([c["mc_max_trans"] for c in chk]); step_v0 = np.array([c["mc_dv_max"] for c in chk])
-            if not dd:
-                sched.wl_factor = chk[0]["wl_factor"]              # :447-448,462-464
-                sched.invt_active = chk[0]["wl_invt_active"]
-                if sched.wl_factor < sched.orig_wl_factor:
-                    sched.firstcycle = False
+            # wl_factor / wl_invt_active come back on EVERY rank (mc_checkpoint_load, :447-448,462-464): with 'dd' every
+            # walker is a rank with an increment, a 1/t flag and a first-cycle state of its own
+            for k, sc in enumerate(sched.scheds if dd else [sched]):
+                sc.wl_factor = float(chk[k]["wl_factor"])
+                sc.invt_active = bool(chk[k]["wl_invt_active"])
+                if sc.wl_factor < sc.orig_wl_factor:
+                    sc.firstcycle = False
+            if dd or wl_swetnam:                                   # per-walker increments (and Swetnam's visit totals) live on the device
+                # sumhist = sum(histogram) is what the loader sets (:475) -- but only past the 'mw' branch's early return
+                # (:469-472): a restarted 'mw' run keeps the module's initial sumhist = 0 (:94)
+                farm.set_factors(wl_factor=[c["wl_factor"] for c in chk],
+                                 sumhist=[float(np.sum(c["histogram"])) if dd else 0.0 for c in chk])
+                restart_factors = farm.factors()
         for w in range(1, walkers + 1):                            # :703-704: a window on one side of mu = 0 fixes the lattice
             ls0 = chk[w - 1]["ls"] if chk is not None else ((sched.windows[w - 1]["ls"] or 1) if dd else 1)
             farm.set_state(w, ls0, farm.initial_mu(w))
@@ -163,7 +178,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             em._chk(em.L.mw_download_positions_range(1, 2 * walkers, x.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
             ref_ljr = np.einsum("bnk,bkd->bnd", farm._s_ref, h)    # ref_ljr follows the cell (fractional reference kept)
             wt, hi, uh = farm.tables_range()
-            facs = farm.factors()[0] if (dd or wl_swetnam) else np.full(walkers, sched.wl_factor)
+            # (the windows' increments are the schedule's: the device copy lags a halving until the next stretch starts)
+            facs = farm.factors()[0] if wl_swetnam else (sched.wl_factors if dd else np.full(walkers, sched.wl_factor))
             for k in range(walkers):
                 st = farm.state(k + 1)
                 mwio.write_checkpoint(os.path.join(outdir, "checkpoint%03d.dat.%d" % (comms.rank * walkers + k, 1 + nchk % 2)),
@@ -270,6 +286,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                    ref_enthalpy=farm.ref_enthalpy,
                    max_trans_bohr=step_t[:32].tolist(), dv_max_bohr=step_v[:32].tolist())
         out["tables"] = synced
+        out["restart_factors"] = None if restart_factors is None else [np.asarray(a).tolist() for a in restart_factors]
         out["joined"] = joined
         if dd:
             out["windows"] = sched.windows

@@ -100,6 +100,7 @@ contains
        write(0,'(A1)',advance='no')msg(k)
     end do
     write(0,*)
+    k = mw_comms_finalize()     ! (nothing of this rank -- its id file, its communicator -- is left for the next job to trip over)
     stop 'comms (RCCL) failure'
   end subroutine comms_check
 

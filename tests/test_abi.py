@@ -97,3 +97,50 @@ def test_comms_library_exports_every_declared_symbol():
     L.mw_comms_last_error.restype = ctypes.c_char_p
     assert L.mw_comms_barrier() != 0 and b"mw_comms_init first" in L.mw_comms_last_error()
     assert L.mw_comms_finalize() == 0                       # nothing to tear down is not an error
+
+
+def test_comms_bootstrap_skips_an_id_file_whose_writer_is_gone(tmp_path):
+    """The RCCL id travels through a file (mw_comms.h).  A file left by a job that died must not be taken for this job's:
+    ranks other than 0 only accept a record whose writer -- pid and process start time in the record -- is alive.  (No GPU
+    is touched before the id is in hand, so this runs on the CPU; a record that IS accepted gets as far as the GPU probe.)"""
+    import struct
+    import subprocess
+    import sys
+    script = """
+import ctypes, os, sys
+L = ctypes.CDLL(sys.argv[1]); L.mw_comms_last_error.restype = ctypes.c_char_p
+r, s = ctypes.c_int(-1), ctypes.c_int(-1)
+rc = L.mw_comms_init(ctypes.byref(r), ctypes.byref(s))
+print(rc, L.mw_comms_last_error().decode())
+"""
+    lib = os.path.join(ROOT, "mc_water_ls_mw_amd", "libmw_comms.so")
+    idf = tmp_path / "id"
+    env = dict(os.environ, MW_COMMS_ID_FILE=str(idf), MW_COMMS_RANK="1", MW_COMMS_SIZE="2", MW_COMMS_TIMEOUT="1",
+               HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+
+    def start_time(pid):
+        return int(open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()[19])
+
+    def record(world, pid, start):
+        return b"MWCOMMS1" + struct.pack("<iiQ", world, pid, start) + bytes(128)
+
+    def run():
+        p = subprocess.run([sys.executable, "-c", script, lib], env=env, capture_output=True, text=True, timeout=120)
+        return p.stdout.strip()
+    dead = subprocess.Popen([sys.executable, "-c", "pass"])
+    dead.wait()
+    idf.write_bytes(record(2, dead.pid, 12345))                       # a dead job's leftover
+    out = run()
+    assert out.startswith("1 ") and "its writer is gone" in out
+    idf.write_bytes(record(3, os.getpid(), start_time(os.getpid())))    # alive, but another job's shape
+    out = run()
+    assert out.startswith("1 ") and "another world size" in out
+    idf.write_bytes(b"\0" * 40)                                        # the old bare-id format / a torn write
+    assert "not an id record" in run()
+    idf.write_bytes(record(2, os.getpid(), start_time(os.getpid())))    # a live rank 0: accepted -- the next stop is the GPU
+    out = run()
+    assert "waited" not in out and ("GPU" in out or "hip" in out or out.startswith("0 "))
+    env.pop("MW_COMMS_ID_FILE")
+    env.pop("MASTER_PORT", None)
+    out = run()                                                         # no way to tell two jobs on one host apart: refused
+    assert out.startswith("1 ") and "MASTER_PORT or MW_COMMS_ID_FILE" in out

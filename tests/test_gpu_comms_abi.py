@@ -34,7 +34,7 @@ assert L.mw_comms_allreduce_sum(x.ctypes.data_as(dp), 4) != 0            # befor
 out["before_init"] = L.mw_comms_last_error().decode()
 r, s = ctypes.c_int(-1), ctypes.c_int(-1)
 ok(L.mw_comms_init(ctypes.byref(r), ctypes.byref(s)))
-out["rank"], out["size"], out["id_file_exists"] = r.value, s.value, os.path.exists(os.environ["MW_COMMS_ID_FILE"])
+out["rank"], out["size"], out["id_file_gone_once_everybody_joined"] = r.value, s.value, not os.path.exists(os.environ["MW_COMMS_ID_FILE"])
 rng = np.random.default_rng(5)
 a, b, c = rng.normal(size=101), rng.normal(size=101), rng.normal(size=101)
 a0, b0, c0 = a.copy(), b.copy(), c.copy()

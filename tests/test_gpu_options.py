@@ -312,3 +312,45 @@ def test_farm_restarts_from_its_own_checkpoints_and_the_files_are_the_references
         assert np.abs(np.array(a["positions"]) - np.array(r["positions"])).max() < 1e-8 and a["ls"] == r["ls"]
         assert np.allclose(a["tables"][1], r["tables"][1], rtol=1e-12, atol=1e-12)
         assert np.allclose(a["tables"][0], r["tables"][0], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("mode", ["dd", "swetnam"])
+def test_farm_restart_restores_the_per_walker_wang_landau_state(tmp_path, mode):
+    """mc_checkpoint_load reads wl_factor / wl_invt_active on EVERY rank (mc_moves.F90:447-464).  With 'dd' every walker is
+    such a rank -- its own increment, halved by its own flatness checks, its own first-cycle state: a restarted run picks all
+    of it up from the walkers' files and ends where the uninterrupted run ends.  With wl_swetnam the increment and the visit
+    total live on the device; the loader's own rule for the total is sumhist = sum(histogram) past the 'mw' branch's early
+    return and the initial 0 inside it (:469-475), so the device must hold exactly that after a restart."""
+    from mc_water_ls_mw_amd import io as mwio
+    from mc_water_ls_mw_amd.farm import run
+    b = boxes48()
+    kw = dict(walkers=2, temperature=200.0, seed=pin.SEED, thermalise=False, list_update_int=11, mpi_sync_int=10 ** 9,
+              wl_factor=F0, outdir=str(tmp_path))
+    if mode == "dd":      # (leshift puts the pair inside both windows' overlap; flatness checks every 4 cycles halve the increments)
+        kw.update(leshift=True, parallel_strategy="dd", window_overlap=2, eq_mc_cycles=2, flat_chk_int=4, wl_schedule=1, wl_minhist=-1)
+    else:
+        kw.update(wl_swetnam=True, wl_alpha=0.01, flat_chk_int=10 ** 9)
+    full = run([b[0][0], b[1][0]], [b[0][1], b[1][1]], cycles=24, **kw)
+    first = run([b[0][0], b[1][0]], [b[0][1], b[1][1]], cycles=12, chkpt_dump_int=12, **kw)
+    chk = [mwio.latest_checkpoint(str(tmp_path), k)[1] for k in range(2)]
+    assert all(c["cycle"] == 12 for c in chk)
+    if mode == "dd":      # (ref_enthalpy of a leshift run is the starting configuration's; a restart is handed the same values)
+        assert all(c["wl_factor"] == first["wl_factor"] < F0 for c in chk)      # halved twice before the restart, the second time AT cycle 12
+        kw.update(input_ref_enthalpy=np.array(full["ref_enthalpy"]))
+    else:
+        assert all(np.isfinite(c["wl_factor"]) and c["wl_factor"] != F0 for c in chk) and chk[0]["wl_factor"] != chk[1]["wl_factor"]
+    rest = run([b[0][0], b[1][0]], [b[0][1], b[1][1]], cycles=12, restart=True, **kw)
+    fac, sumh, _ = rest["restart_factors"]
+    assert fac == [c["wl_factor"] for c in chk]                                 # every walker its own
+    assert sumh == ([float(np.sum(c["histogram"])) for c in chk] if mode == "dd" else [0.0, 0.0])
+    if mode == "dd":
+        assert rest["wl_factor"] == pytest.approx(full["wl_factor"], rel=1e-12)
+        assert [(e["cycle"], e["walker"], e["action"]) for e in first["flatness_events"] + rest["flatness_events"]] == \
+               [(e["cycle"], e["walker"], e["action"]) for e in full["flatness_events"]]
+        for k in range(2):
+            a, r = full["first_walkers"][k], rest["first_walkers"][k]
+            assert np.abs(np.array(a["positions"]) - np.array(r["positions"])).max() < 1e-8 and a["ls"] == r["ls"]
+            assert np.allclose(a["tables"][1], r["tables"][1], rtol=1e-12, atol=1e-12)
+            assert np.allclose(a["tables"][0], r["tables"][0], rtol=1e-9, atol=1e-11)
+    else:
+        assert np.isfinite(rest["wl_factor"]) and rest["histogram_total"] is None
