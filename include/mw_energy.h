@@ -93,6 +93,10 @@ int mw_get_neighbours(int ils, int *nn, int *jn, int *vn);
 /* ---- compute_model_energy(ils) (molint.F90:407-499) ------------------------------ */
 
 int mw_model_energy(int ils, double *e);
+/* compute_model_energy(ils) exactly as the host issues it: xyz = &ljr(1,1,1,ils) is mirrored first, then evaluated -- one
+ * call, one synchronisation (mw_upload_positions + mw_model_energy cost two round trips; the host's volume move pays this
+ * once per lattice per attempt, mc_moves.F90:1340). */
+int mw_model_energy_of(int ils, const double *xyz, double *e);
 /* Same for boxes first_ils .. first_ils+count-1 in one launch. */
 int mw_model_energy_batch(int first_ils, int count, double *e_out);
 /* In-range interaction counts of the last model-energy evaluation of box ils
@@ -114,6 +118,14 @@ int mw_local_energy(int ils, int imol, double *e);
  * r_prev == NULL skips the second patch. */
 int mw_local_energy_patched(int ils, int imol, const double r_imol[3],
                             int imol_prev, const double r_prev[3], double *e);
+/* The same call split in two, for a host that knows its NEXT question while it still waits for the answer to this
+ * one -- the two lattices of a move, mc_moves.F90:1006-1018 and 1076-1092: `post` sends the request of lattice ils to
+ * that lattice's mail slot and returns, `collect` waits for its reply.  One posted request per lattice at a time; any
+ * other single call on that lattice waits for it first.  Both return 2 -- not an error, no message -- when there is
+ * nothing to gain or to collect: the resident server is off (MW_LOCAL_SERVER=0), nothing was posted, or an entry
+ * point that changes device state ran in between (the reply may predate it: ask again with mw_local_energy_patched). */
+int mw_local_energy_post(int ils, int imol, const double r_imol[3], int imol_prev, const double r_prev[3]);
+int mw_local_energy_collect(int ils, double *e);
 
 /* Batched single-move path: request m is (ils[m], imol[m]) and, if trial_xyz
  * is not NULL, molecule imol[m] is evaluated AT trial_xyz[3m..3m+2] without

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <shared_mutex>
 #include <cstring>
@@ -35,7 +36,7 @@ std::shared_mutex g_gate;
 int g_depth = 0;                        // nesting of exclusive entry points on the thread that holds g_mu
 struct DeviceGuard;
 struct ExclusiveGuard;
-#define MW_LOCK ExclusiveGuard mw_lock_; DeviceGuard mw_dev_
+#define MW_LOCK ExclusiveGuard mw_lock_; DeviceGuard mw_dev_; if (mw_lock_.rc) return 1
 
 int fail(const char* fmt, ...)
 {
@@ -137,6 +138,7 @@ struct Ctx {
     int mmode = 0;
     // pinned, device-visible scratch for single results
     double* h_pin = nullptr;
+    char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_bytes = 0;   // pinned + mapped: one box's cell record / positions on their way in
     double* d_pin = nullptr;
     unsigned long long pin_seq = 0;   // completion word of the single-call kernel (h_pin + 8 doubles)
     // resident server of the single local-energy call (k_local_server): mail slots in host-mapped memory
@@ -149,6 +151,8 @@ struct Ctx {
     int nslots = 0;
     bool srv_running = false, srv_enabled = true;
     unsigned long long sseq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long spend[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // per slot: sequence number of a posted, not yet collected request (0: none)
+    unsigned long long spend_epoch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // host mirrors
     std::vector<double> h_ivect;   // nbox * ivcap * 3
     std::vector<int> h_nivect;     // nbox
@@ -158,14 +162,17 @@ struct Ctx {
 Ctx g;
 std::mutex g_slot_mu[8];                // one per mail slot
 std::mutex g_srv_mu;                    // start / stop of the server
+std::atomic<unsigned long long> g_epoch{0};   // bumped by every exclusive entry point: a reply posted before, collected after, is stale
+std::atomic<bool> g_srv_enabled{true};  // MW_LOCAL_SERVER != 0 (read by the single call before it holds any lock)
 
 int server_stop();                      // defined below (needs the context)
 
 struct ExclusiveGuard {
+    int rc = 0;                         // a fault of the resident server surfaces HERE, at the entry point that stopped it
     ExclusiveGuard()
     {
         g_mu.lock();
-        if (g_depth++ == 0) { g_gate.lock(); if (g.srv_running) (void)server_stop(); }
+        if (g_depth++ == 0) { g_gate.lock(); g_epoch.fetch_add(1, std::memory_order_relaxed); if (g.srv_running) rc = server_stop(); }
     }
     ~ExclusiveGuard()
     {
@@ -494,6 +501,7 @@ void release_all()
                     g.d_mwork};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g.h_pin) (void)hipHostFree(g.h_pin);
+    if (g.h_stage) (void)hipHostFree(g.h_stage);
     for (int s = 0; s < kTimerSlots; ++s) {
         if (g.ev[s][0]) (void)hipEventDestroy(g.ev[s][0]);
         if (g.ev[s][1]) (void)hipEventDestroy(g.ev[s][1]);
@@ -668,6 +676,9 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
     HIPCHK(hipHostMalloc(&g.h_pin, 4096, hipHostMallocMapped));
     std::memset(g.h_pin, 0, 4096);
     HIPCHK(hipHostGetDevicePointer((void**)&g.d_pin, g.h_pin, 0));
+    g.stage_bytes = std::max((size_t)nwater * 3 * sizeof(double), sizeof(mw::CellRecord) + (size_t)MW_MAX_IVECT * 3 * sizeof(double));
+    HIPCHK(hipHostMalloc((void**)&g.h_stage, g.stage_bytes, hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void**)&g.d_stage, g.h_stage, 0));
     {   // mail slots of the resident local-energy server: one per lattice, at most 8
         g.nslots = std::min(nboxes, 8);
         HIPCHK(hipStreamCreateWithFlags(&g.sstream, hipStreamNonBlocking));
@@ -679,6 +690,7 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
         HIPCHK(hipHostGetDevicePointer((void**)&g.d_slots, g.h_slots, 0));
         const char* ev = std::getenv("MW_LOCAL_SERVER");
         g.srv_enabled = !(ev && *ev == '0');
+        g_srv_enabled.store(g.srv_enabled, std::memory_order_release);
         g.req_slots = g.h_slots; g.d_req = g.d_slots;
         const char* rq = std::getenv("MW_SERVER_REQ");
         if (!(rq && std::strcmp(rq, "host") == 0)) {
@@ -776,6 +788,22 @@ static int set_cells_impl(int first_ils, int count, const double* h, int* nivect
         g.h_usegrid[b0 + k] = (!g.force_brute && g.h_grid[b0 + k].nc[0] > 0) ? 1 : 0;
         if (!g.h_usegrid[b0 + k]) g.h_grid[b0 + k].nc[0] = 0;
         if (nivect_out) nivect_out[k] = ns[k];
+    }
+    if (count == 1) {
+        // One box (the host's volume move calls compute_ivects four times per attempt, mc_moves.F90:1285-1358,1510-1512): the
+        // record goes into pinned memory the device reads in place, and one small kernel files it -- a launch and a
+        // synchronisation instead of six transfers.
+        mw::CellRecord* rec = reinterpret_cast<mw::CellRecord*>(g.h_stage);
+        rec->niv = ns[0]; rec->usegrid = g.h_usegrid[b0]; rec->vol = vol[0];
+        std::memcpy(rec->h, h, 9 * sizeof(double));
+        rec->grid = g.h_grid[b0];
+        std::memcpy(g.h_stage + sizeof(mw::CellRecord), ivs[0].data(), ivs[0].size() * sizeof(double));
+        hipLaunchKernelGGL(mw::k_set_cell, dim3(1), dim3(256), 0, g.stream, reinterpret_cast<const mw::CellRecord*>(g.d_stage),
+                           reinterpret_cast<const double*>(g.d_stage + sizeof(mw::CellRecord)), g.d_ivect + b0 * g.ivcap * 3, g.d_nivect + b0,
+                           g.d_hmat + 9 * b0, g.d_volume + b0, g.d_grid + b0, g.d_usegrid + b0);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(g.stream));
+        return 0;
     }
     HIPCHK(hipMemcpyAsync(g.d_ivect + b0 * g.ivcap * 3, &g.h_ivect[b0 * g.ivcap * 3], (size_t)count * g.ivcap * 3 * sizeof(double), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipMemcpyAsync(g.d_nivect + b0, &g.h_nivect[b0], (size_t)count * sizeof(int), hipMemcpyHostToDevice, g.stream));
@@ -959,6 +987,24 @@ int mw_model_energy_batch(int first_ils, int count, double* e_out)
 
 int mw_model_energy(int ils, double* e) { return mw_model_energy_batch(ils, 1, e); }
 
+// compute_model_energy(ils) as the host calls it (molint.F90:407-499; after every volume move, mc_moves.F90:1340): mirror the
+// lattice's positions and evaluate, ONE call -- the positions travel through pinned memory, the energy comes back into pinned
+// memory, one synchronisation at the end.
+int mw_model_energy_of(int ils, const double* xyz, double* e)
+{
+    MW_LOCK;
+    if (check_live() || check_box(ils)) return 1;
+    if (!xyz || !e) return fail("mw_model_energy_of: null pointer");
+    const size_t bytes = (size_t)g.N * 3 * sizeof(double);
+    std::memcpy(g.h_stage, xyz, bytes);
+    HIPCHK(hipMemcpyAsync(g.d_pos + (size_t)(ils - 1) * g.N * 3, g.h_stage, bytes, hipMemcpyHostToDevice, g.stream));
+    if (launch_model_energy(ils, 1)) return 1;
+    HIPCHK(hipMemcpyAsync(g.h_pin + 16, g.d_energy + (ils - 1), sizeof(double), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    *e = g.h_pin[16];
+    return 0;
+}
+
 int mw_model_energy_counts(int ils, long long* npairs, long long* ntriplets)
 {
     MW_LOCK;
@@ -1013,35 +1059,20 @@ int server_stop()
 }
 }  // namespace
 
-// One request through the resident server: g_gate shared (no exclusive entry point is running) + the slot's mutex.
-static int local_energy_served(int ils, int imol, const mw::Override& o1, const mw::Override& o2, double* e)
+// Wait for the reply to request `seq` of mail slot `sl` (the slot's mutex and g_gate shared are held by the caller).
+static int server_wait(int sl, unsigned long long seq, double* e)
 {
-    std::shared_lock<std::shared_mutex> gate(g_gate);
-    if (!g.live) return fail("mw: engine not initialised (call mw_init / energy_init first)");
-    if (ils < 1 || ils > g.nbox) return fail("mw: box index %d outside 1..%d", ils, g.nbox);
-    if (imol < 1 || imol > g.N) return fail("mw: molecule index %d outside 1..%d", imol, g.N);
-    const int sl = (ils - 1) % g.nslots;
-    std::lock_guard<std::mutex> slk(g_slot_mu[sl]);
-    { std::lock_guard<std::mutex> lk(g_srv_mu); if (server_start_locked()) return 1; }
     volatile mw::MailSlot* m = g.h_slots + sl;
-    volatile mw::MailSlot* q = g.req_slots + sl;
-    q->box = ils - 1; q->imol = imol - 1;
-    q->flags = 1 | (o1.idx >= 0 ? 2 : 0) | (o2.idx >= 0 ? 4 : 0);
-    q->prev = o2.idx >= 0 ? o2.idx : 0;
-    q->x1 = o1.x; q->y1 = o1.y; q->z1 = o1.z;
-    q->x2 = o2.x; q->y2 = o2.y; q->z2 = o2.z;
-    const unsigned long long seq = ++g.sseq[sl];
-    // fields, seq_a, seq_b in this order: program order for write-back host memory; the store fences keep it for a
-    // write-combining mapping of device memory too
-    std::atomic_thread_fence(std::memory_order_release); __builtin_ia32_sfence();
-    q->seq_a = seq;
-    std::atomic_thread_fence(std::memory_order_release); __builtin_ia32_sfence();
-    q->seq_b = seq;
-    __builtin_ia32_sfence();
+    // The reply normally shows within microseconds.  Every few thousand polls (a read of host memory that only changes when
+    // a wavefront leaves): is the server still there?  It retires by itself after its idle limit, and a request posted just
+    // then would otherwise wait for a restart nobody triggers.  The no-reply limit is wall-clock (MW_SERVER_TIMEOUT seconds,
+    // default 20), not a poll count.
+    static const double timeout_s = [] { const char* ev = std::getenv("MW_SERVER_TIMEOUT"); const double v = ev ? atof(ev) : 0.0; return v > 0.0 ? v : 20.0; }();
+    std::chrono::steady_clock::time_point t_post{};
     for (long spin = 1;; ++spin) {
         if (m->rep_seq == seq) break;
         __builtin_ia32_pause();
-        if ((spin & 0xfffff) == 0) {                          // every ~million polls: is the server still there?
+        if ((spin & 0xfff) == 0 && reinterpret_cast<volatile int*>(&g.h_head->exited)[0] != 0) {
             std::lock_guard<std::mutex> lk(g_srv_mu);
             if (reinterpret_cast<volatile int*>(&g.h_head->exited)[0] != 0) {
                 // it left (idle limit, racing with this request) -- or it faulted: the stream tells.  The slots' wavefronts
@@ -1059,12 +1090,66 @@ static int local_energy_served(int ils, int imol, const mw::Override& o1, const 
                 if (m->rep_seq == seq) break;
                 if (server_start_locked()) return 1;          // it picks the pending request up: rep_seq != req_seq
             }
-            if (spin > (1L << 34)) return fail("mw: no reply from the local-energy server");
+        }
+        if ((spin & 0xffff) == 0) {
+            const auto now = std::chrono::steady_clock::now();
+            if (t_post == std::chrono::steady_clock::time_point{}) t_post = now;
+            else if (std::chrono::duration<double>(now - t_post).count() > timeout_s)
+                return fail("mw: no reply from the local-energy server within %.0f s", timeout_s);
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    *e = m->energy;
+    if (e) *e = m->energy;
     return 0;
+}
+
+// Post one request to the resident server (g_gate shared + the slot's mutex held by the caller); returns its sequence number.
+static int server_post(int sl, int ils, int imol, const mw::Override& o1, const mw::Override& o2, unsigned long long* seq_out)
+{
+    { std::lock_guard<std::mutex> lk(g_srv_mu); if (server_start_locked()) return 1; }
+    volatile mw::MailSlot* q = g.req_slots + sl;
+    q->box = ils - 1; q->imol = imol - 1;
+    q->flags = 1 | (o1.idx >= 0 ? 2 : 0) | (o2.idx >= 0 ? 4 : 0);
+    q->prev = o2.idx >= 0 ? o2.idx : 0;
+    q->x1 = o1.x; q->y1 = o1.y; q->z1 = o1.z;
+    q->x2 = o2.x; q->y2 = o2.y; q->z2 = o2.z;
+    const unsigned long long seq = ++g.sseq[sl];
+    // fields, then the sequence words: program order for write-back host memory; the store fence keeps it for a
+    // write-combining mapping of device memory too
+    // (the two sequence words need no order between themselves: the server acts when BOTH show the new number)
+    std::atomic_thread_fence(std::memory_order_release); __builtin_ia32_sfence();
+    q->seq_a = seq;
+    q->seq_b = seq;
+    __builtin_ia32_sfence();
+    *seq_out = seq;
+    return 0;
+}
+
+static int served_checks(int ils, int imol, const mw::Override& o2)
+{
+    if (!g.live) return fail("mw: engine not initialised (call mw_init / energy_init first)");
+    if (ils < 1 || ils > g.nbox) return fail("mw: box index %d outside 1..%d", ils, g.nbox);
+    if (imol < 1 || imol > g.N) return fail("mw: molecule index %d outside 1..%d", imol, g.N);
+    if (o2.idx >= g.N) return fail("mw: molecule index %d outside 1..%d", o2.idx + 1, g.N);
+    return 0;
+}
+
+// One request through the resident server: g_gate shared (no exclusive entry point is running; everything of the context is
+// read under the gate: mw_finalize / mw_init rewrite it) + the slot's mutex.
+static int local_energy_served(int ils, int imol, const mw::Override& o1, const mw::Override& o2, double* e)
+{
+    std::shared_lock<std::shared_mutex> gate(g_gate);
+    if (served_checks(ils, imol, o2)) return 1;
+    const int sl = (ils - 1) % g.nslots;
+    std::lock_guard<std::mutex> slk(g_slot_mu[sl]);
+    if (g.spend[sl]) {                                        // a posted request nobody collected: its reply first (the slot holds one request)
+        const unsigned long long ps = g.spend[sl];
+        g.spend[sl] = 0;
+        if (server_wait(sl, ps, nullptr)) return 1;
+    }
+    unsigned long long seq = 0;
+    if (server_post(sl, ils, imol, o1, o2, &seq)) return 1;
+    return server_wait(sl, seq, e);
 }
 
 int mw_local_energy_patched(int ils, int imol, const double r_imol[3], int imol_prev, const double r_prev[3], double* e)
@@ -1074,14 +1159,14 @@ int mw_local_energy_patched(int ils, int imol, const double r_imol[3], int imol_
     o2 = o1;
     if (r_imol) { o1.idx = imol - 1; o1.x = r_imol[0]; o1.y = r_imol[1]; o1.z = r_imol[2]; }
     if (r_prev && imol_prev >= 1 && imol_prev != imol) {
-        if (g.live && (imol_prev < 1 || imol_prev > g.N)) return fail("mw: molecule index %d outside 1..%d", imol_prev, g.N);
         o2.idx = imol_prev - 1; o2.x = r_prev[0]; o2.y = r_prev[1]; o2.z = r_prev[2];
     }
-    if (g.srv_enabled) return local_energy_served(ils, imol, o1, o2, e);
+    if (g_srv_enabled.load(std::memory_order_acquire)) return local_energy_served(ils, imol, o1, o2, e);
 
     // MW_LOCAL_SERVER=0: one launch per call (the path the server replaces; kept as its cross-check)
     MW_LOCK;
     if (check_live() || check_box(ils) || check_mol(imol)) return 1;
+    if (o2.idx >= g.N) return fail("mw: molecule index %d outside 1..%d", o2.idx + 1, g.N);
     const unsigned long long seq = ++g.pin_seq;
     hipLaunchKernelGGL(mw::k_local_energy_single, dim3(1), dim3(64), 0, g.stream, g.d_pos, g.d_ivect, g.d_listm, g.d_nn,
                        ils - 1, imol - 1, o1, o2, 1, g.d_pin, g.N, g.ivcap,
@@ -1102,6 +1187,49 @@ int mw_local_energy_patched(int ils, int imol, const double r_imol[3], int imol_
 }
 
 int mw_local_energy(int ils, int imol, double* e) { return mw_local_energy_patched(ils, imol, nullptr, 0, nullptr, e); }
+
+// The call split in two, for a host that knows its NEXT question while it still waits for the answer to this one (the two
+// lattices of a move, mc_moves.F90:1006-1018): post does not wait, collect does.  One posted request per lattice at a time;
+// any other single call on that lattice waits for it first.  Both return 2 -- not an error, no message -- when there is
+// nothing to gain or to collect: the resident server is switched off (MW_LOCAL_SERVER=0), nothing was posted, or an entry
+// point that changes device state ran in between (the reply may predate it: ask again).
+int mw_local_energy_post(int ils, int imol, const double r_imol[3], int imol_prev, const double r_prev[3])
+{
+    if (!g_srv_enabled.load(std::memory_order_acquire)) return 2;
+    mw::Override o1, o2;
+    o1.idx = -1; o1.x = o1.y = o1.z = 0.0;
+    o2 = o1;
+    if (r_imol) { o1.idx = imol - 1; o1.x = r_imol[0]; o1.y = r_imol[1]; o1.z = r_imol[2]; }
+    if (r_prev && imol_prev >= 1 && imol_prev != imol) { o2.idx = imol_prev - 1; o2.x = r_prev[0]; o2.y = r_prev[1]; o2.z = r_prev[2]; }
+    std::shared_lock<std::shared_mutex> gate(g_gate);
+    if (served_checks(ils, imol, o2)) return 1;
+    const int sl = (ils - 1) % g.nslots;
+    std::lock_guard<std::mutex> slk(g_slot_mu[sl]);
+    if (g.spend[sl]) {
+        const unsigned long long ps = g.spend[sl];
+        g.spend[sl] = 0;
+        if (server_wait(sl, ps, nullptr)) return 1;
+    }
+    unsigned long long seq = 0;
+    if (server_post(sl, ils, imol, o1, o2, &seq)) return 1;
+    g.spend[sl] = seq;
+    g.spend_epoch[sl] = g_epoch.load(std::memory_order_relaxed);
+    return 0;
+}
+
+int mw_local_energy_collect(int ils, double* e)
+{
+    std::shared_lock<std::shared_mutex> gate(g_gate);
+    if (!g.live) return fail("mw: engine not initialised (call mw_init / energy_init first)");
+    if (ils < 1 || ils > g.nbox) return fail("mw: box index %d outside 1..%d", ils, g.nbox);
+    const int sl = (ils - 1) % g.nslots;
+    std::lock_guard<std::mutex> slk(g_slot_mu[sl]);
+    const unsigned long long ps = g.spend[sl];
+    if (!ps) return 2;
+    g.spend[sl] = 0;
+    if (server_wait(sl, ps, e)) return 1;
+    return g.spend_epoch[sl] == g_epoch.load(std::memory_order_relaxed) ? 0 : 2;
+}
 
 int mw_moves_upload(int n, const int* ils, const int* imol, const double* trial_xyz)
 {

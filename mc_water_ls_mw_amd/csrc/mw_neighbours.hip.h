@@ -88,6 +88,24 @@ struct GridDesc {
     float eps;             // bound on the error of the float pre-filter's squared distance (k_cell_pairs)
 };
 
+// One box's cell as the host hands it over (mw_set_cell): header, grid descriptor, then nivect image vectors (3 doubles each).
+struct CellRecord { int niv, usegrid; double vol; double h[9]; GridDesc grid; };
+
+// Files a CellRecord (in pinned host memory the device reads in place) into the engine's arrays.  grid = 1, block = 256
+__global__ __launch_bounds__(256)
+void k_set_cell(const CellRecord* __restrict__ rec, const double* __restrict__ iv_in, double* __restrict__ ivect, int* __restrict__ nivect,
+                double* __restrict__ hmat, double* __restrict__ volume, GridDesc* __restrict__ grid, int* __restrict__ usegrid)
+{
+    const int t = threadIdx.x, niv = rec->niv;
+    for (int k = t; k < 3 * niv; k += 256) ivect[k] = iv_in[k];
+    if (t < 9) hmat[t] = rec->h[t];
+    if (t == 9) { *nivect = niv; *usegrid = rec->usegrid; *volume = rec->vol; }
+    constexpr int kWords = (int)(sizeof(GridDesc) / sizeof(int));
+    static_assert(sizeof(GridDesc) % sizeof(int) == 0, "GridDesc is copied word by word");
+    for (int k = t; k < kWords; k += 256) reinterpret_cast<int*>(grid)[k] = reinterpret_cast<const int*>(&rec->grid)[k];
+}
+
+
 // {min, max} row length of each box of a build: reset on the device (no host round trip in front of a build)
 __global__ void k_init_stats(int* __restrict__ stats, int box0, int count)
 {

@@ -38,9 +38,10 @@ ABI_SYMBOLS = (
     "mw_set_cell", "mw_get_ivects", "mw_upload_positions", "mw_download_positions", "mw_patch_position",
     "mw_upload_positions_range", "mw_download_positions_range", "mw_set_cells_range",
     "mw_build_neighbours", "mw_build_neighbours_batch", "mw_get_neighbours",
-    "mw_model_energy", "mw_model_energy_batch", "mw_model_energy_counts",
+    "mw_model_energy", "mw_model_energy_of", "mw_model_energy_batch", "mw_model_energy_counts",
     "mw_model_energy_counts_total", "mw_neighbour_total",
-    "mw_local_energy", "mw_local_energy_patched", "mw_local_energy_batch", "mw_delta_energy_batch",
+    "mw_local_energy", "mw_local_energy_patched", "mw_local_energy_post", "mw_local_energy_collect",
+    "mw_local_energy_batch", "mw_delta_energy_batch",
     "mw_moves_upload", "mw_moves_launch", "mw_moves_fetch", "mw_moves_counts",
     "mw_model_energy_launch", "mw_step_launch", "mw_model_energy_fetch", "mw_build_neighbours_launch", "mw_sync",
     "mw_timer_start", "mw_timer_stop", "mw_timer_elapsed_ms", "mw_device_info",

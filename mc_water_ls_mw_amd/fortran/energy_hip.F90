@@ -76,6 +76,11 @@ module energy
 
   ! molecule queried last in each lattice (0 = none since the last full mirror)
   integer,allocatable,dimension(:),save :: last_imol
+  ! the request posted ahead for lattice 2 (see compute_local_real_energy): what it carried
+  logical,save :: pend = .false.,overlap_calls = .true.
+  integer,save :: pend_imol = 0
+  integer(c_int),save :: pend_prev = 0
+  real(c_double),save :: pend_r1(3) = 0.0_dp,pend_r2(3) = 0.0_dp
   ! .true. after compute_ivects until the lattice's positions have been mirrored again
   logical,allocatable,dimension(:),save :: stale
 
@@ -126,6 +131,12 @@ module energy
        integer(c_int),value :: ils
        real(c_double),intent(out) :: e
      end function mw_model_energy
+     integer(c_int) function mw_model_energy_of(ils,xyz,e) bind(C,name="mw_model_energy_of")
+       import :: c_int,c_double
+       integer(c_int),value :: ils
+       real(c_double),intent(in) :: xyz(3,*)
+       real(c_double),intent(out) :: e
+     end function mw_model_energy_of
      integer(c_int) function mw_local_energy_patched(ils,imol,r_imol,imol_prev,r_prev,e) &
           bind(C,name="mw_local_energy_patched")
        import :: c_int,c_double
@@ -133,6 +144,16 @@ module energy
        real(c_double),intent(in) :: r_imol(3),r_prev(3)
        real(c_double),intent(out) :: e
      end function mw_local_energy_patched
+     integer(c_int) function mw_local_energy_post(ils,imol,r_imol,imol_prev,r_prev) bind(C,name="mw_local_energy_post")
+       import :: c_int,c_double
+       integer(c_int),value :: ils,imol,imol_prev
+       real(c_double),intent(in) :: r_imol(3),r_prev(3)
+     end function mw_local_energy_post
+     integer(c_int) function mw_local_energy_collect(ils,e) bind(C,name="mw_local_energy_collect")
+       import :: c_int,c_double
+       integer(c_int),value :: ils
+       real(c_double),intent(out) :: e
+     end function mw_local_energy_collect
      integer(c_size_t) function c_strlen(s) bind(C,name="strlen")
        import :: c_size_t,c_ptr
        type(c_ptr),value :: s
@@ -176,6 +197,7 @@ contains
     implicit none
     integer :: ils,im,jm,km,ierr
     real(c_double) :: cdev(8)
+    character(len=8) :: envval
 
     allocate(model_energy(1:num_lattices),stat=ierr)
     if (ierr/=0) stop 'Error allocating model and recip energy arrays'
@@ -184,6 +206,9 @@ contains
     allocate(last_imol(1:num_lattices),stat=ierr)
     if (ierr/=0) stop 'Error allocating last_imol'
     last_imol = 0
+    pend = .false.
+    call get_environment_variable('MW_LOCAL_OVERLAP',envval,status=ierr)
+    overlap_calls = .not.(ierr==0 .and. envval(1:1)=='0')
     allocate(stale(1:num_lattices),stat=ierr)
     if (ierr/=0) stop 'Error allocating stale flags'
     stale = .true.
@@ -278,16 +303,59 @@ contains
     ! As molint.F90:220-404: energy of every pair and triplet involving imol,      !
     ! from the host's CURRENT ljr (see the coherence note at the top).             !
     !------------------------------------------------------------------------------!
-    use model, only : ljr
+    use model,      only : ljr
+    use userparams, only : num_lattices
     implicit none
     integer,intent(in) :: imol,ils
     real(c_double) :: e,r1(3),r2(3)
-    integer(c_int) :: prev
+    integer(c_int) :: prev,rc
+    logical :: hit
+
+    ! The answer may be waiting already: the host asks the same question of lattice 2 right after lattice 1
+    ! (mc_moves.F90:1006-1018, 1076-1092), so the call for lattice 1 posted lattice 2's request before it waited for
+    ! its own reply (below).  The reply is this call's if nothing the request carried has changed since: the
+    ! molecule, its position, the previously queried molecule's position, and no bulk change of the lattice.
+    if (pend) then
+       pend = .false.
+       hit = ils==2 .and. imol==pend_imol .and. .not.stale(2)
+       if (hit) hit = all(ljr(:,1,imol,2)==pend_r1)
+       if (hit .and. pend_prev>=1) hit = all(ljr(:,1,pend_prev,2)==pend_r2)
+       rc = mw_local_energy_collect(2_c_int,e)            ! (a reply nobody wants is still waited for: the slot holds one request)
+       if (rc/=0 .and. rc/=2) call mw_check(rc,'compute_local_real_energy')
+       if (hit .and. rc==0) then
+          compute_local_real_energy = e                     ! (last_imol(2) = imol since the post)
+          return
+       end if
+    end if
 
     if (stale(ils)) then
        call mw_check(mw_upload_positions(int(ils,c_int),ljr(:,1,:,ils)),'compute_local_real_energy')
        stale(ils) = .false.
        last_imol(ils) = 0
+    end if
+    ! Only the FIRST question about a molecule is worth posting ahead: the host asks for the old energies of both lattices
+    ! back to back, but it moves the molecule lattice by lattice in between the two "new energy" calls (mc_moves.F90:1076-
+    ! 1083), so lattice 2's trial position does not exist yet when lattice 1's is evaluated.
+    if (ils==1 .and. num_lattices==2 .and. overlap_calls .and. last_imol(1)/=imol) then
+       if (.not.stale(2)) then
+          r1 = ljr(:,1,imol,2)
+          prev = last_imol(2)
+          if (prev>=1 .and. prev/=imol) then
+             r2 = ljr(:,1,prev,2)
+          else
+             prev = 0
+             r2 = 0.0_dp
+          end if
+          rc = mw_local_energy_post(2_c_int,int(imol,c_int),r1,prev,r2)
+          if (rc==0) then
+             pend = .true. ; pend_imol = imol ; pend_prev = prev ; pend_r1 = r1 ; pend_r2 = r2
+             last_imol(2) = imol
+          else if (rc==2) then
+             overlap_calls = .false.                        ! the resident server is switched off: nothing to overlap with
+          else
+             call mw_check(rc,'compute_local_real_energy')
+          end if
+       end if
     end if
     r1 = ljr(:,1,imol,ils)
     prev = last_imol(ils)
@@ -311,10 +379,9 @@ contains
     implicit none
     integer,intent(in) :: ils
     real(c_double) :: e
-    call mw_check(mw_upload_positions(int(ils,c_int),ljr(:,1,:,ils)),'compute_model_energy')
+    call mw_check(mw_model_energy_of(int(ils,c_int),ljr(:,1,:,ils),e),'compute_model_energy')   ! mirror + evaluate, one call
     last_imol(ils) = 0
     stale(ils) = .false.
-    call mw_check(mw_model_energy(int(ils,c_int),e),'compute_model_energy')
     model_energy(ils) = e
     return
   end subroutine compute_model_energy
