@@ -306,10 +306,6 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     if (cntU > kCap) return false;
     MW_STAMP(1);
 
-    double rinv = 0.0, e1 = 0.0, g = 0.0;
-    if (in) pair_terms(r2, rinv, e1, g);
-    const double qq = kSigSq * rinv * rinv;
-    const double accp = in ? (kAeps * (kBigB * (qq * qq) - 1.0)) * e1 : 0.0;  // :294-297 (old in lanes 0..31, trial in 32..63)
     double t3o = 0.0, t3n = 0.0;
     unsigned int nto = 0, ntn = 0;
 
@@ -353,16 +349,6 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (inu && half == 0 && rank > 0 && start > 0)      // (rows are never empty: j lists i back)
         __hip_atomic_fetch_or(&ws->cm[(start - 1) >> 6], 1ull << ((start - 1) & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    if (inu) {
-        if (half == 0) {
-            ws->q[0][rank] = qx; ws->q[1][rank] = qy; ws->q[2][rank] = qz;
-            ws->c[0][rank] = jvx - qx; ws->c[1][rank] = jvy - qy; ws->c[2][rank] = jvz - qz;
-            ws->rinvo[rank] = rinv; ws->go[rank] = g;
-            ws->flag[rank] = flg;
-        } else {
-            ws->rinvn[rank] = rinv; ws->gn[rank] = g;
-        }
-    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -370,8 +356,8 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     // ---- rows of the in-range j: fetched ahead ----------------------------------------------------
     // The i--j--k stage below walks the rows of all in-range j laid end to end, 64 slots per chunk.  A
     // chunk's slot -> (owner rank, owner's packed word, row entry) fetch is issued TWO CHUNKS AHEAD of its
-    // evaluation -- the first two right here, before the j--i--k stage -- so the row fetch (global memory for
-    // the big boxes) is never waited for.
+    // evaluation -- the first two right here, BEFORE the pair terms of pass 0 (a rsqrt, a reciprocal and an exp per
+    // lane: the arithmetic the row fetch from global memory hides behind) -- so the scan never waits for a row.
     MW_STAMP(2);
     int nbefore = 0;                                         // row ends in the chunks already fetched (wave-uniform)
     auto fetch = [&](int t, int& own, int& wj, uint32_t& ent) {
@@ -389,78 +375,105 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     if (T > 0) fetch(lane, own_a, w_a, ent_a);
     if (T > 64) fetch(64 + lane, own_b, w_b, ent_b);
 
-    // ---- j--i--k triplets: pairs (a < b) of in-range neighbours, one pair per lane ------------
-    // (molint.F90:302-318; a is the earlier list slot, so cos is formed in the reference's order)
-    MW_STAMP(3);
-    const int npairs = cntU * (cntU - 1) / 2;
-    for (int p0 = 0; p0 < npairs; p0 += 64) {
-        const int p = p0 + lane;
-        int b = (int)((1.0f + __builtin_amdgcn_sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);   // (v_sqrt_f32, 1 ulp: the two fix-ups below absorb it;
-                                                                                         //  the IEEE sqrtf expansion costs ~20 instructions)
-        if (b * (b - 1) / 2 > p) --b;
-        if ((b + 1) * b / 2 <= p) ++b;
-        const int a = p - b * (b - 1) / 2;
-        if (p < npairs) {
-            // every operand in one batch of LDS reads (one round trip), whichever positions are in range
-            const int fa = ws->flag[a], fb = ws->flag[b];
-            const double qax = ws->q[0][a], qay = ws->q[1][a], qaz = ws->q[2][a];
-            const double qbx = ws->q[0][b], qby = ws->q[1][b], qbz = ws->q[2][b];
-            const double roa = ws->rinvo[a], rob = ws->rinvo[b], goa = ws->go[a], gob = ws->go[b];
-            const double rna = ws->rinvn[a], rnb = ws->rinvn[b], gna = ws->gn[a], gnb = ws->gn[b];
-            if (fa & fb & 1) {
-                const double ct = (((qax - xo) * (qbx - xo) + (qay - yo) * (qby - yo) + (qaz - zo) * (qbz - zo))
-                                   * roa) * rob;                                                // :316,365
-                if (ct < 0.99) { const double d = ct - kCos0; t3o += goa * (gob * (d * d)); ++nto; }
-            }
-            if (fa & fb & 2) {
-                const double ct = (((qax - xn) * (qbx - xn) + (qay - yn) * (qby - yn) + (qaz - zn) * (qbz - zn))
-                                   * rna) * rnb;
-                if (ct < 0.99) { const double d = ct - kCos0; t3n += gna * (gnb * (d * d)); ++ntn; }
-            }
+    // ---- pass 0's pair terms; the in-range neighbours' records into the scratch --------------------
+    double rinv = 0.0, e1 = 0.0, g = 0.0;
+    if (in) pair_terms(r2, rinv, e1, g);
+    const double qq = kSigSq * rinv * rinv;
+    const double accp = in ? (kAeps * (kBigB * (qq * qq) - 1.0)) * e1 : 0.0;  // :294-297 (old in lanes 0..31, trial in 32..63)
+    if (inu) {
+        if (half == 0) {
+            ws->q[0][rank] = qx; ws->q[1][rank] = qy; ws->q[2][rank] = qz;
+            ws->c[0][rank] = jvx - qx; ws->c[1][rank] = jvy - qy; ws->c[2][rank] = jvz - qz;
+            ws->rinvo[rank] = rinv; ws->go[rank] = g;
+            ws->flag[rank] = flg;
+        } else {
+            ws->rinvn[rank] = rinv; ws->gn[rank] = g;
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- i--j--k triplets (molint.F90:324-343): the rows of all in-range j, end to end --------
-    // Two stages.  SCAN: every slot gets the cheap part (gather, distance test); the ~1/3 that are in
-    // range are queued (entry + owner rank, 8 bytes) in the wave's scratch.  FLUSH: whenever 64 are
-    // queued (and at the end) one full pass does the expensive part -- rsqrt, reciprocal, exp and the two
-    // cosines -- with every lane busy, instead of three passes at one third occupancy.
-    MW_STAMP(4);
-    int nq = 0;                                              // queued entries (wave-uniform)
-    auto flush = [&]() {
+    // ---- the triplets, one ITEM per lane ------------------------------------------------------------
+    // Two kinds of item share one instruction stream (what differs sits in two short sections that a pass without
+    // such items skips):
+    //  F  an in-range third body k of an in-range neighbour j, queued by the scan below: the i--j--k triplet
+    //     (molint.F90:324-343) -- gather k, rsqrt / reciprocal / exp of r_jk, then cos(theta) at j in both geometries;
+    //  P  a pair (a < b) of in-range neighbours: the j--i--k triplet (:302-318; a is the earlier list slot, so cos is
+    //     formed in the reference's order) -- everything it needs is in the scratch already.
+    // In both, cos = (A . B) r_A r_B with A = r_i - q_A from the molecule to neighbour A's image (A = j for F, a for P),
+    // and the term is g_A g_B (cos - cos0)^2.
+    MW_STAMP(3);
+    const int npairs = cntU * (cntU - 1) / 2;
+    int nq = 0;                                              // queued F items (wave-uniform)
+    auto items = [&](int nP) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < nq) {
-            const uint32_t e2 = ws->qe[lane];
-            const int qw = ws->qown[lane];
-            const int own = qw & 31, fl = qw >> 25;
-            const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
-            const double pjx = ws->q[0][own], pjy = ws->q[1][own], pjz = ws->q[2][own];
-            const double ro = ws->rinvo[own], rn = ws->rinvn[own], go_ = ws->go[own], gn_ = ws->gn[own];
-            // r_jk = (r_k + ivect(k)) + (ivect(j) - q_j)   (:332,334, the last two terms taken together in pass 0: the very
-            // expression the scan used for the in-range decision)
-            double xk, yk, zk, kvx, kvy, kvz;
-            getpos(kk, xk, yk, zk);
-            getiv(k2, kvx, kvy, kvz);
-            const double bx = (xk + kvx) + ws->c[0][own];
-            const double by = (yk + kvy) + ws->c[1][own];
-            const double bz = (zk + kvz) + ws->c[2][own];
-            const double s2 = bx * bx + by * by + bz * bz;                       // :335 (in range: tested at scan)
-            double rk, gk, e1k;
-            pair_terms(s2, rk, e1k, gk);
-            if (fl & 1) {
-                const double ct = (-((pjx - xo) * bx + (pjy - yo) * by + (pjz - zo) * bz) * ro) * rk;   // :320,341,365
-                if (ct < 0.99) { const double d = ct - kCos0; t3o += go_ * (gk * (d * d)); ++nto; }
+        const int total = nq + nP;
+        for (int base = 0; base < total; base += 64) {
+            const int idx = base + lane;
+            const bool isF = idx < nq, isP = !isF && idx < total;
+            int ia = 0, fl = 0;
+            double box_ = 0.0, boy_ = 0.0, boz_ = 0.0, bnx = 0.0, bny = 0.0, bnz = 0.0;
+            double rbo = 0.0, rbn = 0.0, gbo = 0.0, gbn = 0.0;
+            if (isF) {
+                const uint32_t e2 = ws->qe[idx];
+                const int qw = ws->qown[idx];
+                ia = qw & 31; fl = qw >> 25;
+                const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
+                // r_jk = (r_k + ivect(k)) + (ivect(j) - q_j)   (:332,334, the last two terms taken together in pass 0: the very
+                // expression the scan used for the in-range decision)
+                double xk, yk, zk, kvx, kvy, kvz;
+                getpos(kk, xk, yk, zk);
+                getiv(k2, kvx, kvy, kvz);
+                box_ = (xk + kvx) + ws->c[0][ia];
+                boy_ = (yk + kvy) + ws->c[1][ia];
+                boz_ = (zk + kvz) + ws->c[2][ia];
+                const double s2 = box_ * box_ + boy_ * boy_ + boz_ * boz_;       // :335 (in range: tested at scan)
+                double rk, gk, e1k;
+                pair_terms(s2, rk, e1k, gk);
+                bnx = box_; bny = boy_; bnz = boz_;
+                rbo = rk; rbn = rk; gbo = gk; gbn = gk;
+            } else if (isP) {
+                const int p = idx - nq;
+                int b = (int)((1.0f + __builtin_amdgcn_sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);   // (v_sqrt_f32, 1 ulp: the two fix-ups below absorb it;
+                                                                                                 //  the IEEE sqrtf expansion costs ~20 instructions)
+                if (b * (b - 1) / 2 > p) --b;
+                if ((b + 1) * b / 2 <= p) ++b;
+                ia = p - b * (b - 1) / 2;
+                fl = ws->flag[ia] & ws->flag[b];
+                const double qbx = ws->q[0][b], qby = ws->q[1][b], qbz = ws->q[2][b];
+                box_ = xo - qbx; boy_ = yo - qby; boz_ = zo - qbz;
+                bnx = xn - qbx; bny = yn - qby; bnz = zn - qbz;
+                rbo = ws->rinvo[b]; rbn = ws->rinvn[b]; gbo = ws->go[b]; gbn = ws->gn[b];
             }
-            if (fl & 2) {
-                const double ct = (-((pjx - xn) * bx + (pjy - yn) * by + (pjz - zn) * bz) * rn) * rk;
-                if (ct < 0.99) { const double d = ct - kCos0; t3n += gn_ * (gk * (d * d)); ++ntn; }
+            if (isF || isP) {
+                const double pax = ws->q[0][ia], pay = ws->q[1][ia], paz = ws->q[2][ia];
+                const double rao = ws->rinvo[ia], ran = ws->rinvn[ia], gao = ws->go[ia], gan = ws->gn[ia];
+                if (fl & 1) {
+                    const double ct = (((xo - pax) * box_ + (yo - pay) * boy_ + (zo - paz) * boz_) * rao) * rbo;   // :316,320,341,365
+                    if (ct < 0.99) { const double d = ct - kCos0; t3o += gao * (gbo * (d * d)); ++nto; }          // :367-368,385-387
+                }
+                if (fl & 2) {
+                    const double ct = (((xn - pax) * bnx + (yn - pay) * bny + (zn - paz) * bnz) * ran) * rbn;
+                    if (ct < 0.99) { const double d = ct - kCos0; t3n += gan * (gbn * (d * d)); ++ntn; }
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
         nq = 0;
     };
+
+    // The P items run HERE, between the row fetch and the first use of what it brings: without them the scan's first
+    // chunk waits for global memory (measured: one merged pass of F and P items at the end saves ~60 instructions per
+    // move and LOSES 5 % -- the fetch latency it exposes costs more than the instructions it saves).
+    if (npairs > 0) items(npairs);
+
+    // ---- i--j--k triplets (molint.F90:324-343): the rows of all in-range j, end to end --------
+    // SCAN: every slot gets the cheap part (gather, distance test); the ~1/3 that are in range are queued (entry + owner
+    // rank, 8 bytes) in the wave's scratch as F items; whenever 64 are queued a pass of F items runs with every lane busy.
+    MW_STAMP(4);
     for (int t0 = 0; t0 < T; t0 += 64) {
         const int t = t0 + lane;
         const bool valid = t < T;
@@ -483,7 +496,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
             const bool selfimg = self && (k2 == ((wj >> 10) & 1023));   // the molecule itself, not an image: k's shift undoes j's
             selfmove = self && !selfimg;
         }
-        const double box_ = (xk + kvx) + cjx;                                    // :332,334 (see the flush)
+        const double box_ = (xk + kvx) + cjx;                                    // :332,334 (see the F items)
         const double boy_ = (yk + kvy) + cjy;
         const double boz_ = (zk + kvz) + cjz;
         const double s2o = box_ * box_ + boy_ * boy_ + boz_ * boz_;              // :335
@@ -510,7 +523,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         const bool inq = valid && !self && (s2o < kRcSq);                        // :361; the k == i self term is dropped
         const unsigned long long mq = __ballot(inq);
         const int c = __popcll(mq);
-        if (nq + c > 64) flush();
+        if (nq + c > 64) items(0);
         if (inq) {
             const int slot = nq + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mq, 0u));
             ws->qe[slot] = e2; ws->qown[slot] = own | (wj << 5);
@@ -518,7 +531,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         nq += c;
     }
     MW_STAMP(5);
-    if (nq > 0) flush();
+    if (nq > 0) items(0);                                    // what the scan left in the queue
     __builtin_amdgcn_wave_barrier();                          // scratch is reused by the wave's next request
     MW_STAMP(6);
 

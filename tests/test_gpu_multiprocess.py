@@ -59,3 +59,21 @@ def test_two_rank_dd_farm_stitches_its_windows():
     lo, hi = res["joined_weight_range"]
     assert hi > lo and res["in_window"] == [True]
     assert [e["action"] for e in res["flatness_events"]][:2] == ["first reset", "halved"]
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no launcher environment: the parent -- before it imports torch or touches the GPU --
+    starts one child per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's ONE json line and exits
+    with the children's status (the rank / size bootstrap of comms_mpi.f90:26-71).  It must never come back as a 1-GPU run."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--walkers", "32", "--moves", "256", "--backend", "gloo", "--share-device", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-1500:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["value"] > res["per_gpu"] > 0
+    assert "2 x 32 independent walkers" in res["config"]["parallelism"]
