@@ -63,10 +63,12 @@ _lib = None
 
 
 def load_library(path=LIB_PATH):
-    """dlopen libmw_hip.so.  Raises if it has not been built -- there is no fallback."""
+    """dlopen libmw_hip.so.  Raises if it has not been built -- there is no fallback.
+    (MW_HIP_LIB: another build of the same library, for A/B measurements inside one GPU session.)"""
     global _lib
     if _lib is not None:
         return _lib
+    path = os.environ.get("MW_HIP_LIB", path)
     if not os.path.exists(path):
         raise MwError(f"{path} not found: build it with `python -m mc_water_ls_mw_amd.build` "
                       "(the mW engine has no CPU fallback)")
