@@ -450,7 +450,8 @@ int launch_build(int first, int count)
         HIPCHK(hipGetLastError());
     }
     if (ngrid < count) {
-        hipLaunchKernelGGL(mw::k_build_neighbours, grid, dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_nivect,
+        const int bt = std::min(256, (g.N + 63) & ~63);                           // a block no larger than the box needs
+        hipLaunchKernelGGL(mw::k_build_neighbours, dim3((g.N + bt - 1) / bt, count), dim3(bt), 0, g.stream, g.d_pos, g.d_ivect, g.d_nivect,
                            g.d_listm, g.d_nn, g.d_cin, g.d_stats, g.d_usegrid, g.N, g.S, g.ivcap, box0);
         HIPCHK(hipGetLastError());
     }

@@ -16,7 +16,7 @@ namespace mw {
 // The distance arithmetic is kept unfused (no FMA contraction) so that the
 // in/out decision at the list radius is bit-identical to the reference's
 // molint.F90:529-537 evaluated on a CPU without FMA.
-//   grid = (ceil(N/256), nboxes_in_launch), block = 256
+//   grid = (ceil(N/block), nboxes_in_launch), block = 64 .. 256 (a multiple of 64, no larger than N needs)
 // =====================================================================================
 __global__ __launch_bounds__(256)
 void k_build_neighbours(const double* __restrict__ pos, const double* __restrict__ ivect,
@@ -28,7 +28,10 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
 #pragma clang fp contract(off)
     const int b = box0 + blockIdx.y;
     if (use_grid[b]) return;              // this box goes through k_cell_search
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // (a wavefront without a molecule has nothing to do: with the reference's own 48-molecule cells three of a 256-thread
+    // block's four wavefronts used to walk the whole 27 N^2 loop for nobody -- the launch uses blocks of one wavefront there)
+    if ((int)(blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) >= N) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const double* P  = pos + (size_t)b * N * 3;
     const double* IV = ivect + (size_t)b * ivcap * 3;
     const int niv = nivect[b];
