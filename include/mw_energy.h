@@ -248,6 +248,8 @@ int mw_sweep_broadcast_tables(int first_walker, int count, const double *weight,
                               const double *unbiased_hist);
 int mw_set_model_energy(int ils, double e);
 int mw_sweep_set_state(int walker, int ls, double ls_mu);
+/* The same for `count` consecutive walkers in two transfers (a farm of thousands sets up in a handful of calls). */
+int mw_sweep_set_states_range(int first_walker, int count, const int *ls, const double *ls_mu);
 int mw_sweep_get_state(int walker, int *ls, double *ls_mu, double *model_energy, long long *accepted);
 /* nmoves moves for walkers first_walker .. first_walker+count-1.  log (may be NULL) receives
  * 8 doubles per walker and move: imol, accepted, old1, new1, old2, new2, ls_mu after, diffkT. */

@@ -1525,6 +1525,19 @@ int mw_sweep_set_state(int walker, int ls, double ls_mu)
     return 0;
 }
 
+int mw_sweep_set_states_range(int first_walker, int count, const int* ls, const double* ls_mu)
+{
+    MW_LOCK;
+    if (check_live() || check_walker(first_walker, count)) return 1;
+    if (!ls || !ls_mu) return fail("mw_sweep_set_states_range: null pointer");
+    for (int k = 0; k < count; ++k)
+        if (ls[k] < 1 || ls[k] > g.sp.nlat) return fail("mw_sweep_set_states_range: active lattice %d of walker %d outside 1..%d", ls[k], first_walker + k, g.sp.nlat);
+    HIPCHK(hipMemcpyAsync(g.d_wls + (first_walker - 1), ls, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g.d_wmu + (first_walker - 1), ls_mu, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
 int mw_sweep_get_state(int walker, int* ls, double* ls_mu, double* model_energy, long long* accepted)
 {
     MW_LOCK;

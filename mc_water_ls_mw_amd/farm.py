@@ -157,9 +157,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                 farm.set_factors(wl_factor=[c["wl_factor"] for c in chk],
                                  sumhist=[float(np.sum(c["histogram"])) if dd else 0.0 for c in chk])
                 restart_factors = farm.factors()
-        for w in range(1, walkers + 1):                            # :703-704: a window on one side of mu = 0 fixes the lattice
-            ls0 = chk[w - 1]["ls"] if chk is not None else ((sched.windows[w - 1]["ls"] or 1) if dd else 1)
-            farm.set_state(w, ls0, farm.initial_mu(w))
+        # :703-704: a window on one side of mu = 0 fixes the lattice; every walker's state in two transfers
+        farm.set_states([chk[w]["ls"] if chk is not None else ((sched.windows[w]["ls"] or 1) if dd else 1) for w in range(walkers)])
         from .lattice import ANG_TO_BOHR
         step_t = np.full(walkers, mc_max_trans_ang * ANG_TO_BOHR)  # mc_max_trans / mc_dv_max of every walker, bohr (io.f90:165-166)
         step_v = np.full(walkers, mc_dv_max_ang * ANG_TO_BOHR)

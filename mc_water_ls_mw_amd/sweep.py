@@ -405,6 +405,23 @@ class WalkerFarm:
         mu = mu - self.dref                                                # leshift, :860
         return mu * self.beta - n * math.log(v[b] / v[b + 1])
 
+    def initial_mus(self):
+        """initial_mu of every walker in one go (main.f90:170-174 / mc_moves.F90:857-862, vectorised)."""
+        if self.nlat == 1:
+            return np.zeros(self.nwalkers)
+        e, v, n = self.em.model_energy, self.em.volume, self.em.nwater
+        mu = (e[0::2] + self.pressure * v[0::2]) - (e[1::2] + self.pressure * v[1::2])
+        mu = mu - self.dref                                                # leshift, :860
+        lg = np.array([math.log(r) for r in (v[0::2] / v[1::2])])          # (libm's log, as initial_mu: numpy's may differ in the last bit)
+        return mu * self.beta - n * lg
+
+    def set_states(self, ls, ls_mu=None, first_walker=1):
+        """Active lattice and order parameter of `len(ls)` consecutive walkers in two transfers (ls_mu None: initial_mus)."""
+        ls = np.ascontiguousarray(np.broadcast_to(ls, (self.nwalkers - first_walker + 1,)) if np.ndim(ls) == 0 else ls, dtype=np.int32)
+        mu = self.initial_mus()[first_walker - 1:first_walker - 1 + len(ls)] if ls_mu is None else ls_mu
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        self.em._chk(self.L.mw_sweep_set_states_range(first_walker, len(ls), ls.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), mu.ctypes.data_as(_dp)))
+
     def set_state(self, walker, ls=1, ls_mu=None):
         mu = self.initial_mu(walker) if ls_mu is None else ls_mu
         self.em._chk(self.L.mw_sweep_set_state(walker, ls, ctypes.c_double(mu)))

@@ -30,8 +30,7 @@ def farm_for(cells, nlat, walkers, sigma, temperature):
     em.model_energy_batch(1, walkers * nlat)
     grid = MuGrid(101, -8000.0, 8000.0) if nlat == 2 else None
     farm = WalkerFarm(em, nlat, temperature, 1.1, grid=grid)
-    for w in range(1, walkers + 1):
-        farm.set_state(w, 1, farm.initial_mu(w))
+    farm.set_states(1)
     return em, farm
 
 
