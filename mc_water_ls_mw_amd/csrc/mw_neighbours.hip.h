@@ -623,7 +623,10 @@ void k_cell_pairs(const double* __restrict__ pos, const double* __restrict__ ive
                     const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.x)));
                     const float yi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.y)));
                     const float zi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, o.z)));
-                    int cnt = t0 == 0 ? 0 : __builtin_amdgcn_readfirstlane(W.cnt[il]);       // (first batch: the rows are empty)
+                    // (first batch: the rows are empty.  Later batches: the count WITHOUT the ambiguity flag in bit 30 -- with it,
+                    //  every later hit of a flagged row landed "past the row's end", was counted but not stored, and the sort read
+                    //  whatever LDS held in its place: a wild molecule index in the double-precision re-decision, a GPU fault)
+                    int cnt = t0 == 0 ? 0 : (__builtin_amdgcn_readfirstlane(W.cnt[il]) & 0x3fffffff);
                     int inner_l = 0, amb_l = 0;
 #pragma unroll
                     for (int ch = 0; ch < NCH; ++ch) {

@@ -199,6 +199,38 @@ def test_cell_grid_list_equals_reference_enumeration(case, c_oracle, monkeypatch
         assert np.array_equal(jn, ojn) and np.array_equal(vn, ovn), mode
 
 
+def test_cell_grid_rows_with_several_candidate_batches_and_ambiguous_hits(monkeypatch):
+    """The 1536-molecule Ic / Ih cells have grid cells large enough that a block's candidates come in TWO batches of
+    registers (> 320), and among 64 thermal boxes some rows carry a hit too close to the list radius to call in single
+    precision.  Such a row's count keeps a flag bit between the batches; round 2's kernel added that bit into the slot
+    arithmetic of the second batch, dropped its hits, sorted LDS garbage in their place and -- after a run with other box
+    sizes had left other garbage -- took a wild molecule index into the double-precision re-decision (a GPU memory fault,
+    found in round 3).  Every list of the 64 boxes against the all-pairs builder, entry for entry."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.energy import load_boxes
+    z = [load_golden("ic1536"), load_golden("ih1536")]
+    hs, xs = [], []
+    for w in range(32):
+        for l in range(2):
+            hs.append(z[l]["h"]); xs.append(lat.thermalise(z[l]["xyz"], 0.1, 1000 * l + w))
+    lists, energies = {}, {}
+    for mode in ("grid", "brute"):
+        if mode == "brute":
+            monkeypatch.setenv("MW_FORCE_BRUTE_NEIGHBOURS", "1")
+        else:
+            monkeypatch.delenv("MW_FORCE_BRUTE_NEIGHBOURS", raising=False)
+        em = load_boxes(hs, xs)
+        try:
+            lists[mode] = [em.neighbours(b) for b in range(1, 65)]
+            energies[mode] = em.model_energy.copy()
+        finally:
+            em.energy_deinit()
+    for b in range(64):
+        for a, r in zip(lists["grid"][b], lists["brute"][b]):
+            assert np.array_equal(a, r), b
+    assert np.allclose(energies["grid"], energies["brute"], rtol=1e-12, atol=0.0)
+
+
 def test_single_call_local_energy_follows_host_moves(c_oracle):
     """The drop-in protocol of mc_water_translation (mc_moves.F90:1010-1190):
     old energy, move the molecule on the HOST only, new energy, silently revert
