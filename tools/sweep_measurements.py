@@ -78,6 +78,10 @@ if only in (None, "ih4096"):
 # few walkers: the chip is filled from inside the chains (look-ahead, MW_SWEEP_AHEAD)
 if only in ("few4096",):
     run("ih4096 x 64 walkers", [(h, x)], 1, 64, 600, out)
+if only in ("one4096",):
+    run("ih4096 x 1 walker", [(h, x)], 1, 1, 2000, out)
+if only in ("one1536",):
+    run("pair1536 x 1 walker, WL update + switch per move", [(ic1536["h"], ic1536["xyz"]), (ih1536["h"], ih1536["xyz"])], 2, 1, 2000, out, wl=True)
 if only in ("few1536",):
     run("pair1536 x 32 walkers, WL update + switch per move", [(ic1536["h"], ic1536["xyz"]), (ih1536["h"], ih1536["xyz"])], 2, 32, 600, out, wl=True)
 print(json.dumps(out, indent=1))
