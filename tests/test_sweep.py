@@ -532,3 +532,50 @@ def test_lookahead_is_the_sequential_chain(case, monkeypatch):
         for ta, tb in zip(got[3], ref[3]):
             for a, b in zip(ta, tb):
                 assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dense", "thin_sheared", "ice_sheared"])
+def test_lookahead_on_awkward_boxes(kind, so, monkeypatch):
+    """Look-ahead where the fused routine declines and the plain one steps in (compressed lattices: rows beyond 32 entries,
+    more than 24 in-range neighbours -- the plain routine keeps no account of what it read, so such a move depends on every
+    earlier move of its round), in cells thin enough that a molecule neighbours its own image, and in sheared cells: 4 moves
+    in flight give the one-at-a-time chain bit for bit, and that chain is the oracle's."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.energy import load_boxes
+    from mc_water_ls_mw_amd.sweep import WalkerFarm
+    rng = np.random.default_rng({"dense": 5, "thin_sheared": 6, "ice_sheared": 7}[kind])
+    if kind == "dense":
+        h, x = lat.ice_ih_cell(2.3)
+        h, x = lat.replicate(h, x, (5, 5, 4))                    # 800 molecules, ~40 list neighbours each
+    elif kind == "thin_sheared":
+        h, x = lat.ice_ic_cell(2.75)
+        h, x = lat.replicate(h, x, (1, 10, 9))                   # one cell thick along a: images of a molecule among its neighbours
+    else:
+        h, x = lat.ice_ic_cell(2.8)
+        h, x = lat.replicate(h, x, (5, 5, 4))                    # 800 molecules
+    if kind != "dense":
+        shear = np.eye(3) + rng.uniform(-0.05, 0.05, (3, 3)) * (1 - np.eye(3))
+        h, x = h @ shear, x @ shear
+    assert len(x) * 24 > 16 * 1024                               # positions stay in global memory: the look-ahead builds
+    boxes = [(np.ascontiguousarray(h), lat.thermalise(np.ascontiguousarray(x), 0.05, 40 + w)) for w in range(2)]
+    nmoves = 150
+
+    def run(ahead):
+        monkeypatch.setenv("MW_SWEEP_AHEAD", str(ahead))
+        em = load_boxes([b[0] for b in boxes], [b[1] for b in boxes], maxneigh=64)
+        farm = WalkerFarm(em, 1, 260.0, 0.9)
+        try:
+            farm.set_states(1, np.zeros(2))
+            log = farm.sweep(nmoves, seed=12, move0=0, log=True)
+            return log, [farm.positions(b) for b in (1, 2)], [farm.state(w) for w in (1, 2)], farm
+        finally:
+            em.energy_deinit()
+
+    log1, pos1, st1, farm = run(1)
+    log4, pos4, st4, _ = run(4)
+    assert np.array_equal(log4, log1) and all(np.array_equal(a, b) for a, b in zip(pos4, pos1)) and st4 == st1
+    assert 5 < int(log1[0][:, 1].sum()) < nmoves - 5
+    for w in range(2):
+        ref = so.sweep(nmoves, 12, w, 0, [boxes[w][0]], [boxes[w][1]], farm.beta, farm.max_trans, maxneigh=64)
+        _compare(log1[w], ref, st1[w], [pos1[w]])
