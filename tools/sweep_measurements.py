@@ -18,7 +18,7 @@ from mc_water_ls_mw_amd.energy import EnergyModule  # noqa: E402
 from mc_water_ls_mw_amd.sweep import MuGrid, WalkerFarm  # noqa: E402
 
 
-def farm_for(cells, nlat, walkers, sigma, temperature):
+def farm_for(cells, nlat, walkers, sigma, temperature, mu_range=8000.0):
     n = len(cells[0][1])
     em = EnergyModule(n, walkers * nlat)
     for w in range(walkers):
@@ -28,14 +28,14 @@ def farm_for(cells, nlat, walkers, sigma, temperature):
     em.setup_boxes()
     em.build_neighbours_batch(1, walkers * nlat)
     em.model_energy_batch(1, walkers * nlat)
-    grid = MuGrid(101, -8000.0, 8000.0) if nlat == 2 else None
+    grid = MuGrid(101, -mu_range, mu_range) if nlat == 2 else None
     farm = WalkerFarm(em, nlat, temperature, 1.1, grid=grid)
     farm.set_states(1)
     return em, farm
 
 
-def run(name, cells, nlat, walkers, nmoves, out, wl=False, npt=False):
-    em, farm = farm_for(cells, nlat, walkers, 0.1, 200.0)
+def run(name, cells, nlat, walkers, nmoves, out, wl=False, npt=False, sigma=0.1, mu_range=8000.0):
+    em, farm = farm_for(cells, nlat, walkers, sigma, 200.0, mu_range)
     if wl:            # what the replica farm runs per move: Wang-Landau update + a lattice-switch attempt (farm.py set_options)
         farm.options(record=True, samplerun=False, always_switch=True, npt=npt, wl_factor=0.05)
     if npt:           # io.f90:171-172: volume moves 1/N against translations 0.5
@@ -69,6 +69,9 @@ if only in (None, "pair48wl"):
 if only in (None, "npt48"):
     run("pair48 x 8192 walkers, NPT (volume moves), WL update + switch per move", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 8192, 480, out,
         wl=True, npt=True)
+if only in ("farm48",):     # the replica farm's own settings (farm.py defaults): +-400 window, so walkers do switch lattice
+    run("pair48 x 8192 walkers, WL update + switch per move, farm window", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 8192, 480, out,
+        wl=True, sigma=0.05, mu_range=400.0)
 ic1536, ih1536 = g("ic1536"), g("ih1536")
 if only in (None, "pair1536"):
     run("pair1536 x 2048 walkers", [(ic1536["h"], ic1536["xyz"]), (ih1536["h"], ih1536["xyz"])], 2, 2048, 300, out)
