@@ -257,6 +257,11 @@ int mw_sweep_translation(int first_walker, int count, int nmoves, unsigned long 
                          unsigned long long move0, double *log);
 int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigned long long seed,
                                 unsigned long long move0, int want_log);
+/* Dynamic LDS (bytes) of one walker's workgroup when its positions and list rows live in LDS (nwater <= 64), for list
+ * rows of `row_stride` entries -- host arithmetic only, no device needed.  Eight walkers share a compute unit while this
+ * plus the kernel's static LDS stays within 20480 bytes; the launch picks row_stride = the longest row of any box,
+ * rounded up to even.  Returns -1 for arguments no launch would use. */
+int mw_sweep_lds_bytes(int nlat, int nwater, int nbins, int row_stride, int volume_moves, int samplerun);
 
 /* HIP-event timers on the engine's stream: slot in 0..4095. */
 int mw_timer_start(int slot);

@@ -1915,6 +1915,13 @@ int mw_sweep_get_switches(int walker, long long* switches)
     return 0;
 }
 
+int mw_sweep_lds_bytes(int nlat, int nwater, int nbins, int row_stride, int volume_moves, int samplerun)
+{
+    if (nlat < 1 || nlat > 2 || nwater < 1 || nwater > 64 || nbins < 0 || row_stride < 2 || row_stride > 32) return -1;
+    return (int)mw::sweep_lds(nlat, nlat, 32 /* image vectors per box the engine starts with (mw_init) */, nwater, nbins, true, true,
+                              row_stride, volume_moves != 0, samplerun != 0).total;
+}
+
 int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigned long long seed, unsigned long long move0, int want_log)
 {
     MW_LOCK;
@@ -1951,10 +1958,11 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
             g.nnmax_cached = mx;                     // stats = {min nn, max nn} of the last list build of each box
             g.nnmax_version = g.list_version;
         }
-        if (g.nnmax_cached <= 32) {                  // rows as short as the lists allow: LDS per walker sets the occupancy
-            rstride = std::max(4, (g.nnmax_cached + 3) & ~3);
-            ldslist = mw::sweep_lds(L, L, g.ivcap, g.N, g.sp.nbins, true, true, rstride, withvol).total <= 24 * 1024;
-        }
+        if (g.nnmax_cached <= 32) {                  // rows as short as the lists allow (entries are read one at a time: any even
+            rstride = std::max(4, (g.nnmax_cached + 1) & ~1);      // stride will do): LDS per walker sets the occupancy -- a replica farm's
+            ldslist = mw::sweep_lds(L, L, g.ivcap, g.N, g.sp.nbins, true, true, rstride, withvol, g.sp.samplerun != 0).total <= 24 * 1024;
+        }                                            // longest row of 16 384 boxes grows from 22 to 26 entries as the walkers spread out
+                                                     // (at a stride of 28 a walker went over 20 KiB: seven per CU instead of eight, -12 %)
     }
     // Look-ahead (walkers whose data stay in global memory): as many moves at once as it takes to put ~4 wavefronts on every
     // SIMD, at most 4; MW_SWEEP_AHEAD=1|2|4 overrides.  (Small systems: a move touches most of the box -- no look-ahead.)
@@ -1966,7 +1974,7 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
         if (const char* e = getenv("MW_SWEEP_AHEAD")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) spec = v; }
         if (want_log) spec = std::min(spec, g.sweep_log_ahead);
     }
-    const mw::SweepLds lay = mw::sweep_lds(L, L * spec, g.ivcap, g.N, g.sp.nbins, ldspos, ldslist, rstride, withvol);
+    const mw::SweepLds lay = mw::sweep_lds(L, L * spec, g.ivcap, g.N, g.sp.nbins, ldspos, ldslist, rstride, withvol, g.sp.samplerun != 0);
     const size_t static_lds = 1536;                  // cells and their backups, hand-over words, the walker's control block (generous bound)
     if (lay.total + static_lds > (size_t)160 * 1024 - 8 * 1024)
         return fail("mw_sweep: %u bytes of LDS per walker (image vectors %u, positions %u, list rows %u) exceed what a workgroup may have",

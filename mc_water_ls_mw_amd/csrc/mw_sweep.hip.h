@@ -276,16 +276,20 @@ constexpr unsigned kSweepScratch = (unsigned)((sizeof(WaveScratch) + 15) & ~(siz
 constexpr unsigned kSweepScratchVol = (unsigned)(((kQCap + 1) * 64 * sizeof(uint32_t)) > kSweepScratch ? ((kQCap + 1) * 64 * sizeof(uint32_t)) : kSweepScratch);
 
 // Dynamic LDS of a walker's workgroup (byte offsets), the same arithmetic on the host (launch size) and on the device.
+// Every byte counts for the reference's own 48-molecule cells: eight walkers share a CU when a workgroup's static + dynamic
+// LDS stays within 160 KiB / 8 = 20480 B (mw_sweep_translation_launch).
 struct SweepLds { unsigned iv, pos, tab, uni, mv, scr, row, nn, total, scr_bytes; };
-__host__ __device__ inline SweepLds sweep_lds(int L, int nw, int ivcap, int N, int nbins, bool ldspos, bool ldslist, int rstride, bool withvol)
+__host__ __device__ inline SweepLds sweep_lds(int L, int nw, int ivcap, int N, int nbins, bool ldspos, bool ldslist, int rstride, bool withvol,
+                                              bool samplerun)
 {
     SweepLds o;
     unsigned p = 0;
     o.iv = p;  p += (unsigned)L * ivcap * 24u;                         // image vectors [L][ivcap][3]
     o.pos = p; p += ldspos ? (unsigned)L * N * 24u : 0u;               // positions     [L][N][3]     (small systems)
-    o.tab = p; p += L == 2 ? 5u * nbins * 8u : 0u;                     // weight, mu_bin, binwidth, histogram, unbiased_hist
+    o.tab = p; p += L == 2 ? (samplerun ? 5u : 4u) * nbins * 8u : 0u;  // weight, mu_bin, binwidth, histogram; unbiased_hist in a sample run only
     o.uni = p; p += kUB * 8u * 8u;                                     // uniforms of a batch of moves [kUB][8]
-    o.mv = p;  p += kUB * 32u;                                         // their molecule + displacement [kUB]{x, y, z, imol}
+    o.mv = withvol ? p : o.uni;                                        // their molecule + displacement {x, y, z, imol}: [kUB][4] of their own when
+    p += withvol ? kUB * 32u : 0u;                                     // volume moves read u0..u3 again; else written over u0..u3 of the move
     p = (p + 15u) & ~15u;
     o.scr_bytes = withvol ? kSweepScratchVol : kSweepScratch;          // per wavefront: WaveScratch / the full-box energy's queue
     o.scr = p; p += (unsigned)nw * o.scr_bytes;
@@ -483,14 +487,15 @@ void k_sweep(double* pos, double* hmat, double* ivect,
     const int wlk = walker0 + blockIdx.x;
     const int box0 = wlk * L;
     const int nbins = sp.nbins;
-    const SweepLds lay = sweep_lds(L, NW, ivcap, N, nbins, LDSPOS, LDSLIST, rstride, WITHVOL);
+    const SweepLds lay = sweep_lds(L, NW, ivcap, N, nbins, LDSPOS, LDSLIST, rstride, WITHVOL, sp.samplerun != 0);
     double* siv = reinterpret_cast<double*>(smem_raw + lay.iv);
     double* spos = reinterpret_cast<double*>(smem_raw + lay.pos);
     double* sweight = reinterpret_cast<double*>(smem_raw + lay.tab);
     double* smub = sweight + nbins;
     double* sbw = smub + nbins;
     double* shist = sbw + nbins;
-    double* suhist = shist + nbins;
+    double* suhist = shist + nbins;                       // (there in a sample run only)
+    constexpr int MVS = WITHVOL ? 4 : 8;                  // doubles between two moves' {x, y, z, imol} (sweep_lds)
     double* suni = reinterpret_cast<double*>(smem_raw + lay.uni);
     double* smv = reinterpret_cast<double*>(smem_raw + lay.mv);
     WaveScratch* ws = reinterpret_cast<WaveScratch*>(smem_raw + lay.scr + (unsigned)wv * lay.scr_bytes);
@@ -521,7 +526,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             smub[t] = mu_bin_g[t];
             sbw[t] = binwidth_g[t];
             shist[t] = whist[(size_t)wlk * nbins + t];
-            suhist[t] = wuhist[(size_t)wlk * nbins + t];
+            if (sp.samplerun) suhist[t] = wuhist[(size_t)wlk * nbins + t];
         }
     }
     if (tid < L) {
@@ -810,8 +815,8 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 const double norm = 1.0 / sqrt(x * x + y * y + z * z);                    // :1029
                 x *= norm; y *= norm; z *= norm;
                 const double r = u[4] * 2.0 - 1.0;                                        // :1035
-                smv[tid * 4] = x * max_trans * r; smv[tid * 4 + 1] = y * max_trans * r; smv[tid * 4 + 2] = z * max_trans * r;
-                smv[tid * 4 + 3] = __longlong_as_double((long long)im);
+                smv[tid * MVS] = x * max_trans * r; smv[tid * MVS + 1] = y * max_trans * r; smv[tid * MVS + 2] = z * max_trans * r;
+                smv[tid * MVS + 3] = __longlong_as_double((long long)im);
             }
             wg_sync<NW>();
         }
@@ -928,7 +933,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         // ---- translations: slot s of the round is move mv + s, this wavefront's lattice of it ---------------------------
         const bool mine = slot < ntr;
         const int l = lat;
-        const double* MV = smv + (ub + (mine ? slot : 0)) * 4;
+        const double* MV = smv + (ub + (mine ? slot : 0)) * MVS;
         const double x = MV[0], y = MV[1], z = MV[2];
         const int imol = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(MV[3]));
         const int i = imol - 1;
@@ -970,7 +975,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             if constexpr (SPEC > 1) {
 #pragma unroll
                 for (int o = 0; o < SPEC - 1; ++o) {
-                    const int io = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(smv[(ub + o) * 4 + 3])) - 1;
+                    const int io = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(smv[(ub + o) * MVS + 3])) - 1;
                     oth[o] = o < slot ? io : -1;
                     if (o < slot && io == i) cm |= 1u << o;
                 }
@@ -998,7 +1003,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                     const unsigned dep = scm[s * NLAT] | (L == 2 ? scm[s * NLAT + (L - 1)] : 0u);
                     if ((dep & accmask) != 0u || C.ls != ls) break;     // that evaluation no longer stands: the next round starts with it
                 }
-                const int im = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(smv[(ub + s) * 4 + 3]));
+                const int im = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(smv[(ub + s) * MVS + 3]));
                 const bool ok = decide_trans(s, U0 + 8 * s, im, (unsigned long long)(mv + s));
                 if (ok) accmask |= 1u << s;
                 ++nvalid;

@@ -86,7 +86,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
     last_cycle = start_cycle + cycles
     em.setup_boxes()                                   # cells + positions of every box in a handful of transfers
     try:
-        em.build_neighbours_batch(1, 2 * walkers)
+        list_rows = em.build_neighbours_batch(1, 2 * walkers)          # (shortest, longest) row of any box
         em.model_energy_batch(1, 2 * walkers)
         grid = MuGrid(nbins, -mu_range, mu_range)
         farm = WalkerFarm(em, 2, temperature, mc_max_trans_ang, grid=grid, weight=weight, pressure_au=pressure_atm / 2.90363081e8)
@@ -203,7 +203,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             if first % list_update_int == 0:                       # mc_moves.F90:217-222
                 if npt:
                     farm.sync_cells()                              # device-side volume moves changed the cells
-                em.build_neighbours_batch(1, 2 * walkers)      # checked: fails loudly on list overflow
+                list_rows = em.build_neighbours_batch(1, 2 * walkers)      # checked: fails loudly on list overflow
             # Cycles between two host actions go out as ONE launch (the move counter simply runs on): a launch
             # stages a walker's positions and list rows in LDS, which is amortised over n moves per cycle only.
             # (In 1/t mode the increment changes every cycle, so cycles stay single.)
@@ -283,7 +283,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                    wl_factor=(joined["wl_factor"] if dd else float(farm.factors(1, 1)[0][0]) if wl_swetnam else sched.wl_factor),
                    wl_invt_active=sched.invt_active, flatness_events=events, delta_g=delta_g,
                    ref_enthalpy=farm.ref_enthalpy,
-                   max_trans_bohr=step_t[:32].tolist(), dv_max_bohr=step_v[:32].tolist())
+                   max_trans_bohr=step_t[:32].tolist(), dv_max_bohr=step_v[:32].tolist(),
+                   list_rows_last_rebuild=list(list_rows))
         out["tables"] = synced
         out["restart_factors"] = None if restart_factors is None else [np.asarray(a).tolist() for a in restart_factors]
         out["joined"] = joined

@@ -50,3 +50,26 @@ def test_sweep_kernels_keep_their_register_budget(tmp_path):
         assert get("vgpr_spill_count") == 0 and get("private_segment_fixed_size") == 0, name
         assert get("vgpr_count") <= (168 if withvol else 128), (name, get("vgpr_count"))
     assert seen == 20          # lattices x residency x with / without volume moves, + look-ahead 2 / 4 for global-memory walkers
+
+
+@pytest.mark.skipif(not os.path.exists(READELF), reason="llvm-readelf not in this image")
+def test_eight_small_walkers_share_a_compute_unit(tmp_path):
+    """The reference's own 48-molecule Ic/Ih pair (examples/ice1_gen_weights: nbins = 101), translations only: a walker's
+    static + dynamic LDS must stay within 160 KiB / 8 for the row lengths a replica farm reaches (longest row of 16 384 boxes
+    after 100 cycles at 200 K: 26) -- at 20.6 KiB a compute unit took seven walkers instead of eight and the farm lost 9 %
+    (profiles/r03e_*)."""
+    from mc_water_ls_mw_amd import build as mwbuild
+    from mc_water_ls_mw_amd.energy import load_library
+    mwbuild.build()
+    L = load_library()
+    notes = subprocess.run([READELF, "--notes", _gfx950_code_object(tmp_path)], capture_output=True, text=True, check=True).stdout
+    static = None
+    for blk in notes.split("- .agpr_count")[1:]:
+        if re.search(r"\.name:\s+_ZN2mw7k_sweepILi2ELi1ELb1ELb1ELb0EE", blk):
+            static = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk).group(1))
+    assert static is not None
+    for stride in (22, 26, 30):
+        dyn = L.mw_sweep_lds_bytes(2, 48, 101, stride, 0, 0)
+        assert 0 < dyn and static + dyn <= 20480, (stride, static, dyn)
+    assert static + L.mw_sweep_lds_bytes(2, 48, 101, 26, 0, 1) <= 20480          # a sample run carries the unbiased histogram too
+    assert L.mw_sweep_lds_bytes(2, 48, 101, 40, 0, 0) == -1 and L.mw_sweep_lds_bytes(2, 100, 101, 20, 0, 0) == -1

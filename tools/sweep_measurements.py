@@ -37,16 +37,17 @@ def farm_for(cells, nlat, walkers, sigma, temperature, mu_range=8000.0):
 def run(name, cells, nlat, walkers, nmoves, out, wl=False, npt=False, sigma=0.1, mu_range=8000.0):
     em, farm = farm_for(cells, nlat, walkers, sigma, 200.0, mu_range)
     if wl:            # what the replica farm runs per move: Wang-Landau update + a lattice-switch attempt (farm.py set_options)
-        farm.options(record=True, samplerun=False, always_switch=True, npt=npt, wl_factor=0.05)
+        farm.options(record=True, samplerun=False, always_switch=True, npt=npt, wl_factor=float(os.environ.get("MW_SWEEP_WLF", "0.05")))
     if npt:           # io.f90:171-172: volume moves 1/N against translations 0.5
         farm.moves(trans_prob=0.5, vol_prob=1.0 / len(cells[0][1]), dv_max_ang=0.924)
-    farm.sweep_launch(20, seed=1, move0=0)
+    pre = int(os.environ.get("MW_SWEEP_PRE", "20"))         # moves before the timed launch (a long run-in shows what the
+    farm.sweep_launch(pre, seed=1, move0=0)                 # rate does once the walkers have left their starting configurations)
     em.sync()
     em.timer_start(0)
-    farm.sweep_launch(nmoves, seed=1, move0=20)
+    farm.sweep_launch(nmoves, seed=1, move0=pre)
     em.timer_stop(0)
     ms = em.timer_ms(0)
-    acc = np.mean([farm.state(w)["accepted"] for w in range(1, min(walkers, 64) + 1)]) / (nmoves + 20)
+    acc = np.mean([farm.state(w)["accepted"] for w in range(1, min(walkers, 64) + 1)]) / (nmoves + pre)
     # drift check of walker 1 against a fresh full-box energy (the reference's own consistency test)
     st = farm.state(1)
     fresh = em.model_energy_batch(1, nlat)
