@@ -260,8 +260,10 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
 /* Dynamic LDS (bytes) of one walker's workgroup when its positions and list rows live in LDS (nwater <= 64), for list
  * rows of `row_stride` entries -- host arithmetic only, no device needed.  Eight walkers share a compute unit while this
  * plus the kernel's static LDS stays within 20480 bytes; the launch picks row_stride = the longest row of any box,
- * rounded up to even.  Returns -1 for arguments no launch would use. */
-int mw_sweep_lds_bytes(int nlat, int nwater, int nbins, int row_stride, int volume_moves, int samplerun);
+ * rounded up to even.  image_capacity: image vectors per box the engine has room for (0: 32 as after mw_init, or 48 with
+ * volume moves -- mw_sweep_moves keeps room for one more shell of images than a 27-image cell has).  Returns -1 for
+ * arguments no launch would use. */
+int mw_sweep_lds_bytes(int nlat, int nwater, int nbins, int row_stride, int volume_moves, int samplerun, int image_capacity);
 
 /* HIP-event timers on the engine's stream: slot in 0..4095. */
 int mw_timer_start(int slot);

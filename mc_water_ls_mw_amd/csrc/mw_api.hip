@@ -304,9 +304,8 @@ mw::GridDesc make_grid(const double h[9], const int imv[3], int max_cells)
 
 int grow_ivcap(int need)
 {
-    int cap = g.ivcap;
-    while (cap < need) cap *= 2;
-    if (cap > MW_MAX_IVECT) cap = MW_MAX_IVECT;
+    int cap = std::max(g.ivcap, (need + 3) & ~3);       // (as much as asked for: the Monte Carlo driver keeps every box's table in LDS,
+    if (cap > MW_MAX_IVECT) cap = MW_MAX_IVECT;         //  where a doubled capacity cost the 48-molecule walkers their eighth place per CU)
     std::vector<double> nh((size_t)g.nbox * cap * 3, 0.0);
     for (int b = 0; b < g.nbox; ++b)
         std::memcpy(&nh[(size_t)b * cap * 3], &g.h_ivect[(size_t)b * g.ivcap * 3], sizeof(double) * 3 * g.ivcap);
@@ -1915,11 +1914,14 @@ int mw_sweep_get_switches(int walker, long long* switches)
     return 0;
 }
 
-int mw_sweep_lds_bytes(int nlat, int nwater, int nbins, int row_stride, int volume_moves, int samplerun)
+int mw_sweep_lds_bytes(int nlat, int nwater, int nbins, int row_stride, int volume_moves, int samplerun, int image_capacity)
 {
-    if (nlat < 1 || nlat > 2 || nwater < 1 || nwater > 64 || nbins < 0 || row_stride < 2 || row_stride > 32) return -1;
-    return (int)mw::sweep_lds(nlat, nlat, 32 /* image vectors per box the engine starts with (mw_init) */, nwater, nbins, true, true,
-                              row_stride, volume_moves != 0, samplerun != 0).total;
+    if (nlat < 1 || nlat > 2 || nwater < 1 || nwater > 64 || nbins < 0 || row_stride < 2 || row_stride > 32 ||
+        image_capacity < 0 || image_capacity > MW_MAX_IVECT) return -1;
+    // image vectors per box: what the engine starts with (mw_init); with volume moves, room for one more shell of images
+    // along one axis (mw_sweep_moves) -- 45 -> 48 for the 27-image cells of the reference's examples
+    const int ivcap = image_capacity > 0 ? image_capacity : (volume_moves ? 48 : 32);
+    return (int)mw::sweep_lds(nlat, nlat, ivcap, nwater, nbins, true, true, row_stride, volume_moves != 0, samplerun != 0).total;
 }
 
 int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigned long long seed, unsigned long long move0, int want_log)

@@ -61,8 +61,9 @@ __device__ __forceinline__ uint32_t list_load(ListRsrc rs, uint32_t column_bytes
     return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)column_bytes, s * N * (int)sizeof(uint32_t), 0);
 }
 
-// `queue` points at this thread's column of an LDS array [kQCap + 1][BLOCK] (entry q at queue[q*BLOCK]:
-// consecutive threads, consecutive banks; row kQCap takes what does not fit).  `col` is the byte offset of the
+// `queue` points at this thread's column of an LDS array [QCAP + 1][BLOCK] (entry q at queue[q*BLOCK]:
+// consecutive threads, consecutive banks; row QCAP takes what does not fit -- those entries are found again by a rescan of
+// the column and accumulated after the queued ones, in list order: the sum is the same whatever QCAP is).  `col` is the byte offset of the
 // thread's list column (kNoColumn: none), `mol` the molecule it belongs to, `n` its row length, `nmax`
 // (wave-uniform) the longest row among the wavefront's columns and `c0min` (wave-uniform) the number of
 // leading slots that hold a central-image entry in EVERY column of the wavefront (columns list their central
@@ -72,7 +73,7 @@ __device__ __forceinline__ uint32_t list_load(ListRsrc rs, uint32_t column_bytes
 // in flight, so the HBM latency of the list stream hides behind the LDS gathers and distance tests.
 // LEAN = true (the Monte Carlo driver's volume moves, where this routine is a guest in a kernel sized for something else):
 // no chunk-ahead list prefetch and no double-buffered gathers -- twenty vector registers fewer, `cur` / `col_next` unused.
-template <int BLOCK, bool BATCH4, bool LEAN = false, typename PosFn, typename IvFn>
+template <int BLOCK, bool BATCH4, bool LEAN = false, int QCAP = kQCap, typename PosFn, typename IvFn>
 __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32_t col_next, int mol, int n, int nmax, int c0min,
                                                int N, int S, uint32_t* __restrict__ queue, PosFn getpos, IvFn getiv,
                                                uint32_t (&cur)[8])
@@ -123,7 +124,7 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
                 for (int u = 0; u < 4; ++u) {
                     const double r2 = d[u][0] * d[u][0] + d[u][1] * d[u][1] + d[u][2] * d[u][2];
                     if (sb + u < n && r2 < kRcSq) {                                           // :454
-                        queue[(cnt < kQCap ? cnt : kQCap) * BLOCK] = cur[4 * h + u];
+                        queue[(cnt < QCAP ? cnt : QCAP) * BLOCK] = cur[4 * h + u];
                         ++cnt;
                     }
                 }
@@ -146,7 +147,7 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
                 }
                 const double r2 = dx * dx + dy * dy + dz * dz;
                 if (s0 + u < n && r2 < kRcSq) {                                               // :454
-                    queue[(cnt < kQCap ? cnt : kQCap) * BLOCK] = e;
+                    queue[(cnt < QCAP ? cnt : QCAP) * BLOCK] = e;
                     ++cnt;
                 }
             }
@@ -181,7 +182,7 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
         Sxx = __builtin_fma(hx, dx, Sxx); Syy = __builtin_fma(hy, dy, Syy); Szz = __builtin_fma(hz, dz, Szz);
         Sxy = __builtin_fma(hx, dy, Sxy); Sxz = __builtin_fma(hx, dz, Sxz); Syz = __builtin_fma(hy, dz, Syz);
     };
-    const int nq = cnt < kQCap ? cnt : kQCap;
+    const int nq = cnt < QCAP ? cnt : QCAP;
     if constexpr (LEAN) {
         for (int q = 0; q < nq; ++q) { double v[6]; gather(queue[q * BLOCK], v); accumulate(v); }
     } else if (nq > 0) {
@@ -195,13 +196,13 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
             for (int c = 0; c < 6; ++c) va[c] = vb[c];
         }
     }
-    if (cnt > kQCap) {          // rare (dense configurations): rescan the column for the in-range entries the queue had no room for
+    if (cnt > QCAP) {           // rare (dense configurations): rescan the column for the in-range entries the queue had no room for
         int seen = 0;
         for (int s = 0; s < n; ++s) {
             double v[6];
             gather(list_load(rs, col, s, N, S), v);
             const double dx = (v[0] + v[3]) - xi, dy = (v[1] + v[4]) - yi, dz = (v[2] + v[5]) - zi;
-            if (dx * dx + dy * dy + dz * dz < kRcSq) { if (seen >= kQCap) accumulate(v); ++seen; }
+            if (dx * dx + dy * dy + dz * dz < kRcSq) { if (seen >= QCAP) accumulate(v); ++seen; }
         }
     }
     const double F2 = Sxx * Sxx + Syy * Syy + Szz * Szz + 2.0 * (Sxy * Sxy + Sxz * Sxz + Syz * Syz);

@@ -311,7 +311,8 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
 
     // ---- compact the in-range neighbours (of either position) into the wave's scratch ------------
     const bool inu = (U >> sl) & 1u;
-    const int rank = __popc(U & ((1u << sl) - 1u));
+    // (the in-range slots below this lane's: v_mbcnt counts them without a per-lane mask held in a register from move to move)
+    const int rank = half ? (int)__builtin_amdgcn_mbcnt_hi(U, 0u) : (int)__builtin_amdgcn_mbcnt_lo(U, 0u);
     // The rows of the in-range j are laid end to end (slots 0..T-1).  An inclusive prefix sum over the 32
     // slot lanes of each half gives every j its first slot, and in its upper 16 bits the list slots each
     // evaluation visits (half 0: old position, half 1: trial position).
@@ -345,7 +346,12 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     const int flg = (int)((mo_ >> sl) & 1u) | (int)(((mn_ >> sl) & 1u) << 1);
     const int wv = __builtin_amdgcn_ds_permute(dstl << 2, kimg | (kinv << 10) | (flg << 20));
     // row-end marks: chunk c of the scan reads mask cm[c]; a slot's owner is the number of marks before it
-    if (lane < kCap) ws->cm[lane] = 0ull;
+    {   // (the address is worked out here, from a lane number the compiler cannot hoist: as a loop invariant of the callers'
+        //  move loops it was one more register held from move to move -- the one that tipped a build of the driver into a spill)
+        int lz = lane;
+        asm volatile("" : "+v"(lz));
+        if (lz < kCap) ws->cm[lz] = 0ull;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (inu && half == 0 && rank > 0 && start > 0)      // (rows are never empty: j lists i back)
         __hip_atomic_fetch_or(&ws->cm[(start - 1) >> 6], 1ull << ((start - 1) & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);

@@ -120,6 +120,7 @@ __device__ __forceinline__ void dev_recipmatrix(const double* __restrict__ h, do
     for (int i = 0; i < 9; ++i) rc[i] *= f;
 }
 
+constexpr int kSweepQCap = 9;                             // in-range queue of a volume move's full-box energy: sized to fit the scratch record
 // -------------------------------------------------------------------------------------
 // Volume move of one walker by its wavefront: mc_volume (mc_moves.F90:1216-1534; ref_ljr,
 // which only chain synchronisation reads, is not carried).  Rare (probability ~1/N per move), so it is an
@@ -146,7 +147,7 @@ struct VolCtx {
     const int* order_g;       // molecule of each column
     const int* nns_g;         // row length of each column
     const int* cmax_g;        // longest row per group of 64 columns
-    uint32_t* queue;          // this lane's column of an LDS queue [kQCap][64]
+    uint32_t* queue;          // this lane's column of an LDS queue [kSweepQCap + 1][64]
     int N, S, ivcap, L;
 };
 
@@ -238,7 +239,7 @@ __device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, 
         int n_next = 0, mol_next = 0;
         if (tn < c.N) { col_next = (uint32_t)tn * 4u; n_next = NNS[tn]; mol_next = ORD[tn]; }
         const int cm = __builtin_amdgcn_readfirstlane(CM[base >> 6]);
-        AtomSum a = atom_energy<64, false, true>(rs, col, col_next, mol, act ? (n_cur & 0xff) : 0, cm & 0xff, cm >> 8, c.N, c.S, c.queue, getpos, getiv, cur);
+        AtomSum a = atom_energy<64, false, true, kSweepQCap>(rs, col, col_next, mol, act ? (n_cur & 0xff) : 0, cm & 0xff, cm >> 8, c.N, c.S, c.queue, getpos, getiv, cur);
         if (act) esum += a.e;
         n_cur = n_next; mol = mol_next; col = col_next;
     }
@@ -271,9 +272,11 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-constexpr int kUB = 16;                                   // moves per batch of uniforms (Philox calls are lanes of one pass)
+constexpr int kUB = 8;                                    // moves per batch of uniforms (Philox calls are lanes of one pass; 16 cost 512 B
+                                                          // of LDS more, which an NPT walker of the reference's examples does not have)
 constexpr unsigned kSweepScratch = (unsigned)((sizeof(WaveScratch) + 15) & ~(size_t)15);
-constexpr unsigned kSweepScratchVol = (unsigned)(((kQCap + 1) * 64 * sizeof(uint32_t)) > kSweepScratch ? ((kQCap + 1) * 64 * sizeof(uint32_t)) : kSweepScratch);
+constexpr unsigned kSweepScratchVol = (unsigned)(((kSweepQCap + 1) * 64 * sizeof(uint32_t)) > kSweepScratch ? ((kSweepQCap + 1) * 64 * sizeof(uint32_t)) : kSweepScratch);
+static_assert(kSweepScratchVol == kSweepScratch, "the builds with volume moves take no more LDS per wavefront than the others");
 
 // Dynamic LDS of a walker's workgroup (byte offsets), the same arithmetic on the host (launch size) and on the device.
 // Every byte counts for the reference's own 48-molecule cells: eight walkers share a CU when a workgroup's static + dynamic
@@ -288,8 +291,8 @@ __host__ __device__ inline SweepLds sweep_lds(int L, int nw, int ivcap, int N, i
     o.pos = p; p += ldspos ? (unsigned)L * N * 24u : 0u;               // positions     [L][N][3]     (small systems)
     o.tab = p; p += L == 2 ? (samplerun ? 5u : 4u) * nbins * 8u : 0u;  // weight, mu_bin, binwidth, histogram; unbiased_hist in a sample run only
     o.uni = p; p += kUB * 8u * 8u;                                     // uniforms of a batch of moves [kUB][8]
-    o.mv = withvol ? p : o.uni;                                        // their molecule + displacement {x, y, z, imol}: [kUB][4] of their own when
-    p += withvol ? kUB * 32u : 0u;                                     // volume moves read u0..u3 again; else written over u0..u3 of the move
+    o.mv = o.uni;                                                      // a translation's molecule + displacement {x, y, z, imol}: written over its
+                                                                       // spent uniforms u0..u3 (a volume move keeps its own: it reads them again)
     p = (p + 15u) & ~15u;
     o.scr_bytes = withvol ? kSweepScratchVol : kSweepScratch;          // per wavefront: WaveScratch / the full-box energy's queue
     o.scr = p; p += (unsigned)nw * o.scr_bytes;
@@ -455,8 +458,10 @@ __device__ __forceinline__ int dev_minu_branch(const WalkerCtl& sp, int ls, doub
 // sequential one, move for move and bit for bit -- and a round costs one barrier more than a move did.
 template <int NLAT, int SPEC, bool LDSPOS, bool LDSLIST, bool WITHVOL>
 // Four wavefronts per SIMD are the design point (128 VGPRs; the translation-only build needs 127-136 left to itself, and
-// which side of 128 it lands on depends on what else is compiled with it); the build that carries mc_volume gets three.
-__global__ __launch_bounds__(64 * NLAT * SPEC) __attribute__((amdgpu_waves_per_eu(WITHVOL ? 3 : 4, WITHVOL ? 3 : 4)))
+// which side of 128 it lands on depends on what else is compiled with it).  The builds that carry mc_volume keep to it too
+// -- the reference's own examples are NPT -- since the volume move's addresses are worked out inside its branch (below) and
+// its old volumes wait in LDS; only two lattices + look-ahead + volume moves (few walkers by construction) get three.
+__global__ __launch_bounds__(64 * NLAT * SPEC) __attribute__((amdgpu_waves_per_eu((WITHVOL && NLAT == 2 && SPEC > 1) ? 3 : 4, (WITHVOL && NLAT == 2 && SPEC > 1) ? 3 : 4)))
 void k_sweep(double* pos, double* hmat, double* ivect,
              int* nivect, const uint32_t* __restrict__ listm, const uint32_t* __restrict__ list,
              const int* __restrict__ nn, const int* __restrict__ order, const int* __restrict__ nns,
@@ -476,6 +481,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
     __shared__ double shmat[2][9], srecip[2][9], svol[2];      // the walker's cells: volume moves change them in place
     __shared__ int sniv[2];
     __shared__ double sbk[2][27];     // a volume move's old hmatrix / recip and new recip per lattice
+    __shared__ double svold[2];       // ... and the old volumes (read by the decision after the full-box energies)
     __shared__ double sx[2 * NW < 4 ? 4 : 2 * NW];   // what every wavefront hands to the deciding one: its {e_old, e_new} (volume moves: full-box energies)
     __shared__ unsigned scm[NW];      // ... and which earlier moves of the round its evaluation depends on
     __shared__ int sdec[4 + SPEC];    // the decisions: moves decided this round, active lattice, (volume moves: accepted, bad, bad per lattice), accepted per slot
@@ -495,7 +501,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
     double* sbw = smub + nbins;
     double* shist = sbw + nbins;
     double* suhist = shist + nbins;                       // (there in a sample run only)
-    constexpr int MVS = WITHVOL ? 4 : 8;                  // doubles between two moves' {x, y, z, imol} (sweep_lds)
+    constexpr int MVS = 8;                                // doubles between two moves' {x, y, z, imol} (sweep_lds)
     double* suni = reinterpret_cast<double*>(smem_raw + lay.uni);
     double* smv = reinterpret_cast<double*>(smem_raw + lay.mv);
     WaveScratch* ws = reinterpret_cast<WaveScratch*>(smem_raw + lay.scr + (unsigned)wv * lay.scr_bytes);
@@ -585,13 +591,6 @@ void k_sweep(double* pos, double* hmat, double* ivect,
     }
     __syncthreads();
 
-    VolCtx vc;
-    vc.pos_g = pos + (size_t)box0 * N * 3; vc.spos = LDSPOS ? spos : nullptr;
-    vc.shmat = &shmat[0][0]; vc.srecip = &srecip[0][0]; vc.svol = svol; vc.sbk = &sbk[0][0]; vc.siv = siv; vc.sniv = sniv;
-    vc.hmat_g = hmat + (size_t)box0 * 9; vc.vol_g = volume + box0; vc.ivect_g = ivect + (size_t)box0 * ivcap * 3;
-    vc.nivect_g = nivect + box0; vc.list_g = list + (size_t)box0 * S * N;
-    vc.order_g = order + (size_t)box0 * N; vc.nns_g = nns + (size_t)box0 * N; vc.cmax_g = cmax + (size_t)box0 * ((N + 63) >> 6);
-    vc.queue = reinterpret_cast<uint32_t*>(ws) + lane; vc.N = N; vc.S = S; vc.ivcap = ivcap; vc.L = L;
 
     // mc_lattice_switch's exponent for a walker in lattice lsx with energies E0, E1 (:1557-1572), less new_eta - old_eta
     auto switch_dk = [&](double E0, double E1, int lsx) {
@@ -625,7 +624,9 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                         const double sumh = C.sumh + 1.0;
                         double a2 = 0.0;
                         const double span = C.mu_max - C.mu_min - 1.0;
-                        for (int b = lane; b < nbins; b += 64) {
+                        int lane_s = lane;                                        // (its table addresses are not worth a register held
+                        asm volatile("" : "+v"(lane_s));                          //  through every move of every build)
+                        for (int b = lane_s; b < nbins; b += 64) {
                             const double hb = shist[b] + (b == k - 1 ? visit : 0.0);          // this move's visit is already counted (:1621)
                             const double dev = hb * sbw[b] / sumh - sbw[b] / span;
                             a2 += dev * dev;
@@ -806,7 +807,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 suni[(c >> 2) * 8 + 2 * (c & 3) + 1] = u53(ctr[2], ctr[3]);
             }
             wg_sync<NW>();
-            if (tid < kUB) {
+            if (tid < kUB && !(WITHVOL && !(suni[tid * 8 + 7] < C.transP))) {     // (translations: the move-type test of the rounds below)
                 const double* u = suni + tid * 8;
                 const double max_trans = C.max_trans;
                 int im = (int)(u[0] * (double)N) + 1;                                     // :1001-1002
@@ -830,6 +831,18 @@ void k_sweep(double* pos, double* hmat, double* ivect,
 
         if (ntr == 0) {                                                           // mc_moves.F90:232-235: a volume move
             if constexpr (WITHVOL) {
+                // Everything the volume move addresses is worked out HERE, from a lane number and a box number the compiler
+                // cannot see through: hoisted out of the move loop, these loop-invariant addresses are what pushed the build
+                // past 128 vector registers (three wavefronts per SIMD instead of four, for a branch taken once in N moves).
+                int lv = lane, bv = box0;
+                asm volatile("" : "+v"(lv), "+s"(bv));
+                VolCtx vc;
+                vc.pos_g = pos + (size_t)bv * N * 3; vc.spos = LDSPOS ? spos : nullptr;
+                vc.shmat = &shmat[0][0]; vc.srecip = &srecip[0][0]; vc.svol = svol; vc.sbk = &sbk[0][0]; vc.siv = siv; vc.sniv = sniv;
+                vc.hmat_g = hmat + (size_t)bv * 9; vc.vol_g = volume + bv; vc.ivect_g = ivect + (size_t)bv * ivcap * 3;
+                vc.nivect_g = nivect + bv; vc.list_g = list + (size_t)bv * S * N;
+                vc.order_g = order + (size_t)bv * N; vc.nns_g = nns + (size_t)bv * N; vc.cmax_g = cmax + (size_t)bv * ((N + 63) >> 6);
+                vc.queue = reinterpret_cast<uint32_t*>(ws) + lv; vc.N = N; vc.S = S; vc.ivcap = ivcap; vc.L = L;
                 const double* U = U0;
                 double diffkT = 0.0;
                 bool do_switch = false;
@@ -845,8 +858,9 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                     }
                     do_switch = L == 2 && C.always_switch && !(C.dd && C.cyc < C.eq_cycles);
                 }
-                const double Vo0 = svol[0], Vo1 = L == 2 ? svol[1] : 0.0;
+                if (tid < L) svold[tid] = svol[tid];               // (volume_move_wg's first barrier orders this against the decision)
                 auto decide = [&](double e0n, double e1n, int anybad) -> int {
+                    const double Vo0 = svold[0], Vo1 = L == 2 ? svold[1] : 0.0;
                     // wavefront 0: mc_volume's acceptance (:1361-1410) and, on rejection, the restored order parameter (:1514-1530)
                     const double bk0 = C.men0, bk1 = C.men1;
                     const int ls0 = C.ls;
@@ -891,7 +905,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                     wave_sync();
                     return okv;
                 };
-                const int rv = volume_move_wg<NLAT, NW>(vc, U, C.dv_max, wv, lane, sx, sdec, decide);
+                const int rv = volume_move_wg<NLAT, NW>(vc, U, C.dv_max, wv, lv, sx, sdec, decide);
                 if (wv == 0) {
                     int sw = 0;
                     double l12 = 0.0, l21 = 0.0;
