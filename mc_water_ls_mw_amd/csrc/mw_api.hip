@@ -19,6 +19,7 @@
 #include <shared_mutex>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include <unistd.h>
 
@@ -89,6 +90,7 @@ struct Ctx {
     int cstride = 0;
     std::vector<mw::GridDesc> h_grid;
     std::vector<int> h_usegrid;
+    bool grid_on_device = false;   // some box of this context has (had) a cell grid: descriptors travel with mw_sweep_sync_cells
     bool force_brute = false;
     double* d_partial = nullptr;
     unsigned long long* d_cpartial = nullptr;
@@ -787,6 +789,7 @@ static int set_cells_impl(int first_ils, int count, const double* h, int* nivect
         g.h_grid[b0 + k] = make_grid(m, &imvs[3 * k], g.cstride);
         g.h_usegrid[b0 + k] = (!g.force_brute && g.h_grid[b0 + k].nc[0] > 0) ? 1 : 0;
         if (!g.h_usegrid[b0 + k]) g.h_grid[b0 + k].nc[0] = 0;
+        else g.grid_on_device = true;
         if (nivect_out) nivect_out[k] = ns[k];
     }
     if (count == 1) {
@@ -1761,25 +1764,63 @@ int mw_sweep_sync_cells(int first_ils, int count, double* h_out)
     HIPCHK(hipStreamSynchronize(g.stream));
     for (int w = 0; w < g.nbox; ++w)
         if (flags[(size_t)w] & 1) return fail("mw_sweep: a volume move of walker %d shrank a cell below what %d image vectors cover", w + 1, g.ivcap);
-    // host mirrors for every box, then four bulk uploads (the device already holds these image vectors: same arithmetic)
-    for (int b = 0; b < count; ++b) {
-        const int box = first_ils - 1 + b;
+    // host mirrors for every box, then four bulk uploads (the device already holds these image vectors: same arithmetic).
+    // A farm calls this before every list rebuild for thousands of boxes: the boxes are shared out among the host's cores
+    // (one thread did 16 384 boxes in 3.5 ms, ten times per hundred cycles -- an eighth of an NPT farm's wall time).
+    std::atomic<int> bad_box{-1}, bad_n{0};
+    auto mirror = [&](int lo, int hi) {
         std::vector<double> iv;
-        int imv[3] = {1, 1, 1};
-        const int n = host_ivects(&h[(size_t)b * 9], iv, imv);
-        if (n < 0 || n > g.ivcap) return fail("mw_sweep_sync_cells: box %d needs %d image vectors (capacity %d)", box + 1, n, g.ivcap);
-        std::memcpy(&g.h_ivect[(size_t)box * g.ivcap * 3], iv.data(), iv.size() * sizeof(double));
-        g.h_nivect[box] = n;
-        g.h_grid[box] = make_grid(&h[(size_t)b * 9], imv, g.cstride);
-        g.h_usegrid[box] = (!g.force_brute && g.h_grid[box].nc[0] > 0) ? 1 : 0;
-        if (!g.h_usegrid[box]) g.h_grid[box].nc[0] = 0;
-        if (h_out) std::memcpy(h_out + (size_t)b * 9, &h[(size_t)b * 9], 9 * sizeof(double));
+        for (int b = lo; b < hi; ++b) {
+            const int box = first_ils - 1 + b;
+            int imv[3] = {1, 1, 1};
+            const int n = host_ivects(&h[(size_t)b * 9], iv, imv);
+            if (n < 0 || n > g.ivcap) { int none = -1; if (bad_box.compare_exchange_strong(none, box)) bad_n = n; return; }
+            std::memcpy(&g.h_ivect[(size_t)box * g.ivcap * 3], iv.data(), iv.size() * sizeof(double));
+            g.h_nivect[box] = n;
+            g.h_grid[box] = make_grid(&h[(size_t)b * 9], imv, g.cstride);
+            g.h_usegrid[box] = (!g.force_brute && g.h_grid[box].nc[0] > 0) ? 1 : 0;
+            if (!g.h_usegrid[box]) g.h_grid[box].nc[0] = 0;
+            if (h_out) std::memcpy(h_out + (size_t)b * 9, &h[(size_t)b * 9], 9 * sizeof(double));
+        }
+    };
+    const int nthr = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, count / 512}));
+    if (nthr == 1) mirror(0, count);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthr; ++t)
+            pool.emplace_back(mirror, (int)((long long)count * t / nthr), (int)((long long)count * (t + 1) / nthr));
+        for (auto& th : pool) th.join();
     }
+    if (bad_box.load() >= 0)
+        return fail("mw_sweep_sync_cells: box %d needs %d image vectors (capacity %d)", bad_box.load() + 1, bad_n.load(), g.ivcap);
+    // What goes back to the device is what only the host works out: which boxes take the cell-grid list builder, and their
+    // grid descriptors.  The image vectors do NOT: the volume moves rebuilt them on the device in the reference's order and
+    // arithmetic (dev_compute_ivects), so the device's tables already equal the mirrors just computed -- 19 MB per call for
+    // 16 384 boxes that used to be uploaded regardless, 3 ms of an idle GPU before every list rebuild of an NPT farm.
+    // MW_SYNC_CELLS_VERIFY=1 reads the device's tables back instead and compares them bit for bit (tests).
     const size_t b0 = (size_t)(first_ils - 1);
-    HIPCHK(hipMemcpyAsync(g.d_ivect + b0 * g.ivcap * 3, &g.h_ivect[b0 * g.ivcap * 3], sizeof(double) * 3 * g.ivcap * count, hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemcpyAsync(g.d_nivect + b0, &g.h_nivect[b0], sizeof(int) * count, hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemcpyAsync(g.d_grid + b0, &g.h_grid[b0], sizeof(mw::GridDesc) * count, hipMemcpyHostToDevice, g.stream));
+    bool any_grid = g.grid_on_device;
+    for (int b = 0; b < count; ++b) any_grid = any_grid || g.h_usegrid[b0 + b] != 0;
+    if (any_grid) {
+        HIPCHK(hipMemcpyAsync(g.d_grid + b0, &g.h_grid[b0], sizeof(mw::GridDesc) * count, hipMemcpyHostToDevice, g.stream));
+        g.grid_on_device = true;
+    }
     HIPCHK(hipMemcpyAsync(g.d_usegrid + b0, &g.h_usegrid[b0], sizeof(int) * count, hipMemcpyHostToDevice, g.stream));
+    static const bool verify = [] { const char* e = std::getenv("MW_SYNC_CELLS_VERIFY"); return e && std::atoi(e) != 0; }();
+    if (verify) {
+        std::vector<double> div((size_t)count * g.ivcap * 3);
+        std::vector<int> dn((size_t)count);
+        HIPCHK(hipMemcpyAsync(div.data(), g.d_ivect + b0 * g.ivcap * 3, div.size() * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipMemcpyAsync(dn.data(), g.d_nivect + b0, dn.size() * sizeof(int), hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        for (int b = 0; b < count; ++b) {
+            const int n = g.h_nivect[b0 + b];
+            if (dn[(size_t)b] != n)
+                return fail("mw_sweep_sync_cells: box %d has %d image vectors on the device, %d by the host's arithmetic", (int)b0 + b + 1, dn[(size_t)b], n);
+            if (std::memcmp(&div[(size_t)b * g.ivcap * 3], &g.h_ivect[(b0 + b) * g.ivcap * 3], sizeof(double) * 3 * n) != 0)
+                return fail("mw_sweep_sync_cells: the device's image vectors of box %d differ from the host's", (int)b0 + b + 1);
+        }
+    }
     HIPCHK(hipStreamSynchronize(g.stream));
     return 0;
 }

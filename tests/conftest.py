@@ -11,6 +11,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# mw_sweep_sync_cells no longer re-uploads the image vectors the device's volume moves built: under test, every call reads the
+# device's tables back and fails unless they equal the host's own compute_ivects bit for bit (read once, at the first call).
+os.environ.setdefault("MW_SYNC_CELLS_VERIFY", "1")
+
 #: parity bar of BASELINE.json's north_star: energies within 1e-10 relative of the Fortran reference
 RTOL = 1e-10
 #: the reference author's own absolute tolerance on a move's energy change (mc_moves.F90:1099), Hartree
