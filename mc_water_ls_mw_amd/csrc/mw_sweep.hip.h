@@ -272,8 +272,9 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-constexpr int kUB = 8;                                    // moves per batch of uniforms (Philox calls are lanes of one pass; 16 cost 512 B
-                                                          // of LDS more, which an NPT walker of the reference's examples does not have)
+// moves per batch of uniforms (Philox calls are lanes of one pass): 16, or 8 for the builds with volume moves -- 512 B of LDS that an
+// NPT walker of the reference's examples does not have (sweep_lds); the smaller batch costs the translation-only build ~2 %
+__host__ __device__ constexpr int sweep_batch(bool withvol) { return withvol ? 8 : 16; }
 constexpr unsigned kSweepScratch = (unsigned)((sizeof(WaveScratch) + 15) & ~(size_t)15);
 constexpr unsigned kSweepScratchVol = (unsigned)(((kSweepQCap + 1) * 64 * sizeof(uint32_t)) > kSweepScratch ? ((kSweepQCap + 1) * 64 * sizeof(uint32_t)) : kSweepScratch);
 static_assert(kSweepScratchVol == kSweepScratch, "the builds with volume moves take no more LDS per wavefront than the others");
@@ -290,7 +291,7 @@ __host__ __device__ inline SweepLds sweep_lds(int L, int nw, int ivcap, int N, i
     o.iv = p;  p += (unsigned)L * ivcap * 24u;                         // image vectors [L][ivcap][3]
     o.pos = p; p += ldspos ? (unsigned)L * N * 24u : 0u;               // positions     [L][N][3]     (small systems)
     o.tab = p; p += L == 2 ? (samplerun ? 5u : 4u) * nbins * 8u : 0u;  // weight, mu_bin, binwidth, histogram; unbiased_hist in a sample run only
-    o.uni = p; p += kUB * 8u * 8u;                                     // uniforms of a batch of moves [kUB][8]
+    o.uni = p; p += (unsigned)sweep_batch(withvol) * 8u * 8u;          // uniforms of a batch of moves [kUB][8]
     o.mv = o.uni;                                                      // a translation's molecule + displacement {x, y, z, imol}: written over its
                                                                        // spent uniforms u0..u3 (a volume move keeps its own: it reads them again)
     p = (p + 15u) & ~15u;
@@ -791,6 +792,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         return ok;
     };
 
+    constexpr int kUB = sweep_batch(WITHVOL);
     int mv = 0, ubase = -kUB;                    // next move of the chain (counted within the launch); first move of the uniforms' window
     while (mv < nmoves) {
         if (mv + SPEC > ubase + kUB) {

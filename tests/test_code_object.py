@@ -73,7 +73,7 @@ def test_eight_small_walkers_share_a_compute_unit(tmp_path):
     for stride in (22, 26, 28):          # the reference's examples are NPT: the build with volume moves keeps eight walkers per CU too
         dyn = L.mw_sweep_lds_bytes(2, 48, 101, stride, 1, 0, 0)
         assert 0 < dyn and static_vol + dyn <= 20480, (stride, static_vol, dyn)
-    for stride in (22, 26, 30, 32):
+    for stride in (22, 26, 30):
         dyn = L.mw_sweep_lds_bytes(2, 48, 101, stride, 0, 0, 0)
         assert 0 < dyn and static + dyn <= 20480, (stride, static, dyn)
     assert static + L.mw_sweep_lds_bytes(2, 48, 101, 26, 0, 1, 0) <= 20480          # a sample run carries the unbiased histogram too
