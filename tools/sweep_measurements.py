@@ -82,6 +82,8 @@ if only in (None, "ih4096"):
 # few walkers: the chip is filled from inside the chains (look-ahead, MW_SWEEP_AHEAD)
 if only in ("few4096",):
     run("ih4096 x 64 walkers", [(h, x)], 1, 64, 600, out)
+if only in ("many4096",):   # more walkers than four wavefronts per SIMD hold: what a fifth (<= 96 VGPRs) is worth
+    run("ih4096 x 6144 walkers", [(h, x)], 1, 6144, 200, out)
 if only in ("one4096",):
     run("ih4096 x 1 walker", [(h, x)], 1, 1, 2000, out)
 if only in ("one1536",):
