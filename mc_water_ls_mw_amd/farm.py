@@ -59,6 +59,13 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
     if parallel_strategy not in ("mw", "dd"):
         raise ValueError("Unknown parallel_strategy")                      # mc_moves.F90:720
     dd = parallel_strategy == "dd"
+    nwalk_all = walkers * (comms.world_size if comms is not None else 1)
+    if not dd and not regauge and not samplerun and nwalk_all > 64 and rank == 0:
+        import sys
+        print(f"mc_water_ls_mw_amd.farm: {nwalk_all} walkers exchange their weights with the reference's own arithmetic "
+              "(comms_mpi.f90:256-270), whose uniform offset grows by the number of walkers at every synchronisation: the table "
+              "reaches the end of the double range within a few dozen synchronisations (8192 walkers: 1e307 after 80).  "
+              "regauge=True (--regauge) keeps one shared table in the reference's gauge.", file=sys.stderr)
     n = len(x_pair[0])
     em = EnergyModule(n, 2 * walkers, device=device)
     for w in range(walkers):
