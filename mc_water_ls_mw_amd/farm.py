@@ -98,6 +98,11 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         grid = MuGrid(nbins, -mu_range, mu_range)
         farm = WalkerFarm(em, 2, temperature, mc_max_trans_ang, grid=grid, weight=weight, pressure_au=pressure_atm / 2.90363081e8)
         comms = farm.local_comms() if comms is None else comms             # one exchange object throughout
+        if weight is not None and chk is None:
+            # mc_init (mc_moves.F90:738-776): rank 0 reads eta_weights.dat, the others hold zeros, and comms_allreduce_eta hands
+            # everybody the table -- which is thereby also the baseline of the delta scheme.  Here every walker starts with the
+            # table, so the baseline is set directly (left at zero, the first synchronisation of W walkers returned W x the table).
+            comms.set_weights(np.asarray(weight, dtype=np.float64))
         skw = dict(wl_schedule=wl_schedule, wl_flattol=wl_flattol, wl_minhist=wl_minhist, wl_useinvt=wl_useinvt,
                    wl_swetnam=wl_swetnam, samplerun=samplerun, outdir=outdir)
         if dd:                                                             # :659-709: one window per walker
@@ -335,6 +340,9 @@ def main():
     ap.add_argument("--no-thermalise", action="store_true", help="every walker starts from the input configuration itself (as the ranks of the reference do)")
     ap.add_argument("--eq-adjust", action="store_true", help="eq_adjust_mc: tune the step sizes during equilibration")
     ap.add_argument("--monitor", type=int, default=1000, help="monitor_int")
+    ap.add_argument("--samplerun", action="store_true", help="fixed weights, unbiased histogram (examples/ice1_sample); needs --weights")
+    ap.add_argument("--weights", default=None, help="eta_weights.dat: the starting weights (mc_moves.F90:738-770)")
+    ap.add_argument("--delta-g", type=int, default=100000, help="deltaG_int: cycles between free-energy estimates of a sample run")
     ap.add_argument("--regauge", action="store_true",
                     help="exchange step sums the weight increments proper and subtracts the window minimum once "
                          "(default: the reference's arithmetic, comms_mpi.f90:256-270)")
@@ -356,7 +364,16 @@ def main():
     gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
     z1, z2 = np.load(os.path.join(gold, "ic48.npz")), np.load(os.path.join(gold, "ih48.npz"))
     comms = WalkerComms(101, device=torch.device("cuda", local) if (world > 1 and args.backend == "nccl") else None)
+    weight, file_factor = None, None
+    if args.samplerun and args.weights is None:
+        raise SystemExit("--samplerun needs --weights (the reference stops without eta_weights.dat too)")
+    if args.weights is not None:
+        from . import io as mwio
+        file_factor, _, weight = mwio.read_table(args.weights)
+        if len(weight) != 101:
+            raise SystemExit(f"{args.weights}: {len(weight)} bins, this farm runs the examples' 101")
     res = run([z1["h"], z2["h"]], [z1["xyz"], z2["xyz"]], args.walkers, args.cycles, mpi_sync_int=args.sync,
+              samplerun=args.samplerun, weight=weight, file_wl_factor=file_factor, deltaG_int=args.delta_g,
               device=local, comms=comms, rank=rank, npt=args.npt, wl_factor=args.wl_factor, flat_chk_int=args.flat_chk,
               wl_schedule=args.wl_schedule, wl_flattol=args.wl_flattol, wl_minhist=args.wl_minhist,
               wl_useinvt=args.wl_useinvt, outdir=args.outdir, regauge=args.regauge, parallel_strategy=args.strategy,

@@ -70,6 +70,24 @@ def test_leshift_enters_delta_g(c_oracle):
     assert shifted["delta_g"]["kT"] == pytest.approx(expect, rel=1e-9)
 
 
+def test_starting_weights_survive_the_first_synchronisation_of_several_walkers():
+    """mc_init's comms_allreduce_eta makes the table read from eta_weights.dat the baseline of the delta scheme
+    (mc_moves.F90:738-776): with fixed weights (a sample run) every later synchronisation returns that table, however many
+    walkers there are -- not walkers x the table."""
+    from mc_water_ls_mw_amd.sweep import MuGrid
+    grid = MuGrid(101, -400.0, 400.0)
+    weight = 0.05 * np.abs(grid.mu_bin)
+    b = boxes48()
+    from mc_water_ls_mw_amd.farm import run
+    res = run([b[0][0], b[1][0]], [b[0][1], b[1][1]], walkers=4, cycles=6, temperature=200.0, seed=pin.SEED, thermalise=True,
+              list_update_int=10, mpi_sync_int=3, wl_factor=F0, samplerun=True, weight=weight, deltaG_int=10 ** 6, max_mc_cycles=6, eq_mc_cycles=1)
+    synced_w, synced_h, synced_u = res["tables"]
+    assert np.array_equal(synced_w, weight)
+    for w in res["first_walkers"]:
+        assert np.array_equal(w["tables"][0], weight)
+    assert synced_h.sum() > 0 and synced_u.sum() > 0
+
+
 def test_swetnam_run_follows_the_pinned_oracle(so, c_oracle):
     from mc_water_ls_mw_amd.sweep import MuGrid
     grid = MuGrid(101, -400.0, 400.0)
