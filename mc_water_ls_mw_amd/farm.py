@@ -152,7 +152,14 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             farm._s_ref = np.einsum("bnd,bdk->bnk", np.concatenate([c["ref_ljr"] for c in chk]), np.linalg.inv(em.hmatrix))
             farm.set_tables_range(1, weight=np.array([c["weight"] for c in chk]), histogram=np.array([c["histogram"] for c in chk]),
                                   unbiased_hist=np.array([c["unbiased_hist"] for c in chk]) if samplerun else None)
-            comms.set_histogram(chk[0]["histogram"])               # :455-458 (the weights' baseline is NOT re-based there either)
+            comms.set_histogram(chk[0]["histogram"])               # :455-458
+            # The loader does not re-base the weights (:455-458 name the histograms only): the reference's baseline is what
+            # mc_init's all-reduce left (:775), i.e. the eta_weights.dat the interrupted run dumped -- or zero without that
+            # file, and then R ranks come back from their first synchronisation with R x the table.  A farm has no such file
+            # to fall back on: the baseline is the checkpointed table itself (exactly the synchronised table when checkpoints
+            # fall on synchronisation cycles, as they do with the reference's default intervals).
+            if not dd:
+                comms.set_weights(np.asarray(chk[0]["weight"], dtype=np.float64))
             if samplerun:
                 comms.set_uhistogram(chk[0]["unbiased_hist"])
             step_t0 = np.array([c["mc_max_trans"] for c in chk]); step_v0 = np.array([c["mc_dv_max"] for c in chk])

@@ -332,6 +332,25 @@ def test_farm_restarts_from_its_own_checkpoints_and_the_files_are_the_references
         assert np.allclose(a["tables"][0], r["tables"][0], rtol=1e-9, atol=1e-11)
 
 
+def test_restart_continues_through_table_synchronisations(tmp_path):
+    """Three walkers, tables synchronised every 4 cycles, checkpoint at cycle 8 (a synchronisation cycle): the restarted run's
+    next synchronisation must see the checkpointed table as its baseline -- with the baseline left at zero it returned 3 x the
+    weights -- and the run ends where the uninterrupted one ends."""
+    from mc_water_ls_mw_amd.farm import run
+    b = boxes48()
+    kw = dict(walkers=3, temperature=200.0, seed=pin.SEED, thermalise=True, list_update_int=4, mpi_sync_int=4,
+              wl_factor=F0, flat_chk_int=10 ** 9, outdir=str(tmp_path))
+    full = run([b[0][0], b[1][0]], [b[0][1], b[1][1]], cycles=16, **kw)
+    run([b[0][0], b[1][0]], [b[0][1], b[1][1]], cycles=8, chkpt_dump_int=8, **kw)
+    rest = run([b[0][0], b[1][0]], [b[0][1], b[1][1]], cycles=8, restart=True, **kw)
+    assert full["tables"][0].max() > 0
+    assert np.allclose(rest["tables"][0], full["tables"][0], rtol=1e-9, atol=1e-11)      # weights
+    assert np.allclose(rest["tables"][1], full["tables"][1], rtol=1e-12, atol=1e-12)     # histogram
+    for k in range(3):
+        a, r = full["first_walkers"][k], rest["first_walkers"][k]
+        assert np.abs(np.array(a["positions"]) - np.array(r["positions"])).max() < 1e-8 and a["ls"] == r["ls"]
+
+
 @pytest.mark.parametrize("mode", ["dd", "swetnam"])
 def test_farm_restart_restores_the_per_walker_wang_landau_state(tmp_path, mode):
     """mc_checkpoint_load reads wl_factor / wl_invt_active on EVERY rank (mc_moves.F90:447-464).  With 'dd' every walker is
