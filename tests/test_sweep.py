@@ -291,11 +291,13 @@ def test_farm_loop_equals_oracle_replay_including_stale_list_drift(so, c_oracle)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nlat", [2, 1])
-def test_npt_sweep_with_volume_moves_on_device_follows_the_oracle(so, c_oracle, nlat):
+@pytest.mark.parametrize("nlat,scale", [(2, 1.0), (1, 1.0), (2, 0.8)])
+def test_npt_sweep_with_volume_moves_on_device_follows_the_oracle(so, c_oracle, nlat, scale):
     """The whole move set on the device: translations, volume moves (both cells change, positions rescaled, image
     vectors rebuilt, full-box energies with the existing lists, restore on rejection), Wang-Landau updates, lattice
-    switches; lists rebuilt in between after mw_sweep_sync_cells.  Walker by walker against mwo_sweep_full."""
+    switches; lists rebuilt in between after mw_sweep_sync_cells.  Walker by walker against mwo_sweep_full.
+    scale = 0.8: the cells compressed to twice the density -- a dozen neighbours inside the cutoff (the volume move's
+    full-box energy overflows its in-range queue and rescans), list rows past the 32 entries the LDS copies hold."""
     from mc_water_ls_mw_amd import lattice as lat
     from mc_water_ls_mw_amd.sweep import MuGrid
     from oracle import FullSweepState
@@ -303,9 +305,9 @@ def test_npt_sweep_with_volume_moves_on_device_follows_the_oracle(so, c_oracle, 
     grid = MuGrid(101, -400.0, 400.0)
     boxes, nw = [], 4
     for w in range(nw):
-        boxes.append((z1["h"], lat.thermalise(z1["xyz"], 0.06, 360 + w)))
+        boxes.append((z1["h"] * scale, lat.thermalise(z1["xyz"], 0.06, 360 + w) * scale))
         if nlat == 2:
-            boxes.append((z2["h"], lat.thermalise(z2["xyz"], 0.06, 380 + w)))
+            boxes.append((z2["h"] * scale, lat.thermalise(z2["xyz"], 0.06, 380 + w) * scale))
     p_au = 1.0 / 2.90363081e8
     from mc_water_ls_mw_amd.energy import load_boxes
     from mc_water_ls_mw_amd.sweep import WalkerFarm
