@@ -206,6 +206,20 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                                            unbiased_hist=uh[k], hmatrix=h[2 * k:2 * k + 2], ref_ljr=ref_ljr[2 * k:2 * k + 2],
                                            ljr=x[2 * k:2 * k + 2], ls=st["ls"]))
             nchk += 1
+        def check_flags_everywhere():
+            """farm.check_flags on every rank, and every rank stops if one of them has to (the reference's ranks agree before they
+            stop, mc_moves.F90:187-201; a rank that raised alone left the others waiting in their next collective)."""
+            err = None
+            try:
+                farm.check_flags()
+            except Exception as e:                                 # noqa: BLE001 -- re-raised below, after the ranks have agreed
+                err = e
+            stop = comms.get_max(1.0 if err is not None else 0.0) if comms.world_size > 1 else float(err is not None)
+            if err is not None:
+                raise err
+            if stop:
+                raise RuntimeError("another rank's walkers failed their window / image-vector check (its message says which)")
+
         mon_acc = mon_vatt = mon_vacc = np.zeros(walkers, dtype=np.int64)
         mon_cycle = 0
         t0 = time.perf_counter()
@@ -234,7 +248,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             if cyc % mpi_sync_int == 0:                            # mc_moves.F90:258-276
                 em.sync()
                 if npt or dd:
-                    farm.check_flags()
+                    check_flags_everywhere()
                 if not dd:                                         # (:270-272: the windows exchange nothing)
                     synced = farm.synchronise(comms, regauge=regauge)
             if cyc % monitor_int == 0:                             # mc_monitor_stats, :281-284
@@ -280,7 +294,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                 write_checkpoints(cyc)
         em.sync()
         if npt or dd:
-            farm.check_flags()                                     # every walker, not only the ones read out below
+            check_flags_everywhere()                               # every walker, not only the ones read out below
         wall = time.perf_counter() - t0
         joined = None
         if dd:                                                     # mc_monitor_stats, :1883-1886

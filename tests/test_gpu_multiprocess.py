@@ -77,3 +77,18 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["value"] > res["per_gpu"] > 0
     assert "2 x 32 independent walkers" in res["config"]["parallelism"]
+
+
+def test_every_rank_stops_when_one_rank_has_walkers_outside_their_windows():
+    """Four windows over two ranks, the pair starting at mu ~ -0.1: the outer windows' walkers are not inside their windows after
+    three equilibration cycles, and the run stops with the reference's message (mc_moves.F90:187-201) -- on EVERY rank, promptly:
+    a rank that raised alone left the other one waiting in the windows' all-gather."""
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "mc_water_ls_mw_amd.farm", "--walkers", "2", "--cycles", "8", "--strategy", "dd",
+           "--leshift", "--eq-cycles", "3", "--no-thermalise", "--backend", "gloo", "--share-device"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    # (here both ranks hold an outer window: each reports its own walkers, after the two have agreed to stop)
+    assert out.stderr.count("MwError: Error : Not all walkers have reached their designated window after 3 MC cycles") == 2
+    assert "join_eta" not in out.stderr                            # nobody went on to the windows' all-gather
