@@ -323,8 +323,30 @@ def self_launch(n, json_fd):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # rank 0's output is drained by a thread while all ranks are watched: a rank that dies (a bad device index, an
+    # allocation that fails) would otherwise leave the others in a collective until its watchdog gives up -- the
+    # survivors are ended here instead (exactly the children started above), and the failure is reported at once
+    import threading
+    import time
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            deadline = time.monotonic() + 10.0
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.1)
+    codes = [p.wait() for p in procs]
+    reader.join(timeout=10.0)
+    out0 = b"".join(c for c in chunks if c)
     lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.strip()]
     if any(codes):
         sys.stderr.write(f"bench.py --gpus {n}: rank exit codes {codes}\n")

@@ -69,3 +69,17 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+def test_self_launched_ranks_that_fail_are_reported_at_once():
+    """`python bench.py --gpus 2` on a box without an MI355X: both children refuse to run (no CPU fallback), and the parent says
+    which ranks failed and returns their status instead of waiting for a line that never comes."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box WITHOUT a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 1 and p.stdout.strip() == ""
+    assert "rank exit codes [1, 1]" in p.stderr and p.stderr.count("no CPU fallback") == 2
