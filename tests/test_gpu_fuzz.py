@@ -75,3 +75,39 @@ def test_random_systems_follow_the_oracle(seed, c_oracle):
             assert np.all(np.abs((en - eo) - (rn - ro))[~big] <= DE_ATOL), (kind, nreq)
     finally:
         em.energy_deinit()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_systems_through_the_monte_carlo_driver(seed, c_oracle):
+    """The same random systems through the device-resident driver (one lattice, two walkers): every residency of a walker's
+    data (positions + rows in LDS, positions only, global memory with and without look-ahead), ragged and over-long rows,
+    cells thin enough for self images -- the chain is the oracle's move for move."""
+    from mc_water_ls_mw_amd.energy import load_boxes
+    from mc_water_ls_mw_amd.sweep import WalkerFarm
+    from oracle import SweepOracle
+    from test_sweep import _compare
+    rng = np.random.default_rng(9000 + seed)
+    kind, h, x = random_system(rng)
+    if len(x) < 2:
+        pytest.skip("a single molecule has nothing to move against")
+    iv = c_oracle.ivects(h)
+    if len(iv) > 1000:
+        pytest.skip("cell too thin for the image table")
+    if c_oracle.neighbours(x, iv, 64)[0].max() > 60:
+        pytest.skip("too dense for maxneigh = 64 once molecules move")
+    so = SweepOracle()
+    from mc_water_ls_mw_amd import lattice as lat
+    boxes = [(h, lat.thermalise(x, 0.02, 70 + w)) for w in range(2)]
+    nmoves = 160
+    em = load_boxes([b[0] for b in boxes], [b[1] for b in boxes], maxneigh=64)
+    farm = WalkerFarm(em, 1, float(rng.uniform(150.0, 400.0)), float(rng.uniform(0.3, 1.1)))
+    try:
+        farm.set_states(1, np.zeros(2))
+        log = farm.sweep(nmoves, seed=31 + seed, move0=5, log=True)
+        pos = [farm.positions(b) for b in (1, 2)]
+        st = [farm.state(w) for w in (1, 2)]
+        for w in range(2):
+            ref = so.sweep(nmoves, 31 + seed, w, 5, [boxes[w][0]], [boxes[w][1]], farm.beta, farm.max_trans, maxneigh=64)
+            _compare(log[w], ref, st[w], [pos[w]])
+    finally:
+        em.energy_deinit()
