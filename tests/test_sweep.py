@@ -290,29 +290,18 @@ def test_farm_loop_equals_oracle_replay_including_stale_list_drift(so, c_oracle)
         assert abs(res["drift_walker1_Ha"][l] - drift_oracle[l]) < 1e-9
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("nlat,scale", [(2, 1.0), (1, 1.0), (2, 0.8)])
-def test_npt_sweep_with_volume_moves_on_device_follows_the_oracle(so, c_oracle, nlat, scale):
-    """The whole move set on the device: translations, volume moves (both cells change, positions rescaled, image
-    vectors rebuilt, full-box energies with the existing lists, restore on rejection), Wang-Landau updates, lattice
-    switches; lists rebuilt in between after mw_sweep_sync_cells.  Walker by walker against mwo_sweep_full.
-    scale = 0.8: the cells compressed to twice the density -- a dozen neighbours inside the cutoff (the volume move's
-    full-box energy overflows its in-range queue and rescans), list rows past the 32 entries the LDS copies hold."""
-    from mc_water_ls_mw_amd import lattice as lat
+def _npt_against_oracle(so, c_oracle, boxes, nlat, nw, temperature=200.0, max_trans_ang=1.1, pressure_atm=1.0, vol_prob=0.1,
+                        dv_max_ang=0.924, seed=11, nmoves=96):
+    """`nw` walkers of `nlat` lattices each (boxes: nlat * nw (h, xyz) pairs): two launches of `nmoves` moves with volume moves on
+    the device, lists rebuilt in between after mw_sweep_sync_cells, against mwo_sweep_full walker by walker."""
     from mc_water_ls_mw_amd.sweep import MuGrid
     from oracle import FullSweepState
-    z1, z2 = load_golden("ic48"), load_golden("ih48")
     grid = MuGrid(101, -400.0, 400.0)
-    boxes, nw = [], 4
-    for w in range(nw):
-        boxes.append((z1["h"] * scale, lat.thermalise(z1["xyz"], 0.06, 360 + w) * scale))
-        if nlat == 2:
-            boxes.append((z2["h"] * scale, lat.thermalise(z2["xyz"], 0.06, 380 + w) * scale))
-    p_au = 1.0 / 2.90363081e8
+    p_au = pressure_atm / 2.90363081e8
     from mc_water_ls_mw_amd.energy import load_boxes
     from mc_water_ls_mw_amd.sweep import WalkerFarm
     em = load_boxes([b[0] for b in boxes], [b[1] for b in boxes])
-    farm = WalkerFarm(em, nlat, 200.0, 1.1, grid=grid, weight=np.zeros(101), pressure_au=p_au)
+    farm = WalkerFarm(em, nlat, temperature, max_trans_ang, grid=grid, weight=np.zeros(101), pressure_au=p_au)
     try:
         if nlat == 2:
             farm.options(record=True, samplerun=False, always_switch=True, npt=True, wl_factor=0.05)
@@ -320,16 +309,17 @@ def test_npt_sweep_with_volume_moves_on_device_follows_the_oracle(so, c_oracle, 
             em._chk(em.L.mw_sweep_options(0, 1, 0, 1, __import__("ctypes").c_double(grid.av_binwidth),
                                           __import__("ctypes").c_double(0.0), __import__("ctypes").c_double(0.0),
                                           __import__("ctypes").c_double(p_au)))
-        farm.moves(trans_prob=0.5, vol_prob=0.1, dv_max_ang=0.924)
+        farm.moves(trans_prob=0.5, vol_prob=vol_prob, dv_max_ang=dv_max_ang)
         mus = [farm.initial_mu(w) for w in range(1, nw + 1)]
         for w in range(1, nw + 1):
             farm.set_state(w, 1, mus[w - 1])
         e0 = em.model_energy.copy()
-        log_a = farm.sweep(96, seed=11, move0=0, log=True)
+        log_a = farm.sweep(nmoves, seed=seed, move0=0, log=True)
         farm.sync_cells()
         em.build_neighbours_batch(1, nlat * nw)
-        log_b = farm.sweep(96, seed=11, move0=96, log=True)
+        log_b = farm.sweep(nmoves, seed=seed, move0=nmoves, log=True)
         hdev = farm.sync_cells()
+        nvol = 0
         for w in range(nw):
             bx = boxes[nlat * w:nlat * w + nlat]
             st = FullSweepState(c_oracle, [b[0] for b in bx], [b[1] for b in bx])
@@ -337,12 +327,12 @@ def test_npt_sweep_with_volume_moves_on_device_follows_the_oracle(so, c_oracle, 
             st.ls_mu = mus[w]
             wt, hi, uh = np.zeros(101), np.zeros(101), np.zeros(101)
             kw = dict(record=nlat == 2, samplerun=False, always_switch=nlat == 2, npt=True, wl_factor=0.05, pressure=p_au)
-            la = so.full(st, 96, 11, w, 0, farm.transP, farm.dv_max, farm.beta, farm.max_trans, grid, wt, hi, uh, **kw)
+            la = so.full(st, nmoves, seed, w, 0, farm.transP, farm.dv_max, farm.beta, farm.max_trans, grid, wt, hi, uh, **kw)
             st.rebuild_lists(c_oracle)
-            lb = so.full(st, 96, 11, w, 96, farm.transP, farm.dv_max, farm.beta, farm.max_trans, grid, wt, hi, uh, **kw)
+            lb = so.full(st, nmoves, seed, w, nmoves, farm.transP, farm.dv_max, farm.beta, farm.max_trans, grid, wt, hi, uh, **kw)
             ref, dev = np.concatenate([la, lb]), np.concatenate([log_a[w], log_b[w]])
             assert np.array_equal(dev[:, 0], ref[:, 0]) and np.array_equal(dev[:, 1], ref[:, 1])     # molecule, outcome flags
-            assert st.nvol[0] > 10
+            nvol += int(st.nvol[0])
             assert farm.volume_moves(w + 1) == (int(st.nvol[0]), int(st.nvol[1]))
             assert np.allclose(dev[:, 2:7], ref[:, 2:7], rtol=1e-9, atol=1e-9)
             for l in range(nlat):
@@ -354,8 +344,51 @@ def test_npt_sweep_with_volume_moves_on_device_follows_the_oracle(so, c_oracle, 
             if nlat == 2:
                 t = farm.tables(w + 1)
                 assert np.allclose(t[0], wt, rtol=1e-10, atol=1e-11) and np.allclose(t[1], hi, rtol=1e-12)
+        return nvol
     finally:
         em.energy_deinit()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nlat,scale", [(2, 1.0), (1, 1.0), (2, 0.8)])
+def test_npt_sweep_with_volume_moves_on_device_follows_the_oracle(so, c_oracle, nlat, scale):
+    """The whole move set on the device: translations, volume moves (both cells change, positions rescaled, image
+    vectors rebuilt, full-box energies with the existing lists, restore on rejection), Wang-Landau updates, lattice
+    switches; lists rebuilt in between after mw_sweep_sync_cells.  Walker by walker against mwo_sweep_full.
+    scale = 0.8: the cells compressed to twice the density -- a dozen neighbours inside the cutoff (the volume move's
+    full-box energy overflows its in-range queue and rescans), list rows past the 32 entries the LDS copies hold."""
+    from mc_water_ls_mw_amd import lattice as lat
+    z1, z2 = load_golden("ic48"), load_golden("ih48")
+    boxes, nw = [], 4
+    for w in range(nw):
+        boxes.append((z1["h"] * scale, lat.thermalise(z1["xyz"], 0.06, 360 + w) * scale))
+        if nlat == 2:
+            boxes.append((z2["h"] * scale, lat.thermalise(z2["xyz"], 0.06, 380 + w) * scale))
+    assert _npt_against_oracle(so, c_oracle, boxes, nlat, nw) > 10 * nw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_npt_driver_on_random_lattice_pairs(so, c_oracle, seed):
+    """Seeded variety for the volume-move path: Ic / Ih cells of equal molecule count, replicated, scaled between twice and
+    0.8 times the ice density, sheared, at random temperature, pressure (up to 10^4 atm: cells that do shrink) and step sizes."""
+    from mc_water_ls_mw_amd import lattice as lat
+    rng = np.random.default_rng(4200 + seed)
+    z1, z2 = load_golden("ic48"), load_golden("ih48")
+    reps = [(1, 1, 1), (1, 1, 2), (2, 1, 1), (1, 2, 2)][int(rng.integers(0, 4))]
+    nlat = 2 if rng.random() < 0.75 else 1
+    scale = float(rng.uniform(0.8, 1.08))
+    boxes, nw = [], 2
+    shear = np.eye(3) + (rng.uniform(-0.04, 0.04, (3, 3)) * (1 - np.eye(3)) if rng.random() < 0.5 else 0.0)
+    for w in range(nw):
+        for l, z in enumerate((z1, z2)[:nlat]):
+            h, x = lat.replicate(z["h"], z["xyz"], reps)
+            x = lat.thermalise(x, float(rng.uniform(0.02, 0.1)), 900 + 10 * w + l)
+            boxes.append((np.ascontiguousarray(h @ shear) * scale, np.ascontiguousarray(x @ shear) * scale))
+    nvol = _npt_against_oracle(so, c_oracle, boxes, nlat, nw, temperature=float(rng.uniform(150.0, 350.0)),
+                               max_trans_ang=float(rng.uniform(0.3, 1.1)), pressure_atm=float(10.0 ** rng.uniform(0.0, 4.0)),
+                               vol_prob=float(rng.uniform(0.05, 0.3)), dv_max_ang=float(rng.uniform(0.2, 1.2)), seed=50 + seed, nmoves=80)
+    assert nvol > 4
 
 
 @pytest.mark.gpu
