@@ -593,15 +593,23 @@ void k_sweep(double* pos, double* hmat, double* ivect,
     __syncthreads();
 
 
-    // mc_lattice_switch's exponent for a walker in lattice lsx with energies E0, E1 (:1557-1572), less new_eta - old_eta
-    auto switch_dk = [&](double E0, double E1, int lsx) {
+    // mc_lattice_switch's exponent for a walker in lattice lsx with energies E0, E1 (:1557-1572) in two parts: the energy /
+    // volume terms that stand BEFORE "+ new_eta - old_eta" in the reference's expression, and the leshift terms added after it
+    auto switch_dk_terms = [&](double E0, double E1, int lsx, double& lesh) {
         const double Els = lsx == 1 ? E0 : E1, Elsn = lsx == 1 ? E1 : E0;
         const double V1 = svol[0], V2 = svol[1];
         const double Vls = lsx == 1 ? V1 : V2, Vlsn = lsx == 1 ? V2 : V1;
         double dk;
         if (C.npt) dk = C.beta * Elsn - C.beta * Els + C.beta * C.pressure * (Vlsn - Vls) - (double)N * (lsx == 1 ? C.lgv21 : C.lgv12);
         else       dk = C.beta * Elsn - C.beta * Els;
-        return dk + (lsx == 1 ? C.beta * C.dref : -(C.beta * C.dref));        // leshift: - beta ref(lsn) + beta ref(ls), :1567,1572
+        lesh = lsx == 1 ? C.beta * C.dref : -(C.beta * C.dref);               // leshift: - beta ref(lsn) + beta ref(ls), :1567,1572
+        return dk;
+    };
+    // ... and the whole of it less new_eta - old_eta (= eta_weight(ls_mu) - eta_weight(ls_mu): see post_move)
+    auto switch_dk = [&](double E0, double E1, int lsx) {
+        double lesh;
+        const double dk = switch_dk_terms(E0, E1, lsx, lesh);
+        return dk + lesh;
     };
     // What follows EITHER move type (wavefront 0): mc_update_wl_bins (:1597-1689) on the walker's tables, then one
     // mc_lattice_switch attempt (:1536-1594).  eta_fin = eta_weight(ls_mu) with the weights as the move found them,
@@ -681,17 +689,30 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             }
         }
         if (do_switch) {
-            // new_eta - old_eta of the switch (:1557-1558) = eta_weight(ls_mu) - eta_weight(ls_mu) with the weights as they are
-            // NOW: 0 unless that weight is not finite
-            double deta;
-            if (C.samplerun || !C.record) deta = eta_fin - eta_fin;
+            // new_eta - old_eta of the switch (:1557-1558) = eta_weight(ls_mu) - eta_weight(ls_mu) with the weights as they are NOW,
+            // added to the energy terms ONE AFTER THE OTHER (:1561-1563): (x + eta) - eta.  For a modest eta that is x to a rounding
+            // residue below 1.2e-10 (|eta| < 2^20; less than two exp implementations differ by in exp(-x) once |x| > 1e-6) and the
+            // exponential computed ahead (cmp_sw) stands.  A large eta absorbs x -- above all the hard wall of a walker OUTSIDE its
+            // order-parameter range, eta = huge(1.0_dp): the difference is then exactly 0 and the reference always switches.  There
+            // the expression is evaluated as the reference writes it.
+            double cmp = cmp_sw, ew = 0.0;
+            const bool wall = C.mg.in_window && (C.ls_mu < C.mg.mu_lo || C.ls_mu > C.mg.mu_hi);
+            bool plain;
+            if (C.samplerun || !C.record) { ew = eta_fin; plain = !wall && fabs(ew) < 1048576.0; }
             else {
                 const int k = kc < 2 ? 2 : (kc > nbins - 1 ? nbins - 1 : kc);
                 const double wa = fabs(sweight[k - 2]), wb = fabs(sweight[k - 1]), wc = fabs(sweight[k]);
-                if (wa < 1.0e150 && wb < 1.0e150 && wc < 1.0e150) deta = 0.0;     // finite weights interpolate to a finite weight
-                else { const double ew = lane_eta(C.mg, sweight, smub, sbw, C.ls_mu, kc); deta = ew - ew; }
+                plain = !wall && wa < 1048576.0 && wb < 1048576.0 && wc < 1048576.0;   // (interpolation stays between its nodes' weights)
+                if (!plain) ew = lane_eta(C.mg, sweight, smub, sbw, C.ls_mu, kc);
             }
-            double cmp = deta == 0.0 ? cmp_sw : deta;                             // exp(-(dk + deta)), dk + 0 = dk
+            if (!plain) {
+                double lesh;
+                double d = switch_dk_terms(C.men0, C.men1, C.ls, lesh);
+                d = d + ew;
+                d = d - ew;
+                d = d + lesh;
+                cmp = exp_any(-d);                                                // (NaN for weights that are not finite: no switch)
+            }
             cmp = cmp > 1.0 ? 1.0 : cmp;
             if (u6 < cmp) {
                 const double V1 = svol[0], V2 = svol[1];

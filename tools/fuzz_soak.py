@@ -14,16 +14,22 @@ import torch  # noqa: E402,F401
 import test_gpu_fuzz as fz  # noqa: E402
 from oracle import COracle  # noqa: E402
 
+import test_sweep as ts  # noqa: E402
+from oracle import SweepOracle  # noqa: E402
+
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 c = COracle()
+so = SweepOracle()
 bad, skipped = [], 0
 for seed in range(first, first + count):
-    for name in ("test_random_systems_follow_the_oracle", "test_random_systems_through_the_monte_carlo_driver"):
-        fn = getattr(fz, name)
-        fn = getattr(fn, "__wrapped__", fn)
+    for name in ("test_random_systems_follow_the_oracle", "test_random_systems_through_the_monte_carlo_driver",
+                 "test_npt_driver_on_random_lattice_pairs"):
         try:
-            fn(seed, c)
+            if name.startswith("test_npt"):
+                ts.test_npt_driver_on_random_lattice_pairs(so, c, seed)          # (volume moves on random Ic / Ih pairs)
+            else:
+                getattr(fz, name)(seed, c)
         except pytest.skip.Exception:
             skipped += 1
         except Exception:                                        # noqa: BLE001
