@@ -291,46 +291,72 @@ def test_farm_loop_equals_oracle_replay_including_stale_list_drift(so, c_oracle)
 
 
 def _npt_against_oracle(so, c_oracle, boxes, nlat, nw, temperature=200.0, max_trans_ang=1.1, pressure_atm=1.0, vol_prob=0.1,
-                        dv_max_ang=0.924, seed=11, nmoves=96):
+                        dv_max_ang=0.924, seed=11, nmoves=96, mu_range=400.0, weight0=None, samplerun=False, always_switch=True,
+                        wl_factor=0.05, eta_interp=True, leshift=False, minu=False, log_unbiased_norm=0.0):
     """`nw` walkers of `nlat` lattices each (boxes: nlat * nw (h, xyz) pairs): two launches of `nmoves` moves with volume moves on
-    the device, lists rebuilt in between after mw_sweep_sync_cells, against mwo_sweep_full walker by walker."""
+    the device (vol_prob = 0: translations only, NVT acceptance), lists rebuilt in between after mw_sweep_sync_cells, against
+    mwo_sweep_full walker by walker.  Two lattices: the run options of mc_cycle (weights, sample run, leshift, MINU, ...)."""
     from mc_water_ls_mw_amd.sweep import MuGrid
     from oracle import FullSweepState
-    grid = MuGrid(101, -400.0, 400.0)
+    grid = MuGrid(101, -mu_range, mu_range)
     p_au = pressure_atm / 2.90363081e8
+    npt = vol_prob > 0.0
+    weight0 = np.zeros(101) if weight0 is None else np.asarray(weight0, dtype=np.float64)
     from mc_water_ls_mw_amd.energy import load_boxes
     from mc_water_ls_mw_amd.sweep import WalkerFarm
     em = load_boxes([b[0] for b in boxes], [b[1] for b in boxes])
-    farm = WalkerFarm(em, nlat, temperature, max_trans_ang, grid=grid, weight=np.zeros(101), pressure_au=p_au)
+    farm = WalkerFarm(em, nlat, temperature, max_trans_ang, grid=grid, weight=weight0.copy(), eta_interp=eta_interp, pressure_au=p_au)
+    ref_h = (0.0, 0.0)
     try:
         if nlat == 2:
-            farm.options(record=True, samplerun=False, always_switch=True, npt=True, wl_factor=0.05)
+            farm.options(record=True, samplerun=samplerun, always_switch=always_switch, npt=npt, wl_factor=wl_factor,
+                         log_unbiased_norm=log_unbiased_norm)
+            if leshift:
+                ref_h = farm.starting_enthalpy(1, npt)
+                farm.leshift(ref_h)
+            if minu:
+                farm.minu(True)
         else:
             em._chk(em.L.mw_sweep_options(0, 1, 0, 1, __import__("ctypes").c_double(grid.av_binwidth),
                                           __import__("ctypes").c_double(0.0), __import__("ctypes").c_double(0.0),
                                           __import__("ctypes").c_double(p_au)))
-        farm.moves(trans_prob=0.5, vol_prob=vol_prob, dv_max_ang=dv_max_ang)
+        if npt:
+            farm.moves(trans_prob=0.5, vol_prob=vol_prob, dv_max_ang=dv_max_ang)
         mus = [farm.initial_mu(w) for w in range(1, nw + 1)]
         for w in range(1, nw + 1):
             farm.set_state(w, 1, mus[w - 1])
         e0 = em.model_energy.copy()
         log_a = farm.sweep(nmoves, seed=seed, move0=0, log=True)
-        farm.sync_cells()
+        hdev = farm.sync_cells() if npt else np.array(em.hmatrix)
         em.build_neighbours_batch(1, nlat * nw)
         log_b = farm.sweep(nmoves, seed=seed, move0=nmoves, log=True)
-        hdev = farm.sync_cells()
+        if npt:
+            hdev = farm.sync_cells()
         nvol = 0
+        transP, dvm = (farm.transP, farm.dv_max) if npt else (1.0, 0.0)
+        if leshift:
+            so.set_leshift(*ref_h)
+        so.set_minu(minu)
+        try:
+            refs = []
+            for w in range(nw):
+                bx = boxes[nlat * w:nlat * w + nlat]
+                st = FullSweepState(c_oracle, [b[0] for b in bx], [b[1] for b in bx])
+                st.model_energy[:] = e0[nlat * w:nlat * w + nlat]
+                st.ls_mu = mus[w]
+                wt, hi, uh = weight0.copy(), np.zeros(101), np.zeros(101)
+                kw = dict(record=nlat == 2, samplerun=samplerun and nlat == 2, always_switch=always_switch and nlat == 2, npt=npt,
+                          wl_factor=wl_factor, pressure=p_au, eta_interp=eta_interp, log_unbiased_norm=log_unbiased_norm)
+                la = so.full(st, nmoves, seed, w, 0, transP, dvm, farm.beta, farm.max_trans, grid, wt, hi, uh, **kw)
+                st.rebuild_lists(c_oracle)
+                lb = so.full(st, nmoves, seed, w, nmoves, transP, dvm, farm.beta, farm.max_trans, grid, wt, hi, uh, **kw)
+                refs.append((st, wt, hi, uh, np.concatenate([la, lb])))
+        finally:
+            so.set_leshift(0.0, 0.0)
+            so.set_minu(False)
         for w in range(nw):
-            bx = boxes[nlat * w:nlat * w + nlat]
-            st = FullSweepState(c_oracle, [b[0] for b in bx], [b[1] for b in bx])
-            st.model_energy[:] = e0[nlat * w:nlat * w + nlat]
-            st.ls_mu = mus[w]
-            wt, hi, uh = np.zeros(101), np.zeros(101), np.zeros(101)
-            kw = dict(record=nlat == 2, samplerun=False, always_switch=nlat == 2, npt=True, wl_factor=0.05, pressure=p_au)
-            la = so.full(st, nmoves, seed, w, 0, farm.transP, farm.dv_max, farm.beta, farm.max_trans, grid, wt, hi, uh, **kw)
-            st.rebuild_lists(c_oracle)
-            lb = so.full(st, nmoves, seed, w, nmoves, farm.transP, farm.dv_max, farm.beta, farm.max_trans, grid, wt, hi, uh, **kw)
-            ref, dev = np.concatenate([la, lb]), np.concatenate([log_a[w], log_b[w]])
+            st, wt, hi, uh, ref = refs[w]
+            dev = np.concatenate([log_a[w], log_b[w]])
             assert np.array_equal(dev[:, 0], ref[:, 0]) and np.array_equal(dev[:, 1], ref[:, 1])     # molecule, outcome flags
             nvol += int(st.nvol[0])
             assert farm.volume_moves(w + 1) == (int(st.nvol[0]), int(st.nvol[1]))
@@ -344,6 +370,8 @@ def _npt_against_oracle(so, c_oracle, boxes, nlat, nw, temperature=200.0, max_tr
             if nlat == 2:
                 t = farm.tables(w + 1)
                 assert np.allclose(t[0], wt, rtol=1e-10, atol=1e-11) and np.allclose(t[1], hi, rtol=1e-12)
+                if samplerun:
+                    assert np.allclose(t[2], uh, rtol=1e-9, atol=1e-300)
         return nvol
     finally:
         em.energy_deinit()
@@ -392,6 +420,35 @@ def test_npt_driver_on_random_lattice_pairs(so, c_oracle, seed):
                                max_trans_ang=float(rng.uniform(0.3, 1.1)), pressure_atm=float(10.0 ** rng.uniform(0.0, 4.0)),
                                vol_prob=float(rng.uniform(0.05, 0.3)), dv_max_ang=float(rng.uniform(0.2, 1.2)), seed=50 + seed, nmoves=80)
     assert nvol > 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_driver_run_options_on_random_pairs(so, c_oracle, seed):
+    """The run options of mc_cycle in random combination on the 48-molecule Ic / Ih pair (scaled 0.85 .. 1.05): NVT or NPT, a
+    weight table of random size (bumps of a few kT up to 10^8 kT, where the switch's eta terms absorb the energies), an order-
+    parameter range that may leave the walkers outside it, weight generation or a sample run, leshift, MINU, interpolation off."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.sweep import MuGrid
+    rng = np.random.default_rng(6100 + seed)
+    z1, z2 = load_golden("ic48"), load_golden("ih48")
+    scale = float(rng.uniform(0.85, 1.05))
+    boxes, nw = [], 2
+    for w in range(nw):
+        for l, z in enumerate((z1, z2)):
+            boxes.append((z["h"] * scale, lat.thermalise(z["xyz"], float(rng.uniform(0.02, 0.1)), 700 + 10 * w + l) * scale))
+    mu_range = float(rng.choice([60.0, 400.0, 400.0, 3000.0]))
+    grid = MuGrid(101, -mu_range, mu_range)
+    amp = float(10.0 ** rng.uniform(0.0, 8.0)) if rng.random() < 0.5 else float(rng.uniform(0.0, 20.0))
+    weight0 = amp * (np.exp(-(grid.mu_bin / (0.3 * mu_range)) ** 2) + 0.3 * rng.random(101))
+    samplerun = bool(rng.random() < 0.4)
+    npt = bool(rng.random() < 0.5)
+    _npt_against_oracle(so, c_oracle, boxes, 2, nw, temperature=float(rng.uniform(150.0, 300.0)), max_trans_ang=float(rng.uniform(0.3, 1.1)),
+                        pressure_atm=float(10.0 ** rng.uniform(0.0, 3.0)), vol_prob=float(rng.uniform(0.05, 0.3)) if npt else 0.0,
+                        dv_max_ang=float(rng.uniform(0.2, 1.0)), seed=90 + seed, nmoves=80, mu_range=mu_range, weight0=weight0,
+                        samplerun=samplerun, always_switch=bool(rng.random() < 0.8), wl_factor=0.0 if samplerun else float(rng.uniform(0.001, 0.5)),
+                        eta_interp=bool(rng.random() < 0.8), leshift=bool(rng.random() < 0.4), minu=bool(rng.random() < 0.3),
+                        log_unbiased_norm=float(rng.uniform(0.0, 5.0)) if samplerun else 0.0)
 
 
 @pytest.mark.gpu
