@@ -17,6 +17,12 @@ from oracle import COracle  # noqa: E402
 import test_sweep as ts  # noqa: E402
 from oracle import SweepOracle  # noqa: E402
 
+class _Env:                      # what the tests use of pytest's monkeypatch
+    @staticmethod
+    def setenv(k, v):
+        os.environ[k] = v
+
+
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 c = COracle()
@@ -24,10 +30,14 @@ so = SweepOracle()
 bad, skipped = [], 0
 for seed in range(first, first + count):
     for name in ("test_random_systems_follow_the_oracle", "test_random_systems_through_the_monte_carlo_driver",
-                 "test_npt_driver_on_random_lattice_pairs", "test_driver_run_options_on_random_pairs"):
+                 "test_npt_driver_on_random_lattice_pairs", "test_driver_run_options_on_random_pairs",
+                 "test_lookahead_with_random_run_options"):
         try:
             if name.startswith("test_npt"):
                 ts.test_npt_driver_on_random_lattice_pairs(so, c, seed)          # (volume moves on random Ic / Ih pairs)
+            elif name.startswith("test_lookahead"):
+                ts.test_lookahead_with_random_run_options(seed, _Env)            # (look-ahead 2 / 4 = the sequential chain)
+                os.environ.pop("MW_SWEEP_AHEAD", None)
             elif name.startswith("test_driver"):
                 ts.test_driver_run_options_on_random_pairs(so, c, seed)          # (the run options of mc_cycle in random combination)
             else:
