@@ -441,6 +441,8 @@ def test_driver_run_options_on_random_pairs(so, c_oracle, seed):
     grid = MuGrid(101, -mu_range, mu_range)
     amp = float(10.0 ** rng.uniform(0.0, 8.0)) if rng.random() < 0.5 else float(rng.uniform(0.0, 20.0))
     weight0 = amp * (np.exp(-(grid.mu_bin / (0.3 * mu_range)) ** 2) + 0.3 * rng.random(101))
+    if rng.random() < 0.3:                                        # (tables with negative entries: what many walkers exchanging with the
+        weight0 = weight0 - float(rng.uniform(0.0, 2.0)) * amp    #  reference's own arithmetic end up with, WalkerFarm.synchronise)
     samplerun = bool(rng.random() < 0.4)
     npt = bool(rng.random() < 0.5)
     _npt_against_oracle(so, c_oracle, boxes, 2, nw, temperature=float(rng.uniform(150.0, 300.0)), max_trans_ang=float(rng.uniform(0.3, 1.1)),
