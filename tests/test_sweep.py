@@ -292,7 +292,7 @@ def test_farm_loop_equals_oracle_replay_including_stale_list_drift(so, c_oracle)
 
 def _npt_against_oracle(so, c_oracle, boxes, nlat, nw, temperature=200.0, max_trans_ang=1.1, pressure_atm=1.0, vol_prob=0.1,
                         dv_max_ang=0.924, seed=11, nmoves=96, mu_range=400.0, weight0=None, samplerun=False, always_switch=True,
-                        wl_factor=0.05, eta_interp=True, leshift=False, minu=False, log_unbiased_norm=0.0):
+                        wl_factor=0.05, eta_interp=True, leshift=False, minu=False, log_unbiased_norm=0.0, swetnam_alpha=None):
     """`nw` walkers of `nlat` lattices each (boxes: nlat * nw (h, xyz) pairs): two launches of `nmoves` moves with volume moves on
     the device (vol_prob = 0: translations only, NVT acceptance), lists rebuilt in between after mw_sweep_sync_cells, against
     mwo_sweep_full walker by walker.  Two lattices: the run options of mc_cycle (weights, sample run, leshift, MINU, ...)."""
@@ -316,6 +316,9 @@ def _npt_against_oracle(so, c_oracle, boxes, nlat, nw, temperature=200.0, max_tr
                 farm.leshift(ref_h)
             if minu:
                 farm.minu(True)
+            if swetnam_alpha is not None:                            # (as farm.run: every walker its own increment, starting at wl_factor)
+                farm.swetnam(True, swetnam_alpha, wl_factor)
+                farm.set_factors(wl_factor=np.full(nw, wl_factor))
         else:
             em._chk(em.L.mw_sweep_options(0, 1, 0, 1, __import__("ctypes").c_double(grid.av_binwidth),
                                           __import__("ctypes").c_double(0.0), __import__("ctypes").c_double(0.0),
@@ -345,17 +348,23 @@ def _npt_against_oracle(so, c_oracle, boxes, nlat, nw, temperature=200.0, max_tr
                 st.model_energy[:] = e0[nlat * w:nlat * w + nlat]
                 st.ls_mu = mus[w]
                 wt, hi, uh = weight0.copy(), np.zeros(101), np.zeros(101)
+                if swetnam_alpha is not None:
+                    so.set_swetnam(True, swetnam_alpha, wl_factor, -mu_range, mu_range, 0.0)
                 kw = dict(record=nlat == 2, samplerun=samplerun and nlat == 2, always_switch=always_switch and nlat == 2, npt=npt,
                           wl_factor=wl_factor, pressure=p_au, eta_interp=eta_interp, log_unbiased_norm=log_unbiased_norm)
                 la = so.full(st, nmoves, seed, w, 0, transP, dvm, farm.beta, farm.max_trans, grid, wt, hi, uh, **kw)
                 st.rebuild_lists(c_oracle)
                 lb = so.full(st, nmoves, seed, w, nmoves, transP, dvm, farm.beta, farm.max_trans, grid, wt, hi, uh, **kw)
-                refs.append((st, wt, hi, uh, np.concatenate([la, lb])))
+                refs.append((st, wt, hi, uh, np.concatenate([la, lb]), so.get_swetnam() if swetnam_alpha is not None else None))
         finally:
             so.set_leshift(0.0, 0.0)
             so.set_minu(False)
+            so.set_swetnam(False)
         for w in range(nw):
-            st, wt, hi, uh, ref = refs[w]
+            st, wt, hi, uh, ref, swet = refs[w]
+            if swet is not None:                                     # Swetnam's visit total and the increment it led to
+                f, sh, _ = farm.factors(w + 1, 1)
+                assert sh[0] == swet[0] and f[0] == pytest.approx(swet[1], rel=1e-9, abs=1e-12)
             dev = np.concatenate([log_a[w], log_b[w]])
             assert np.array_equal(dev[:, 0], ref[:, 0]) and np.array_equal(dev[:, 1], ref[:, 1])     # molecule, outcome flags
             nvol += int(st.nvol[0])
@@ -450,7 +459,8 @@ def test_driver_run_options_on_random_pairs(so, c_oracle, seed):
                         dv_max_ang=float(rng.uniform(0.2, 1.0)), seed=90 + seed, nmoves=80, mu_range=mu_range, weight0=weight0,
                         samplerun=samplerun, always_switch=bool(rng.random() < 0.8), wl_factor=0.0 if samplerun else float(rng.uniform(0.001, 0.5)),
                         eta_interp=bool(rng.random() < 0.8), leshift=bool(rng.random() < 0.4), minu=bool(rng.random() < 0.3),
-                        log_unbiased_norm=float(rng.uniform(0.0, 5.0)) if samplerun else 0.0)
+                        log_unbiased_norm=float(rng.uniform(0.0, 5.0)) if samplerun else 0.0,
+                        swetnam_alpha=float(10.0 ** rng.uniform(-3.0, 0.0)) if (not samplerun and rng.random() < 0.3) else None)
 
 
 @pytest.mark.gpu
