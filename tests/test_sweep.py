@@ -292,7 +292,8 @@ def test_farm_loop_equals_oracle_replay_including_stale_list_drift(so, c_oracle)
 
 def _npt_against_oracle(so, c_oracle, boxes, nlat, nw, temperature=200.0, max_trans_ang=1.1, pressure_atm=1.0, vol_prob=0.1,
                         dv_max_ang=0.924, seed=11, nmoves=96, mu_range=400.0, weight0=None, samplerun=False, always_switch=True,
-                        wl_factor=0.05, eta_interp=True, leshift=False, minu=False, log_unbiased_norm=0.0, swetnam_alpha=None):
+                        wl_factor=0.05, eta_interp=True, leshift=False, minu=False, log_unbiased_norm=0.0, swetnam_alpha=None,
+                        dd=None):
     """`nw` walkers of `nlat` lattices each (boxes: nlat * nw (h, xyz) pairs): two launches of `nmoves` moves with volume moves on
     the device (vol_prob = 0: translations only, NVT acceptance), lists rebuilt in between after mw_sweep_sync_cells, against
     mwo_sweep_full walker by walker.  Two lattices: the run options of mc_cycle (weights, sample run, leshift, MINU, ...)."""
@@ -316,6 +317,19 @@ def _npt_against_oracle(so, c_oracle, boxes, nlat, nw, temperature=200.0, max_tr
                 farm.leshift(ref_h)
             if minu:
                 farm.minu(True)
+            wins = None
+            if dd is not None:                                       # dd = (windows in all, overlap, eq_mc_cycles): walker w = window w mod size
+                wins = [grid.window(w % dd[0], dd[0], dd[1]) for w in range(nw)]
+                farm.set_windows(wins)
+                farm.dd(True, dd[2])
+                wrow = np.tile(weight0, (nw, 1))                     # mc_moves.F90:808-812: only the window's part of the weights
+                for k, w_ in enumerate(wins):
+                    wrow[k, :w_["start_bin"] - 1] = 0.0
+                    wrow[k, w_["end_bin"]:] = 0.0
+                farm.set_tables_range(1, weight=wrow)
+                farm.set_factors(wl_factor=np.full(nw, wl_factor))
+                farm.options(record=True, samplerun=samplerun, always_switch=always_switch, npt=npt, wl_factor=0.0,
+                             log_unbiased_norm=log_unbiased_norm)      # (per-walker increments, as farm.run's 'dd' branch)
             if swetnam_alpha is not None:                            # (as farm.run: every walker its own increment, starting at wl_factor)
                 farm.swetnam(True, swetnam_alpha, wl_factor)
                 farm.set_factors(wl_factor=np.full(nw, wl_factor))
@@ -348,20 +362,31 @@ def _npt_against_oracle(so, c_oracle, boxes, nlat, nw, temperature=200.0, max_tr
                 st.model_energy[:] = e0[nlat * w:nlat * w + nlat]
                 st.ls_mu = mus[w]
                 wt, hi, uh = weight0.copy(), np.zeros(101), np.zeros(101)
+                go = grid
+                if dd is not None:
+                    go = grid.restricted(wins[w])
+                    wt[:wins[w]["start_bin"] - 1] = 0.0
+                    wt[wins[w]["end_bin"]:] = 0.0
+                    so.set_dd(True, dd[2], False)
                 if swetnam_alpha is not None:
                     so.set_swetnam(True, swetnam_alpha, wl_factor, -mu_range, mu_range, 0.0)
                 kw = dict(record=nlat == 2, samplerun=samplerun and nlat == 2, always_switch=always_switch and nlat == 2, npt=npt,
                           wl_factor=wl_factor, pressure=p_au, eta_interp=eta_interp, log_unbiased_norm=log_unbiased_norm)
-                la = so.full(st, nmoves, seed, w, 0, transP, dvm, farm.beta, farm.max_trans, grid, wt, hi, uh, **kw)
+                la = so.full(st, nmoves, seed, w, 0, transP, dvm, farm.beta, farm.max_trans, go, wt, hi, uh, **kw)
                 st.rebuild_lists(c_oracle)
-                lb = so.full(st, nmoves, seed, w, nmoves, transP, dvm, farm.beta, farm.max_trans, grid, wt, hi, uh, **kw)
-                refs.append((st, wt, hi, uh, np.concatenate([la, lb]), so.get_swetnam() if swetnam_alpha is not None else None))
+                lb = so.full(st, nmoves, seed, w, nmoves, transP, dvm, farm.beta, farm.max_trans, go, wt, hi, uh, **kw)
+                refs.append((st, wt, hi, uh, np.concatenate([la, lb]), so.get_swetnam() if swetnam_alpha is not None else None,
+                             so.get_dd() if dd is not None else None))
         finally:
             so.set_leshift(0.0, 0.0)
             so.set_minu(False)
             so.set_swetnam(False)
+            so.set_dd(False)
         for w in range(nw):
-            st, wt, hi, uh, ref, swet = refs[w]
+            st, wt, hi, uh, ref, swet, ddst = refs[w]
+            if ddst is not None:                                     # walker_in_window, and "not all walkers have reached their window"
+                assert bool(farm.factors(w + 1, 1)[2][0]) == ddst[0]
+                assert (em.L.mw_sweep_check_flags(w + 1, 1) != 0) == ddst[1]
             if swet is not None:                                     # Swetnam's visit total and the increment it led to
                 f, sh, _ = farm.factors(w + 1, 1)
                 assert sh[0] == swet[0] and f[0] == pytest.approx(swet[1], rel=1e-9, abs=1e-12)
@@ -461,6 +486,30 @@ def test_driver_run_options_on_random_pairs(so, c_oracle, seed):
                         eta_interp=bool(rng.random() < 0.8), leshift=bool(rng.random() < 0.4), minu=bool(rng.random() < 0.3),
                         log_unbiased_norm=float(rng.uniform(0.0, 5.0)) if samplerun else 0.0,
                         swetnam_alpha=float(10.0 ** rng.uniform(-3.0, 0.0)) if (not samplerun and rng.random() < 0.3) else None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_driver_window_decomposition_on_random_pairs(so, c_oracle, seed):
+    """parallel_strategy = 'dd' in the driver on its own (mc_moves.F90:181-210,243-248,659-709): each walker confined to one of 2-5
+    windows of the order-parameter range (which its start may or may not lie in), an equilibration period of 0-3 cycles during which
+    a walker outside its window carries no weight and attempts no switch, the flag for one still outside at its end."""
+    from mc_water_ls_mw_amd import lattice as lat
+    rng = np.random.default_rng(7300 + seed)
+    z1, z2 = load_golden("ic48"), load_golden("ih48")
+    scale = float(rng.uniform(0.95, 1.03))
+    boxes, nw = [], 3
+    for w in range(nw):
+        for l, z in enumerate((z1, z2)):
+            boxes.append((z["h"] * scale, lat.thermalise(z["xyz"], float(rng.uniform(0.02, 0.1)), 600 + 10 * w + l) * scale))
+    mu_range = float(rng.choice([60.0, 150.0, 400.0]))
+    weight0 = float(rng.uniform(0.0, 10.0)) * rng.random(101)
+    samplerun, npt = bool(rng.random() < 0.3), bool(rng.random() < 0.5)
+    _npt_against_oracle(so, c_oracle, boxes, 2, nw, temperature=float(rng.uniform(150.0, 300.0)), max_trans_ang=float(rng.uniform(0.3, 1.1)),
+                        pressure_atm=1.0, vol_prob=float(rng.uniform(0.05, 0.2)) if npt else 0.0, dv_max_ang=float(rng.uniform(0.2, 0.9)),
+                        seed=300 + seed, nmoves=80, mu_range=mu_range, weight0=weight0, samplerun=samplerun, always_switch=True,
+                        wl_factor=0.0 if samplerun else float(rng.uniform(0.005, 0.3)), leshift=bool(rng.random() < 0.6),
+                        dd=(int(rng.integers(2, 6)), int(rng.integers(1, 4)), int(rng.integers(0, 4))))
 
 
 @pytest.mark.gpu

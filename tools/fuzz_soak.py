@@ -31,13 +31,15 @@ bad, skipped = [], 0
 for seed in range(first, first + count):
     for name in ("test_random_systems_follow_the_oracle", "test_random_systems_through_the_monte_carlo_driver",
                  "test_npt_driver_on_random_lattice_pairs", "test_driver_run_options_on_random_pairs",
-                 "test_lookahead_with_random_run_options"):
+                 "test_lookahead_with_random_run_options", "test_driver_window_decomposition_on_random_pairs"):
         try:
             if name.startswith("test_npt"):
                 ts.test_npt_driver_on_random_lattice_pairs(so, c, seed)          # (volume moves on random Ic / Ih pairs)
             elif name.startswith("test_lookahead"):
                 ts.test_lookahead_with_random_run_options(seed, _Env)            # (look-ahead 2 / 4 = the sequential chain)
                 os.environ.pop("MW_SWEEP_AHEAD", None)
+            elif name.startswith("test_driver_window"):
+                ts.test_driver_window_decomposition_on_random_pairs(so, c, seed)  # ('dd' windows, equilibration period, its flag)
             elif name.startswith("test_driver"):
                 ts.test_driver_run_options_on_random_pairs(so, c, seed)          # (the run options of mc_cycle in random combination)
             else:
