@@ -42,16 +42,32 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
     int cnt = 0, cin_ = 0, bnd_ = 0;       // cin_: entries already inside the energy cutoff, bnd_: any non-central image
                                            // (both sort keys of k_list_order)
 
+    // The image vectors are wave-uniform: nine at a time arrive in ONE batch of scalar loads (27 is what every cell wider than
+    // the cutoff has).  Loaded one by one inside the test loop -- a scalar load and a wait per image, which no unrolling moved
+    // across the loop's branches -- the ~200 cycles per test were the load's latency: 116 us for ONE 48-molecule box.
+    constexpr int kIvBatch = 9;
     for (int j = 0; j < N; ++j) {                                           // :525
         const double vx = P[3 * j] - xi, vy = P[3 * j + 1] - yi, vz = P[3 * j + 2] - zi;   // :529
-        for (int k = 0; k < niv; ++k) {                                     // :531
-            const double tx = vx + IV[3 * k], ty = vy + IV[3 * k + 1], tz = vz + IV[3 * k + 2];   // :534
-            const double r2 = tx * tx + ty * ty + tz * tz;                  // :535
-            if (r2 < kRnSq && !(k == 0 && j == i)) {                        // :532,537
-                if (active && cnt < S) LM[cnt] = pack_entry(j, k);
-                ++cnt;
-                cin_ += r2 < kRcSq ? 1 : 0;
-                bnd_ |= k != 0 ? 1 : 0;
+        for (int k0 = 0; k0 < niv; k0 += kIvBatch) {                        // :531
+            double iv[kIvBatch][3];
+#pragma unroll
+            for (int u = 0; u < kIvBatch; ++u) {
+                const int kk = k0 + u < niv ? k0 + u : niv - 1;             // (uniform; a slot past the table is not tested)
+                iv[u][0] = IV[3 * kk]; iv[u][1] = IV[3 * kk + 1]; iv[u][2] = IV[3 * kk + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < kIvBatch; ++u) {
+                const int k = k0 + u;
+                if (k < niv) {                                              // (uniform)
+                    const double tx = vx + iv[u][0], ty = vy + iv[u][1], tz = vz + iv[u][2];   // :534
+                    const double r2 = tx * tx + ty * ty + tz * tz;          // :535
+                    if (r2 < kRnSq && !(k == 0 && j == i)) {                // :532,537
+                        if (active && cnt < S) LM[cnt] = pack_entry(j, k);
+                        ++cnt;
+                        cin_ += r2 < kRcSq ? 1 : 0;
+                        bnd_ |= k != 0 ? 1 : 0;
+                    }
+                }
             }
         }
     }
