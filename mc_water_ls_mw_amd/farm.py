@@ -158,8 +158,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             # file, and then R ranks come back from their first synchronisation with R x the table.  A farm has no such file
             # to fall back on: the baseline is the checkpointed table itself (exactly the synchronised table when checkpoints
             # fall on synchronisation cycles, as they do with the reference's default intervals).
-            if not dd:
-                comms.set_weights(np.asarray(chk[0]["weight"], dtype=np.float64))
+            if not dd:                                             # (rank 0's, for everybody: the delta scheme needs ONE baseline)
+                comms.set_weights(comms._bcast(np.asarray(chk[0]["weight"], dtype=np.float64)))
             if samplerun:
                 comms.set_uhistogram(chk[0]["unbiased_hist"])
             step_t0 = np.array([c["mc_max_trans"] for c in chk]); step_v0 = np.array([c["mc_dv_max"] for c in chk])
@@ -361,6 +361,10 @@ def main():
     ap.add_argument("--no-thermalise", action="store_true", help="every walker starts from the input configuration itself (as the ranks of the reference do)")
     ap.add_argument("--eq-adjust", action="store_true", help="eq_adjust_mc: tune the step sizes during equilibration")
     ap.add_argument("--monitor", type=int, default=1000, help="monitor_int")
+    ap.add_argument("--temperature", type=float, default=200.0, help="Kelvin")
+    ap.add_argument("--pressure", type=float, default=1.0, help="atmospheres (with --npt)")
+    ap.add_argument("--mu-range", type=float, default=400.0, help="the order parameter runs over -mu_range .. +mu_range (101 bins)")
+    ap.add_argument("--list-update", type=int, default=10, help="list_update_int: cycles between Verlet-list rebuilds")
     ap.add_argument("--samplerun", action="store_true", help="fixed weights, unbiased histogram (examples/ice1_sample); needs --weights")
     ap.add_argument("--weights", default=None, help="eta_weights.dat: the starting weights (mc_moves.F90:738-770)")
     ap.add_argument("--delta-g", type=int, default=100000, help="deltaG_int: cycles between free-energy estimates of a sample run")
@@ -395,6 +399,7 @@ def main():
             raise SystemExit(f"{args.weights}: {len(weight)} bins, this farm runs the examples' 101")
     res = run([z1["h"], z2["h"]], [z1["xyz"], z2["xyz"]], args.walkers, args.cycles, mpi_sync_int=args.sync,
               samplerun=args.samplerun, weight=weight, file_wl_factor=file_factor, deltaG_int=args.delta_g,
+              temperature=args.temperature, pressure_atm=args.pressure, mu_range=args.mu_range, list_update_int=args.list_update,
               device=local, comms=comms, rank=rank, npt=args.npt, wl_factor=args.wl_factor, flat_chk_int=args.flat_chk,
               wl_schedule=args.wl_schedule, wl_flattol=args.wl_flattol, wl_minhist=args.wl_minhist,
               wl_useinvt=args.wl_useinvt, outdir=args.outdir, regauge=args.regauge, parallel_strategy=args.strategy,
