@@ -92,3 +92,16 @@ def test_every_rank_stops_when_one_rank_has_walkers_outside_their_windows():
     # (here both ranks hold an outer window: each reports its own walkers, after the two have agreed to stop)
     assert out.stderr.count("MwError: Error : Not all walkers have reached their designated window after 3 MC cycles") == 2
     assert "join_eta" not in out.stderr                            # nobody went on to the windows' all-gather
+
+
+def test_two_rank_restart_continues_the_synchronised_run(tmp_path):
+    """Two ranks x four walkers, tables synchronised every 10 cycles, checkpoints at cycle 20: the restarted second half ends
+    where the uninterrupted 40 cycles end (the checkpointed table is every rank's baseline of the delta exchange -- left at zero,
+    the first synchronisation after a restart returned 8 x the weights)."""
+    common = ["-m", "mc_water_ls_mw_amd.farm", "--walkers", "4", "--sync", "10", "--backend", "gloo", "--share-device"]
+    full = _launch(common + ["--cycles", "40"])
+    _launch(common + ["--cycles", "20", "--chkpt", "20", "--outdir", str(tmp_path)])
+    rest = _launch(common + ["--cycles", "20", "--restart", "--outdir", str(tmp_path)])
+    assert rest["ranks_agree"] is True and full["ranks_agree"] is True
+    assert rest["weight_max"] == pytest.approx(full["weight_max"], rel=1e-9) and full["weight_max"] > 0
+    assert rest["histogram_total"] == pytest.approx(full["histogram_total"], rel=1e-12)
