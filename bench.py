@@ -187,7 +187,7 @@ def kernel_roofline(name, alg_bytes, avg_ms, units, counters, copy_gbs):
          "hbm_traffic_frac": None}
     c = counters.get(name)
     if c:
-        cyc_grbm = c["GRBM_GUI_ACTIVE"] / 8.0                   # the counter sums the 8 XCDs; over-counts sub-0.3-ms launches
+        cyc_grbm = c["GRBM_GUI_ACTIVE"] / float(counters.get("xcds", 8))   # the counter sums the XCDs; over-counts sub-0.3-ms launches
         cpu_ = counters.get("cycles_per_us")                    # shader clock during the counter passes (from the long kernel)
         cyc_valu = c["dur_us_sq1"] * cpu_ if cpu_ and "dur_us_sq1" in c else cyc_grbm     # the launch's cycles in the pass that
         cyc_lds = c["dur_us_sq2"] * cpu_ if cpu_ and "dur_us_sq2" in c else cyc_grbm      # counted VALU / LDS activity

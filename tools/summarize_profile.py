@@ -79,8 +79,22 @@ for k, cs in sorted(pmc.items()):
 # of a kernel in a pass = its duration in that pass x this clock: GRBM_GUI_ACTIVE itself over-counts short kernels (a
 # persistent k_model_energy launch reads 25 % more "cycles" than its duration allows at the 2.4 GHz ceiling).
 mv = counters.get("k_move_energy", {})
+
+
+def gpu_agent(src_dir):
+    """XCDs, CUs and SIMDs of the profiled GPU from rocprofv3's agent table (8 / 256 / 1024 on an MI355X)."""
+    for root_, _, files in os.walk(src_dir):
+        for f in files:
+            if f.endswith("agent_info.csv"):
+                for r in csv.DictReader(open(os.path.join(root_, f))):
+                    if r.get("Agent_Type", r.get("Type", "")).upper().find("GPU") >= 0 and int(r.get("Cu_Count", 0) or 0) > 0:
+                        return int(r.get("Num_Xcc", 8) or 8), int(r["Cu_Count"]), int(r.get("Simd_Count", 0) or 0)
+    return 8, 256, 1024
+
+
+counters["xcds"], counters["compute_units"], counters["simds"] = gpu_agent(src)
 if "GRBM_GUI_ACTIVE" in mv and "dur_us_sq2" in mv:
-    counters["cycles_per_us"] = mv["GRBM_GUI_ACTIVE"] / 8.0 / mv["dur_us_sq2"]
+    counters["cycles_per_us"] = mv["GRBM_GUI_ACTIVE"] / counters["xcds"] / mv["dur_us_sq2"]
 json.dump(counters, open(os.path.join(dst, "counters.json"), "w"), indent=1)
 open(os.path.join(dst, f"{tag}_pmc_counters.txt"), "w").write("\n".join(sq_lines) + "\n")
 print("\n".join(lines[:12]))

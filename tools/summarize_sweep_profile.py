@@ -17,7 +17,20 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"sweepprof_{tag}")
 dst = os.path.join(root, "profiles")
-NSIMD = 1024
+
+
+def gpu_agent(src_dir):
+    """XCDs, CUs and SIMDs of the profiled GPU from rocprofv3's agent table (8 / 256 / 1024 on an MI355X)."""
+    for root_, _, files in os.walk(src_dir):
+        for f in files:
+            if f.endswith("agent_info.csv"):
+                for r in csv.DictReader(open(os.path.join(root_, f))):
+                    if r.get("Agent_Type", r.get("Type", "")).upper().find("GPU") >= 0 and int(r.get("Cu_Count", 0) or 0) > 0:
+                        return int(r.get("Num_Xcc", 8) or 8), int(r["Cu_Count"]), int(r.get("Simd_Count", 0) or 1024)
+    return 8, 256, 1024
+
+
+NXCD, NCU, NSIMD = gpu_agent(src)
 
 
 def longest_sweep_dispatch(path):
@@ -78,12 +91,12 @@ for case in sorted(os.listdir(src)):
         der["salu_insts_per_move"] = ctr.get("SQ_INSTS_SALU", 0) / moves
         der["lds_insts_per_move"] = ctr.get("SQ_INSTS_LDS", 0) / moves
     if "GRBM_GUI_ACTIVE" in ctr and "dur_us_sq2" in ctr:
-        clk = ctr["GRBM_GUI_ACTIVE"] / 8.0 / ctr["dur_us_sq2"]          # shader cycles per us (long launch: reads true)
+        clk = ctr["GRBM_GUI_ACTIVE"] / NXCD / ctr["dur_us_sq2"]          # shader cycles per us (long launch: reads true)
         der["clock_MHz"] = clk
         if "SQ_ACTIVE_INST_VALU" in ctr:
             der["valu_busy"] = ctr["SQ_ACTIVE_INST_VALU"] * 4.0 / (NSIMD * ctr["dur_us_sq1"] * clk)
         if "SQ_LDS_IDX_ACTIVE" in ctr:
-            der["lds_busy"] = ctr["SQ_LDS_IDX_ACTIVE"] / (256 * ctr["dur_us_sq2"] * clk)
+            der["lds_busy"] = ctr["SQ_LDS_IDX_ACTIVE"] / (NCU * ctr["dur_us_sq2"] * clk)
             der["lds_bank_conflict_share"] = ctr["SQ_LDS_BANK_CONFLICT"] / max(ctr["SQ_LDS_IDX_ACTIVE"], 1.0)
         if "SQ_WAVE_CYCLES" in ctr:
             der["waves_per_simd_avg"] = ctr["SQ_WAVE_CYCLES"] * 4.0 / (NSIMD * ctr["dur_us_sq1"] * clk)
