@@ -73,6 +73,27 @@ if only in (None, "npt48"):
 if only in ("farm48",):     # the replica farm's own settings (farm.py defaults): +-400 window, so walkers do switch lattice
     run("pair48 x 8192 walkers, WL update + switch per move, farm window", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 8192, 480, out,
         wl=True, sigma=0.05, mu_range=400.0)
+# a handful of the reference's own walkers (it runs one per MPI rank): the speed of ONE chain, look-ahead inside it
+if only in ("one48",):
+    run("pair48 x 1 walker, WL update + switch per move", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 1, 4800, out,
+        wl=True, sigma=0.05, mu_range=400.0)
+if only in ("one48npt",):
+    run("pair48 x 1 walker, NPT, WL update + switch per move", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 1, 4800, out,
+        wl=True, npt=True, sigma=0.05, mu_range=400.0)
+if only in ("eight48npt",):
+    run("pair48 x 8 walkers, NPT, WL update + switch per move", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 8, 4800, out,
+        wl=True, npt=True, sigma=0.05, mu_range=400.0)
+if only in ("few48npt",):
+    run("pair48 x 256 walkers, NPT, WL update + switch per move", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 256, 2400, out,
+        wl=True, npt=True, sigma=0.05, mu_range=400.0)
+if only is not None and only.startswith("n48npt_"):       # n48npt_<walkers>: where look-ahead stops paying for small walkers
+    nwalk = int(only.split("_")[1])
+    run(f"pair48 x {nwalk} walkers, NPT, WL update + switch per move", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, nwalk, 1200, out,
+        wl=True, npt=True, sigma=0.05, mu_range=400.0)
+if only is not None and only.startswith("n48wl_"):
+    nwalk = int(only.split("_")[1])
+    run(f"pair48 x {nwalk} walkers, WL update + switch per move", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, nwalk, 1200, out,
+        wl=True, sigma=0.05, mu_range=400.0)
 ic1536, ih1536 = g("ic1536"), g("ih1536")
 if only in (None, "pair1536"):
     run("pair1536 x 2048 walkers", [(ic1536["h"], ic1536["xyz"]), (ih1536["h"], ih1536["xyz"])], 2, 2048, 300, out)
