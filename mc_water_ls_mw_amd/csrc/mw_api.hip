@@ -551,8 +551,14 @@ static const void* sweep_kernel(int nlat, int residency, bool withvol, int spec)
          {MW_SWEEP_K(1, 4, true, true, false), MW_SWEEP_K(1, 4, true, true, true)}},         // chains, and their speed is the chain's
         {{MW_SWEEP_K(2, 2, true, true, false), MW_SWEEP_K(2, 2, true, true, true)},
          {MW_SWEEP_K(2, 4, true, true, false), MW_SWEEP_K(2, 4, true, true, true)}}};
+    static const void* const ahead_pos[2][2][2] = {   // ... and for the sizes in between (positions in LDS, rows in global memory)
+        {{MW_SWEEP_K(1, 2, true, false, false), MW_SWEEP_K(1, 2, true, false, true)},
+         {MW_SWEEP_K(1, 4, true, false, false), MW_SWEEP_K(1, 4, true, false, true)}},
+        {{MW_SWEEP_K(2, 2, true, false, false), MW_SWEEP_K(2, 2, true, false, true)},
+         {MW_SWEEP_K(2, 4, true, false, false), MW_SWEEP_K(2, 4, true, false, true)}}};
 #undef MW_SWEEP_K
     if (spec > 1 && residency == 0) return ahead[nlat - 1][spec == 4 ? 1 : 0][withvol ? 1 : 0];
+    if (spec > 1 && residency == 1) return ahead_pos[nlat - 1][spec == 4 ? 1 : 0][withvol ? 1 : 0];
     if (spec > 1 && residency == 2) return ahead_lds[nlat - 1][spec == 4 ? 1 : 0][withvol ? 1 : 0];
     return tab[nlat - 1][residency][withvol ? 1 : 0];
 }
@@ -738,8 +744,8 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
     for (int v = 0; v < 12; ++v)   // the sweep driver's dynamic LDS (image vectors of small or sheared cells, staged positions and rows) can pass 64 KiB
         HIPCHK(hipFuncSetAttribute(sweep_kernel(1 + (v & 1), (v >> 1) % 3, v >= 6, 1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
-    for (int v = 0; v < 16; ++v)
-        HIPCHK(hipFuncSetAttribute(sweep_kernel(1 + (v & 1), (v & 8) ? 2 : 0, (v & 2) != 0, (v & 4) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+    for (int v = 0; v < 24; ++v)
+        HIPCHK(hipFuncSetAttribute(sweep_kernel(1 + (v & 1), v >> 3, (v & 2) != 0, (v & 4) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
     g.live = true;
     return 0;
 }
@@ -2016,9 +2022,9 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
     // Look-ahead: as many moves at once as it takes to put ~4 wavefronts on every SIMD, at most 4; MW_SWEEP_AHEAD=1|2|4 overrides.
     // For walkers in global memory, and for walkers entirely in LDS (the reference's 48-molecule cells: a move reads most of such
     // a box, so any ACCEPTED move ends the round -- but nine moves in ten are rejected, and a handful of walkers, which is how the
-    // reference itself runs, leaves the chip to their chains).  Positions in LDS with rows in global memory: no look-ahead build.
+    // reference itself runs, leaves the chip to their chains), and for the sizes in between.
     int spec = 1;
-    if (!ldspos || ldslist) {
+    {
         // ... as long as every walker of the launch still has a place on the chip: a compute unit holds 16 wavefronts of <= 128
         // VGPRs (12 of the one build that needs more), i.e. 16 / (lattices x look-ahead) workgroups.  Measured on 48-molecule pairs
         // (tools/sweep_measurements.py n48wl_<walkers> / n48npt_<walkers>): 4 ahead wins up to 512 walkers (256 with volume moves),

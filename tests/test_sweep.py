@@ -695,8 +695,8 @@ def test_lookahead_is_the_sequential_chain(case, monkeypatch):
 def test_lookahead_with_random_run_options(seed, monkeypatch):
     """Look-ahead under the run options of mc_cycle in random combination: weights of any size, walkers inside or outside the
     order-parameter range, weight generation or sample run, switch attempts, leshift, MINU, NVT or volume moves.  On a 768-molecule
-    Ic / Ih pair (walkers in global memory, moves that do collide) and, odd seeds, on the 48-molecule pair itself (walkers entirely
-    in LDS, where a move reads most of the box: any accepted move ends the round).  2 and 4 moves in flight = the one-at-a-time
+    Ic / Ih pair (walkers in global memory, moves that do collide) and, odd seeds, on the 48-molecule pair itself and its 192-molecule replica (walkers
+    entirely / with their positions in LDS, where a move reads most of the box: any accepted move ends the round).  2 and 4 moves in flight = the one-at-a-time
     chain, bit for bit."""
     from mc_water_ls_mw_amd import lattice as lat
     from mc_water_ls_mw_amd.sweep import MuGrid
@@ -704,10 +704,11 @@ def test_lookahead_with_random_run_options(seed, monkeypatch):
     z1, z2 = load_golden("ic48"), load_golden("ih48")
     scale = float(rng.uniform(0.9, 1.04))
     small = seed % 2 == 1
+    reps = ((1, 1, 1) if seed % 4 == 1 else (1, 2, 2)) if small else (2, 2, 4)      # 48: rows in LDS too; 192: positions only
     boxes, nw = [], 2
     for w in range(nw):
         for l, z in enumerate((z1, z2)):
-            h, x = lat.replicate(z["h"], z["xyz"], (1, 1, 1) if small else (2, 2, 4))
+            h, x = lat.replicate(z["h"], z["xyz"], reps)
             boxes.append((h * scale, lat.thermalise(x, float(rng.uniform(0.03, 0.12)), 800 + 10 * w + l) * scale))
     assert small or len(boxes[0][1]) * 24 * 2 > 16 * 1024         # (768 molecules: positions stay in global memory)
     mu_range = float(rng.choice([300.0, 3000.0, 20000.0]))
