@@ -77,6 +77,10 @@ if only in ("farm48",):     # the replica farm's own settings (farm.py defaults)
 if only in ("one48",):
     run("pair48 x 1 walker, WL update + switch per move", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 1, 4800, out,
         wl=True, sigma=0.05, mu_range=400.0)
+if only in ("one48plain",):
+    run("pair48 x 1 walker", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 1, 4800, out, sigma=0.05, mu_range=400.0)
+if only in ("one48single",):
+    run("ic48 x 1 walker (one lattice)", [(ic48["h"], ic48["xyz"])], 1, 1, 4800, out, sigma=0.05)
 if only in ("one48npt",):
     run("pair48 x 1 walker, NPT, WL update + switch per move", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 1, 4800, out,
         wl=True, npt=True, sigma=0.05, mu_range=400.0)
