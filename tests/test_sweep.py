@@ -636,7 +636,7 @@ def test_random_single_box_walkers_follow_the_oracle(seed, so):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["ih1000", "pair1536_wl", "ih1000_npt"])
+@pytest.mark.parametrize("case", ["ih1000", "pair1536_wl", "ih1000_npt", "ih64", "ih64_npt", "ih288", "ih288_npt"])
 def test_lookahead_is_the_sequential_chain(case, monkeypatch):
     """Look-ahead (several moves of a walker evaluated at once, decided in order; mw_sweep.hip.h) changes nothing: the move
     log, the final positions and the tables of a run with 2 or 4 moves in flight are BITWISE those of the one-move-at-a-time
@@ -647,8 +647,9 @@ def test_lookahead_is_the_sequential_chain(case, monkeypatch):
 
     def run(ahead):
         monkeypatch.setenv("MW_SWEEP_AHEAD", str(ahead))
-        if case.startswith("ih1000"):
-            h, x0 = lat.ice_box("ih", (5, 5, 5), 0.0)
+        if case.startswith("ih"):                       # one lattice: 1000 molecules (global memory), 288 (positions in LDS), 64 (rows too)
+            reps = {"ih1000": (5, 5, 5), "ih64": (2, 2, 2), "ih288": (3, 4, 3)}[case.split("_")[0]]
+            h, x0 = lat.ice_box("ih", reps, 0.0)
             boxes = [(h, lat.thermalise(x0, 0.12, 300 + w)) for w in range(3)]
             em, farm = _farm(boxes, 1, 230.0, 1.1)
             nlat = 1
@@ -662,7 +663,7 @@ def test_lookahead_is_the_sequential_chain(case, monkeypatch):
             farm.options(record=True, samplerun=False, always_switch=True, npt=False, wl_factor=0.05)
             nlat = 2
         try:
-            if case == "ih1000_npt":
+            if case.endswith("_npt"):
                 em._chk(em.L.mw_sweep_options(0, 1, 0, 1, __import__("ctypes").c_double(1.0), __import__("ctypes").c_double(0.0),
                                               __import__("ctypes").c_double(0.0), __import__("ctypes").c_double(1.0 / 2.90363081e8)))
                 farm.moves(trans_prob=0.5, vol_prob=0.05, dv_max_ang=0.3)
