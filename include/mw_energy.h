@@ -257,6 +257,10 @@ int mw_sweep_translation(int first_walker, int count, int nmoves, unsigned long 
                          unsigned long long move0, double *log);
 int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigned long long seed,
                                 unsigned long long move0, int want_log);
+/* What the last launch of the driver looked like (any pointer may be NULL): lattices per walker, moves in flight per walker
+ * (look-ahead: 1, 2 or 4), where a walker's data lived (0: global memory, 1: positions in LDS, 2: positions and list rows in
+ * LDS), whether the build carried volume moves, dynamic LDS per workgroup, and the LDS row stride (0 when rows stay global). */
+int mw_sweep_last_launch(int *nlat, int *ahead, int *residency, int *volume_moves, int *lds_bytes, int *row_stride);
 /* Dynamic LDS (bytes) of one walker's workgroup when its positions and list rows live in LDS (nwater <= 64), for list
  * rows of `row_stride` entries -- host arithmetic only, no device needed.  Eight walkers share a compute unit while this
  * plus the kernel's static LDS stays within 20480 bytes; the launch picks row_stride = the longest row of any box,

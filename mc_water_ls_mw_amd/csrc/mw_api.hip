@@ -90,6 +90,7 @@ struct Ctx {
     int cstride = 0;
     std::vector<mw::GridDesc> h_grid;
     std::vector<int> h_usegrid;
+    int last_sweep[6] = {0, 0, 0, 0, 0, 0};   // what the last launch of the driver was: lattices, look-ahead, residency, volume moves, LDS bytes, row stride
     bool grid_on_device = false;   // some box of this context has (had) a cell grid: descriptors travel with mw_sweep_sync_cells
     bool force_brute = false;
     double* d_partial = nullptr;
@@ -2052,6 +2053,18 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
                     &w0, &dlog, &rstride, &wwin, &g.d_wfac, &g.d_wsum, &g.d_winflag, &wstep};
     HIPCHK(hipLaunchKernel(kern, dim3(count), dim3(64 * L * spec), args, lay.total, g.stream));
     HIPCHK(hipGetLastError());
+    g.last_sweep[0] = L; g.last_sweep[1] = spec; g.last_sweep[2] = ldslist ? 2 : (ldspos ? 1 : 0); g.last_sweep[3] = withvol ? 1 : 0;
+    g.last_sweep[4] = (int)lay.total; g.last_sweep[5] = ldslist ? rstride : 0;
+    return 0;
+}
+
+int mw_sweep_last_launch(int* nlat, int* ahead, int* residency, int* volume_moves, int* lds_bytes, int* row_stride)
+{
+    MW_LOCK;
+    if (check_live()) return 1;
+    if (g.last_sweep[0] == 0) return fail("mw_sweep_last_launch: no launch of the driver yet");
+    int* out[6] = {nlat, ahead, residency, volume_moves, lds_bytes, row_stride};
+    for (int k = 0; k < 6; ++k) if (out[k]) *out[k] = g.last_sweep[k];
     return 0;
 }
 

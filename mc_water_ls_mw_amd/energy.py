@@ -46,7 +46,7 @@ ABI_SYMBOLS = (
     "mw_model_energy_launch", "mw_step_launch", "mw_model_energy_fetch", "mw_build_neighbours_launch", "mw_sync",
     "mw_timer_start", "mw_timer_stop", "mw_timer_elapsed_ms", "mw_device_info",
     "mw_sweep_configure", "mw_set_model_energy", "mw_sweep_set_state", "mw_sweep_set_states_range", "mw_sweep_get_state",
-    "mw_sweep_translation", "mw_sweep_translation_launch", "mw_sweep_lds_bytes",
+    "mw_sweep_translation", "mw_sweep_translation_launch", "mw_sweep_lds_bytes", "mw_sweep_last_launch",
     "mw_sweep_options", "mw_sweep_get_tables", "mw_sweep_set_tables", "mw_sweep_get_switches", "mw_sweep_get_shifts_range",
     "mw_sweep_reduce_tables", "mw_sweep_broadcast_tables",
     "mw_sweep_get_tables_range", "mw_sweep_set_tables_range",

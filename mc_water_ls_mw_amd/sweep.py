@@ -253,6 +253,13 @@ class WalkerFarm:
         mc_moves.F90:187-201)."""
         self.em._chk(self.L.mw_sweep_check_flags(1, self.nwalkers))
 
+    def last_launch(self):
+        """What the last launch looked like: dict(nlat, ahead, residency, volume_moves, lds_bytes, row_stride) -- residency 0: a
+        walker's data in global memory, 1: positions in LDS, 2: positions and list rows in LDS; ahead: moves of a chain in flight."""
+        v = [ctypes.c_int(0) for _ in range(6)]
+        self.em._chk(self.L.mw_sweep_last_launch(*[ctypes.byref(x) for x in v]))
+        return dict(zip(("nlat", "ahead", "residency", "volume_moves", "lds_bytes", "row_stride"), (x.value for x in v)))
+
     def sync_cells(self):
         """Bring the host's hmatrix / volume / image vectors / grid descriptors up to date after device-side
         volume moves (call before rebuilding neighbour lists)."""

@@ -801,3 +801,53 @@ def test_lookahead_on_awkward_boxes(kind, so, monkeypatch):
     for w in range(2):
         ref = so.sweep(nmoves, 12, w, 0, [boxes[w][0]], [boxes[w][1]], farm.beta, farm.max_trans, maxneigh=64)
         _compare(log1[w], ref, st1[w], [pos1[w]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nlat", [1, 2])
+@pytest.mark.parametrize("residency", [0, 1, 2])
+@pytest.mark.parametrize("npt", [False, True])
+def test_every_build_of_the_driver_runs_the_same_chain(nlat, residency, npt, monkeypatch):
+    """The 36 instantiations of k_sweep -- lattices x where a walker's data live x with / without volume moves x 1, 2 or 4 moves in
+    flight -- each actually launched (mw_sweep_last_launch says which build a launch took) and, for the same walkers, 2 and 4 moves
+    in flight reproduce the one-move-at-a-time chain bit for bit."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.energy import load_boxes
+    from mc_water_ls_mw_amd.sweep import MuGrid, WalkerFarm
+    z1, z2 = load_golden("ic48"), load_golden("ih48")
+    reps = {0: (2, 2, 4), 1: (1, 2, 2), 2: (1, 1, 1)}[residency]          # 768 / 192 / 48 molecules per lattice
+    boxes, nw = [], 2
+    for w in range(nw):
+        for l, z in enumerate((z1, z2)[:nlat]):
+            h, x = lat.replicate(z["h"], z["xyz"], reps)
+            boxes.append((h, lat.thermalise(x, 0.08, 40 + 10 * w + l)))
+    grid = MuGrid(101, -3000.0, 3000.0) if nlat == 2 else None
+
+    def run(ahead):
+        monkeypatch.setenv("MW_SWEEP_AHEAD", str(ahead))
+        em = load_boxes([b[0] for b in boxes], [b[1] for b in boxes])
+        farm = WalkerFarm(em, nlat, 220.0, 1.0, grid=grid, pressure_au=1.0 / 2.90363081e8)
+        try:
+            if nlat == 2:
+                farm.options(record=True, samplerun=False, always_switch=True, npt=npt, wl_factor=0.05)
+            elif npt:
+                em._chk(em.L.mw_sweep_options(0, 1, 0, 1, __import__("ctypes").c_double(1.0), __import__("ctypes").c_double(0.0),
+                                              __import__("ctypes").c_double(0.0), __import__("ctypes").c_double(1.0 / 2.90363081e8)))
+            if npt:
+                farm.moves(trans_prob=0.5, vol_prob=0.08, dv_max_ang=0.4)
+            for w in range(1, nw + 1):
+                farm.set_state(w, 1, farm.initial_mu(w))
+            log = farm.sweep(200, seed=5, move0=0, log=True)
+            what = farm.last_launch()
+            assert (what["nlat"], what["ahead"], what["residency"], what["volume_moves"]) == (nlat, ahead, residency, int(npt)), what
+            assert (what["row_stride"] > 0) == (residency == 2)
+            return log, [farm.positions(b) for b in range(1, len(boxes) + 1)], [farm.state(w) for w in range(1, nw + 1)]
+        finally:
+            em.energy_deinit()
+
+    ref = run(1)
+    assert 5 < int((ref[0][0][:, 1].astype(int) & 1).sum()) < 195
+    for ahead in (2, 4):
+        got = run(ahead)
+        assert np.array_equal(got[0], ref[0], equal_nan=True)
+        assert all(np.array_equal(a, b) for a, b in zip(got[1], ref[1])) and got[2] == ref[2]
