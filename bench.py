@@ -311,39 +311,62 @@ def self_launch(n, json_fd):
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (the environment torch.distributed.run would give
     them), relay rank 0's ONE JSON line and return the worst exit status.  Called before anything in this process has
     touched the GPU; the children are ordinary child processes (no exec from a process that holds the device)."""
+    import signal
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    # rank 0's output is drained by a thread while all ranks are watched: a rank that dies (a bad device index, an
-    # allocation that fails) would otherwise leave the others in a collective until its watchdog gives up -- the
-    # survivors are ended here instead (exactly the children started above), and the failure is reported at once
     import threading
     import time
+    # The port is held (bound, not listening) until every child exists: picking a number and closing the socket at once left a
+    # window in which another job could take it -- and the same number keys the RCCL id file.  SO_REUSEADDR lets rank 0's store
+    # bind it while this socket is still open; it is closed as soon as the children have been started.
+    sk = socket.socket()
+    sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    procs = []
+
+    def end_children():
+        """Terminate, then kill, exactly the children started here."""
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+
+    def on_term(signum, frame):                       # a SIGTERM to the parent must not leave the ranks holding their GPUs
+        raise KeyboardInterrupt
+
+    old_term = signal.signal(signal.SIGTERM, on_term)
     chunks = []
-    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-    reader.start()
-    while any(p.poll() is None for p in procs):
-        if any(p.poll() not in (None, 0) for p in procs):
-            for p in procs:
-                if p.poll() is None:
-                    p.terminate()
-            deadline = time.monotonic() + 10.0
-            for p in procs:
-                try:
-                    p.wait(timeout=max(0.1, deadline - time.monotonic()))
-                except subprocess.TimeoutExpired:
-                    p.kill()
-            break
-        time.sleep(0.1)
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # ranks above 0 print nothing on stdout by design; whatever a failing one does print there goes to stderr, not away
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr))
+        sk.close()
+        # rank 0's output is drained by a thread while all ranks are watched: a rank that dies (a bad device index, an
+        # allocation that fails) would otherwise leave the others in a collective until its watchdog gives up -- the
+        # survivors are ended here instead (exactly the children started above), and the failure is reported at once
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                end_children()
+                break
+            time.sleep(0.1)
+    except BaseException:                             # interrupted (SIGINT / SIGTERM) or failed to start a rank
+        end_children()
+        raise
+    finally:
+        sk.close()
+        signal.signal(signal.SIGTERM, old_term)
     codes = [p.wait() for p in procs]
     reader.join(timeout=10.0)
     out0 = b"".join(c for c in chunks if c)

@@ -44,6 +44,7 @@ int mw_comms_bcast(void *buf, long nbytes, int root);
 int mw_comms_sendrecv(void *buf, long nbytes, int snode, int rnode);  /* snode sends buf, rnode receives into buf */
 int mw_comms_barrier(void);
 int mw_comms_finalize(void);
+int mw_comms_abort(void);     /* failure path: drop the id file, ncclCommAbort, wait for nobody (the caller then stops) */
 int mw_comms_rank(void);
 int mw_comms_size(void);
 const char *mw_comms_last_error(void);

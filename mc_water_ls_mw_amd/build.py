@@ -43,14 +43,18 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in DEPS)
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build():
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """`out`: another file name for a variant of the library (diagnostic builds, A/B measurements with MW_HIP_LIB)."""
+    lib = out or LIB
+    if not force and out is None and not needs_build():
         return LIB
-    cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-o", LIB, *SOURCES]
+    if out is not None and not force and os.path.exists(out) and all(os.path.getmtime(p) <= os.path.getmtime(out) for p in DEPS):
+        return out
+    cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-o", lib, *SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 def build_comms(force=False, verbose=False):

@@ -175,7 +175,20 @@ struct ExclusiveGuard {
     ExclusiveGuard()
     {
         g_mu.lock();
-        if (g_depth++ == 0) { g_gate.lock(); g_epoch.fetch_add(1, std::memory_order_relaxed); if (g.srv_running) rc = server_stop(); }
+        if (g_depth++ == 0) {
+            g_gate.lock(); g_epoch.fetch_add(1, std::memory_order_relaxed);
+            if (g.srv_running) rc = server_stop();
+            // A request posted ahead (mw_local_energy_post) that the server never got to -- it left between the post and this
+            // entry point -- is CANCELLED: marked as answered, so that the server started by the next single call does not
+            // replay it and commit its stale override positions over what this entry point is about to upload.  (Its collect
+            // returns 2, "ask again", because of the epoch.)  The server is stopped: nobody else writes the reply lines.
+            if (g.live && g.h_slots)
+                for (int sl = 0; sl < g.nslots && sl < 8; ++sl)
+                    if (g.spend[sl] && reinterpret_cast<volatile unsigned long long*>(&g.h_slots[sl].rep_seq)[0] != g.spend[sl]) {
+                        reinterpret_cast<volatile unsigned long long*>(&g.h_slots[sl].rep_seq)[0] = g.spend[sl];
+                        std::atomic_thread_fence(std::memory_order_seq_cst);
+                    }
+        }
     }
     ~ExclusiveGuard()
     {
@@ -2077,6 +2090,21 @@ int mw_sweep_translation(int first_walker, int count, int nmoves, unsigned long 
     HIPCHK(hipStreamSynchronize(g.stream));
     return 0;
 }
+
+#ifdef MW_SWEEP_STAMPS
+// Diagnostic build only (tools/sweep_stamps.py): the cycle sums of walker 0's first wavefront; reset != 0 zeroes them afterwards.
+int mw_debug_sweep_stamps(unsigned long long* out, int n, int reset)
+{
+    MW_LOCK;
+    if (check_live()) return 1;
+    unsigned long long st[48];
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpyFromSymbol(st, HIP_SYMBOL(mw::g_sweep_stamps), sizeof st));
+    for (int k = 0; k < n && k < 48; ++k) out[k] = st[k];
+    if (reset) { memset(st, 0, sizeof st); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(mw::g_sweep_stamps), st, sizeof st)); }
+    return 0;
+}
+#endif
 
 int mw_sync(void)
 {

@@ -303,6 +303,7 @@ int mw_comms_barrier(void)
 
 int mw_comms_finalize(void)
 {
+    if (c.own_id_file) { unlink(c.id_file.c_str()); c.own_id_file = false; }   // also after an initialisation that failed half way
     if (!c.live) return 0;
     HIPOK(hipSetDevice(c.device));
     HIPOK(hipStreamSynchronize(c.stream));
@@ -311,8 +312,19 @@ int mw_comms_finalize(void)
     if (c.d_buf) HIPOK(hipFree(c.d_buf));
     if (c.d_out) HIPOK(hipFree(c.d_out));
     HIPOK(hipStreamDestroy(c.stream));
-    if (c.own_id_file) unlink(c.id_file.c_str());
     c = Comms{};
+    return 0;
+}
+
+// The failure path: a collective failed or a peer is gone.  Nothing here may wait for the other ranks -- no stream
+// synchronisation, no ncclCommDestroy (both can block for ever with a peer missing, and the failing rank would keep its GPU):
+// the id file goes, the communicator is aborted, and the caller stops the process.
+int mw_comms_abort(void)
+{
+    if (c.own_id_file) { unlink(c.id_file.c_str()); c.own_id_file = false; }
+    if (!c.live) return 0;
+    c.live = false;
+    (void)ncclCommAbort(c.comm);
     return 0;
 }
 

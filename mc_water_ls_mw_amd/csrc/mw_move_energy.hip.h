@@ -256,7 +256,12 @@ static_assert(sizeof(WaveScratch) % 16 == 0, "scratch records must keep 16-byte 
 // (cells at least three list radii wide along every cell vector -- every box that goes through the cell-grid builder):
 // a row entry with k == i is then the molecule itself, and the both-geometries branch and the inverse-image bookkeeping
 // behind it fall away (25 vector instructions per move).
-#ifdef MW_LAT_STAMPS      // tools/kbench built with -DMW_LAT_STAMPS only: where one wavefront's time goes (100 MHz ticks)
+#if defined(MW_SWEEP_STAMPS)   // a diagnostic build of the library only (tools/sweep_stamps.py): shader-clock cycles per stage of walker 0's
+                              // first wavefront, summed over the launch -- g_sweep_stamps[16 + k] = cycles between stamp k - 1 and stamp k
+__device__ unsigned long long g_sweep_stamps[48];
+#define MW_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x < 64) { const unsigned long long mw_t = clock64(); \
+                         if (lane == 0 && (k) > 0) g_sweep_stamps[16 + (k)] += mw_t - mw_tprev; mw_tprev = mw_t; } } while (0)
+#elif defined(MW_LAT_STAMPS)      // tools/kbench built with -DMW_LAT_STAMPS only: where one wavefront's time goes (100 MHz ticks)
 __device__ unsigned long long g_lat_stamps[16];
 #define MW_STAMP(k) do { if (lane == 0) g_lat_stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -275,6 +280,9 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
                                                  const int* oth = nullptr, unsigned* cmask = nullptr)
 {
     unsigned cm = 0u;
+#ifdef MW_SWEEP_STAMPS
+    unsigned long long mw_tprev = 0ull;
+#endif
     // ---- pass 0: imol's own row; lanes 0..31 take slot l against the OLD position, lanes 32..63 the same
     // slot against the TRIAL position, so that one rsqrt/reciprocal/exp sequence serves both evaluations.
     // `e` arrives as entry (lane & 31) of imol's row, fetched by the caller ahead of time (whatever the row

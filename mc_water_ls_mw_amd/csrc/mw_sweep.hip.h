@@ -416,6 +416,16 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
 //    not in registers: a wave-uniform double costs two VECTOR registers, and thirty of them held across the energy
 //    evaluation were the difference between two and four wavefronts per SIMD.
 // =====================================================================================
+// Diagnostic build only (-DMW_SWEEP_STAMPS, tools/sweep_stamps.py): cycles of walker 0's first wavefront per phase of a round,
+// summed over the launch into g_sweep_stamps[0..15] (mw_move_energy.hip.h holds the array and the stages of one evaluation).
+#ifdef MW_SWEEP_STAMPS
+#define MW_SW_NOW() ((blockIdx.x == 0 && wv == 0) ? (unsigned long long)clock64() : 0ull)
+#define MW_SW_ACC(k, d) do { if (blockIdx.x == 0 && wv == 0 && lane == 0) g_sweep_stamps[k] += (d); } while (0)
+#else
+#define MW_SW_NOW() 0ull
+#define MW_SW_ACC(k, d) do { } while (0)
+#endif
+
 struct WalkerCtl {
     // the launch's parameters as this walker sees them (its own window, step sizes, increment)
     double beta, pressure, dref, av_binwidth, log_unbiased_norm, transP, ref1, ref2, wl_alpha, orig_wl_factor, mu_min, mu_max;
@@ -462,7 +472,11 @@ template <int NLAT, int SPEC, bool LDSPOS, bool LDSLIST, bool WITHVOL>
 // which side of 128 it lands on depends on what else is compiled with it).  The builds that carry mc_volume keep to it too
 // -- the reference's own examples are NPT -- since the volume move's addresses are worked out inside its branch (below) and
 // its old volumes wait in LDS; only two lattices + look-ahead + volume moves (few walkers by construction) get three.
+#ifdef MW_SWEEP_WAVES_CAP     // diagnostic builds only (tools/variants.py): e.g. 5 -> 96 vector registers, a build that SPILLS, to show that one is still correct
+__global__ __launch_bounds__(64 * NLAT * SPEC) __attribute__((amdgpu_waves_per_eu(MW_SWEEP_WAVES_CAP, MW_SWEEP_WAVES_CAP)))
+#else
 __global__ __launch_bounds__(64 * NLAT * SPEC) __attribute__((amdgpu_waves_per_eu((WITHVOL && NLAT == 2 && SPEC > 1) ? 3 : 4, (WITHVOL && NLAT == 2 && SPEC > 1) ? 3 : 4)))
+#endif
 void k_sweep(double* pos, double* hmat, double* ivect,
              int* nivect, const uint32_t* __restrict__ listm, const uint32_t* __restrict__ list,
              const int* __restrict__ nn, const int* __restrict__ order, const int* __restrict__ nns,
@@ -617,6 +631,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
     auto post_move = [&](double eta_fin, double cmp_sw, double ufac, bool do_switch, double u6) -> int {
         int sw = 0;
         const int kc = C.k_cur;
+        [[maybe_unused]] const unsigned long long sw_p0 = MW_SW_NOW();
         if (C.record) {                                                           // mc_update_wl_bins, :1597-1689
             const int k = kc;
             if (k >= 1 && k <= nbins) {
@@ -688,6 +703,8 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 wave_sync();
             }
         }
+        [[maybe_unused]] const unsigned long long sw_p1 = MW_SW_NOW();
+        MW_SW_ACC(13, sw_p1 - sw_p0);
         if (do_switch) {
             // new_eta - old_eta of the switch (:1557-1558) = eta_weight(ls_mu) - eta_weight(ls_mu) with the weights as they are NOW,
             // added to the energy terms ONE AFTER THE OTHER (:1561-1563): (x + eta) - eta.  For a modest eta that is x to a rounding
@@ -724,14 +741,20 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 wave_sync();
             }
         }
+        MW_SW_ACC(14, MW_SW_NOW() - sw_p1);
         return sw;
     };
 
     int ls = C.ls;                               // the active lattice, followed by every wavefront
+    [[maybe_unused]] const unsigned long long sw_k0 = MW_SW_NOW();
+#ifdef MW_SWEEP_STAMPS
+    const unsigned long long sw_w0 = wall_clock64();
+#endif
 
     // ---- the decision on a translation (wavefront 0), mc_moves.F90:1090-1209, for the move in slot s of the round ---------
     // U: the move's uniforms; imol: its molecule; the energies come from the wavefronts of that slot through `sx`.
     auto decide_trans = [&](int s, const double* U, int imol, unsigned long long movenum) -> bool {
+        [[maybe_unused]] const unsigned long long sw_d0 = MW_SW_NOW();
         if (C.dd && C.within == 0) {                               // top of a cycle: the equilibration check of mc_cycle (:181-210)
             const int cyc = C.cyc;
             if (lane == 0) {
@@ -775,6 +798,8 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 minu_ls = dev_minu_branch(C, ls0, mn0, mn1, svol[0], svol[1], ls0 == 1 ? bk0 : bk1, ls0 == 1 ? svol[0] : svol[1],
                                           C.npt != 0, N, eta_new, eta_old, diffkT);
         }
+        [[maybe_unused]] const unsigned long long sw_d1 = MW_SW_NOW();
+        MW_SW_ACC(10, sw_d1 - sw_d0);
         // the move's exponentials in one stream: lane 0 the acceptance; lanes 1, 2 the lattice switch that follows an
         // accepted / a rejected move (mc_lattice_switch, :1536-1594); lanes 3, 4 the unbiased histogram's factor (:1627-1629)
         double dkA = 0.0, dkR = 0.0;
@@ -800,8 +825,12 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             eta_fin = eta_rev; cmp_sw = readlane_f64(ex, 2); ufac = readlane_f64(ex, 4);
         }
         wave_sync();
+        [[maybe_unused]] const unsigned long long sw_d2 = MW_SW_NOW();
+        MW_SW_ACC(11, sw_d2 - sw_d1);
         int sw = 0;
         if (L == 2) sw = post_move(eta_fin, cmp_sw, ufac, do_switch, U[6]);
+        [[maybe_unused]] const unsigned long long sw_d3 = MW_SW_NOW();
+        MW_SW_ACC(12, sw_d3 - sw_d2);
         if (lane == 0) {
             if (mvlog) {
                 double* q = mvlog + ((size_t)blockIdx.x * nmoves + movenum) * 8;
@@ -810,12 +839,14 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             if (C.dd) { const int w = C.within + 1; if (w == N) { C.within = 0; C.cyc = C.cyc + 1; } else C.within = w; }
         }
         wave_sync();
+        MW_SW_ACC(15, MW_SW_NOW() - sw_d3);
         return ok;
     };
 
     constexpr int kUB = sweep_batch(WITHVOL);
     int mv = 0, ubase = -kUB;                    // next move of the chain (counted within the launch); first move of the uniforms' window
     while (mv < nmoves) {
+        [[maybe_unused]] const unsigned long long sw_u0 = MW_SW_NOW();
         if (mv + SPEC > ubase + kUB) {
             // the next kUB moves' random numbers: Philox call c of move m is thread 4 m + c (the same stream as the
             // oracle's mwo_move_uniforms: counter (move lo, move hi, walker, call), key = seed), then per move its
@@ -844,6 +875,8 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             }
             wg_sync<NW>();
         }
+        [[maybe_unused]] const unsigned long long sw_r0 = MW_SW_NOW();
+        MW_SW_ACC(6, sw_r0 - sw_u0);
         const int ub = mv - ubase;                // the round's first move inside the window
         const double* U0 = suni + ub * 8;         // u0..u7 per move: molecule, direction x3, length, acceptance, lattice switch (:1576), move type (:226)
         // the round: the run of translations that starts here, at most one per slot (a volume move is a round of its own)
@@ -1031,7 +1064,10 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             }
             if (lane == 0) { sx[2 * wv] = res.eo; sx[2 * wv + 1] = res.en; scm[wv] = cm; }
         }
+        [[maybe_unused]] const unsigned long long sw_e = MW_SW_NOW();
         wg_sync<NW>();                                 // every evaluation of the round is in (one wavefront: nothing of the walker's state is read ahead of it)
+        [[maybe_unused]] const unsigned long long sw_b = MW_SW_NOW();
+        MW_SW_ACC(0, sw_e - sw_r0); MW_SW_ACC(1, sw_b - sw_e);
         if (wv == 0) {
             unsigned accmask = 0u;
             int nvalid = 0;
@@ -1051,6 +1087,8 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 for (int s = 0; s < SPEC; ++s) sdec[4 + s] = (int)((accmask >> s) & 1u);
             }
         }
+        [[maybe_unused]] const unsigned long long sw_d = MW_SW_NOW();
+        MW_SW_ACC(2, sw_d - sw_b);
         if (NW > 1) wg_sync<NW>(); else wave_sync();
         const int nvalid = sdec[0];
         ls = sdec[1];
@@ -1062,7 +1100,12 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         mv += nvalid;
         // the next round must see the committed positions: with look-ahead, the other slots' of the same lattice too
         if (SPEC > 1) wg_sync<NW>(); else wave_sync();
+        MW_SW_ACC(3, MW_SW_NOW() - sw_d); MW_SW_ACC(4, (unsigned long long)nvalid); MW_SW_ACC(5, 1ull);
     }
+    MW_SW_ACC(7, MW_SW_NOW() - sw_k0);
+#ifdef MW_SWEEP_STAMPS
+    MW_SW_ACC(8, wall_clock64() - sw_w0);
+#endif
     __syncthreads();
     if (L == 2 && C.record) {
         for (int t = tid; t < nbins; t += NTHR) {

@@ -20,11 +20,15 @@ import time
 import numpy as np
 
 
+#: farms of more walkers than this (all ranks together) exchange one shared table by default (``regauge``)
+REGAUGE_ABOVE = 64
+
+
 def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=400.0, wl_factor=0.05,
         list_update_int=10, mpi_sync_int=250, sigma_ang=0.05, seed=2025, device=0, comms=None, rank=0,
         samplerun=False, weight=None, npt=False, pressure_atm=1.0,
         flat_chk_int=10000, wl_schedule=0, wl_flattol=0.05, wl_minhist=20, wl_useinvt=False, file_wl_factor=None,
-        deltaG_int=100000, max_mc_cycles=None, eq_mc_cycles=0, outdir=None, thermalise=True, regauge=False,
+        deltaG_int=100000, max_mc_cycles=None, eq_mc_cycles=0, outdir=None, thermalise=True, regauge=None,
         parallel_strategy="mw", window_overlap=2, leshift=False, input_ref_enthalpy=None, wl_swetnam=False, wl_alpha=1.0,
         eq_adjust_mc=False, mc_target_ratio=0.5, monitor_int=1000, mc_max_trans_ang=1.1, mc_dv_max_ang=0.924,
         latt_sync_int=10000, chkpt_dump_int=None, restart=False, minu=False):
@@ -33,10 +37,13 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
     ``flat_chk_int`` ... ``file_wl_factor``: the Wang-Landau schedule (mc_check_flatness, :291-294;
     :mod:`mc_water_ls_mw_amd.schedule`); ``deltaG_int``: free-energy estimate of a sample run (:302-306);
     ``outdir``: where wlf.dat and the tagged tables go (nothing is written when None).
-    ``regauge``: False (default) is the reference's exchange arithmetic to the letter (comms_mpi.f90:256-270: every
-    rank's increment carries the window minimum it subtracted); True sums the increments proper and subtracts the
-    minimum once (WalkerFarm.synchronise) -- the mode for farms of hundreds of walkers per GPU, where the reference's
-    scheme loses the weights' precision within a few synchronisations (tests/test_sweep.py shows the growth).
+    ``regauge``: False is the reference's exchange arithmetic to the letter (comms_mpi.f90:256-270: every rank's
+    increment carries the window minimum it subtracted); True sums the increments proper and subtracts the minimum
+    once (WalkerFarm.synchronise): one shared table in the reference's own gauge, identical to the reference for one
+    walker.  None (default) = True for more than ``REGAUGE_ABOVE`` = 64 walkers in all, False up to there: the
+    reference's scheme multiplies a uniform offset by -(walkers - 1) at every synchronisation (harmless for its 8 ranks
+    over a run, 1.9e10 after four synchronisations of 8192 walkers; tests/test_sweep.py shows the growth), so a farm of
+    hundreds of walkers that followed it to the letter would be faithful and useless.
     ``parallel_strategy``: 'mw' (every walker samples the whole range, tables synchronised every mpi_sync_int cycles) or
     'dd' (mc_moves.F90:659-709: every walker of every GPU is one window of ``world x walkers``, overlapping its
     neighbours by ``window_overlap`` bins, with its own increment and flatness check and no exchange; the windows are
@@ -60,12 +67,14 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         raise ValueError("Unknown parallel_strategy")                      # mc_moves.F90:720
     dd = parallel_strategy == "dd"
     nwalk_all = walkers * (comms.world_size if comms is not None else 1)
-    if not dd and not regauge and not samplerun and nwalk_all > 64 and rank == 0:
+    if regauge is None:
+        regauge = nwalk_all > REGAUGE_ABOVE
+    if not dd and not regauge and not samplerun and nwalk_all > REGAUGE_ABOVE and rank == 0:
         import sys
         print(f"mc_water_ls_mw_amd.farm: {nwalk_all} walkers exchange their weights with the reference's own arithmetic "
-              "(comms_mpi.f90:256-270), whose uniform offset grows by the number of walkers at every synchronisation: the table "
-              "reaches the end of the double range within a few dozen synchronisations (8192 walkers: 1e307 after 80).  "
-              "regauge=True (--regauge) keeps one shared table in the reference's gauge.", file=sys.stderr)
+              "(comms_mpi.f90:256-270, asked for with regauge=False / --no-regauge), whose uniform offset grows by the number of "
+              "walkers at every synchronisation: the table reaches the end of the double range within a few dozen synchronisations "
+              "(8192 walkers: 1e307 after 80).", file=sys.stderr)
     n = len(x_pair[0])
     em = EnergyModule(n, 2 * walkers, device=device)
     for w in range(walkers):
@@ -78,13 +87,22 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         from . import io as mwio
         chk = [mwio.latest_checkpoint(outdir, rank * walkers + w)[1] for w in range(walkers)]
         start_cycle = chk[0]["cycle"]
+        # The ranks AGREE before any of them stops: a rank that raised on its own left the others waiting in the broadcast
+        # below or in the first synchronisation.  Every rank takes part in the broadcast of rank 0's cycle number (mc_cycle_num is
+        # rank 0's, :441: ranks that picked files of different cycles would pair their collectives wrongly) and in one get_max
+        # of "something is wrong here"; then all of them raise, the bad ones saying what they found.
+        bad = None
         if any(c["cycle"] != start_cycle for c in chk):
-            raise ValueError("the walkers' checkpoint files are not of the same cycle: "
-                             + ", ".join(str(c["cycle"]) for c in chk[:8]))
-        if comms is not None and comms.world_size > 1:                     # mc_cycle_num is rank 0's, broadcast (:441): ranks that picked
-            agreed = comms.bcast_int(start_cycle, 0)                       # files of different cycles would pair their collectives wrongly
-            if agreed != start_cycle:
-                raise ValueError(f"rank {rank} restarts from cycle {start_cycle}, rank 0 from {agreed}: checkpoint files out of step")
+            bad = ("the walkers' checkpoint files are not of the same cycle: " + ", ".join(str(c["cycle"]) for c in chk[:8]))
+        if comms is not None and comms.world_size > 1:
+            agreed = comms.bcast_int(start_cycle, 0)
+            if bad is None and agreed != start_cycle:
+                bad = f"rank {rank} restarts from cycle {start_cycle}, rank 0 from {agreed}: checkpoint files out of step"
+            anybad = comms.get_max(0.0 if bad is None else 1.0)
+            if bad is None and anybad:
+                bad = f"rank {rank}: another rank's checkpoint files are out of step (its message says which); cycle here {start_cycle}"
+        if bad is not None:
+            raise ValueError(bad)
         for w, c in enumerate(chk):
             if c["nwater"] != n or len(c["hmatrix"]) != 2:
                 raise ValueError("checkpoint does not match this run")
@@ -317,7 +335,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                    wl_invt_active=sched.invt_active, flatness_events=events, delta_g=delta_g,
                    ref_enthalpy=farm.ref_enthalpy,
                    max_trans_bohr=step_t[:32].tolist(), dv_max_bohr=step_v[:32].tolist(),
-                   list_rows_last_rebuild=list(list_rows))
+                   list_rows_last_rebuild=list(list_rows), regauge=bool(regauge))
         out["tables"] = synced
         out["restart_factors"] = None if restart_factors is None else [np.asarray(a).tolist() for a in restart_factors]
         out["joined"] = joined
@@ -368,9 +386,11 @@ def main():
     ap.add_argument("--samplerun", action="store_true", help="fixed weights, unbiased histogram (examples/ice1_sample); needs --weights")
     ap.add_argument("--weights", default=None, help="eta_weights.dat: the starting weights (mc_moves.F90:738-770)")
     ap.add_argument("--delta-g", type=int, default=100000, help="deltaG_int: cycles between free-energy estimates of a sample run")
-    ap.add_argument("--regauge", action="store_true",
-                    help="exchange step sums the weight increments proper and subtracts the window minimum once "
-                         "(default: the reference's arithmetic, comms_mpi.f90:256-270)")
+    ap.add_argument("--regauge", dest="regauge", action="store_true", default=None,
+                    help="exchange step sums the weight increments proper and subtracts the window minimum once: one shared table "
+                         "(default for more than 64 walkers in all)")
+    ap.add_argument("--no-regauge", dest="regauge", action="store_false",
+                    help="the reference's exchange arithmetic to the letter, comms_mpi.f90:256-270 (default up to 64 walkers in all)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist

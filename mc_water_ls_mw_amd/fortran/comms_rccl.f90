@@ -78,6 +78,10 @@ module comms
        import :: c_int
        integer(c_int) :: rc
      end function mw_comms_finalize
+     function mw_comms_abort() bind(C,name='mw_comms_abort') result(rc)
+       import :: c_int
+       integer(c_int) :: rc
+     end function mw_comms_abort
      function mw_comms_last_error() bind(C,name='mw_comms_last_error') result(p)
        import :: c_ptr
        type(c_ptr) :: p
@@ -100,7 +104,9 @@ contains
        write(0,'(A1)',advance='no')msg(k)
     end do
     write(0,*)
-    k = mw_comms_finalize()     ! (nothing of this rank -- its id file, its communicator -- is left for the next job to trip over)
+    ! Nothing of this rank is left for the next job to trip over (its id file), and nothing here waits for a peer that may be
+    ! gone: the communicator is aborted, not destroyed (a stream synchronisation or ncclCommDestroy could block for ever).
+    k = mw_comms_abort()
     stop 'comms (RCCL) failure'
   end subroutine comms_check
 

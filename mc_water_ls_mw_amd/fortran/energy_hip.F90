@@ -305,12 +305,19 @@ contains
     !------------------------------------------------------------------------------!
     use model,      only : ljr
     use userparams, only : num_lattices
+!$  use omp_lib,    only : omp_in_parallel
     implicit none
     integer,intent(in) :: imol,ils
     real(c_double) :: e,r1(3),r2(3)
     integer(c_int) :: prev,rc
-    logical :: hit
+    logical :: hit,par
 
+    ! Inside an OpenMP parallel region (the reference's dormant `!$omp parallel do` over ils, mc_moves.F90:1006-1018) the
+    ! two lattices are asked about by two threads at once: nothing is posted ahead there -- the threads ARE the overlap --
+    ! and the bookkeeping of a request posted earlier by serial code is settled by one thread at a time.
+    par = .false.
+!$  par = omp_in_parallel()
+!$omp critical (mw_energy_pending)
     ! The answer may be waiting already: the host asks the same question of lattice 2 right after lattice 1
     ! (mc_moves.F90:1006-1018, 1076-1092), so the call for lattice 1 posted lattice 2's request before it waited for
     ! its own reply (below).  The reply is this call's if nothing the request carried has changed since: the
@@ -322,10 +329,14 @@ contains
        if (hit .and. pend_prev>=1) hit = all(ljr(:,1,pend_prev,2)==pend_r2)
        rc = mw_local_energy_collect(2_c_int,e)            ! (a reply nobody wants is still waited for: the slot holds one request)
        if (rc/=0 .and. rc/=2) call mw_check(rc,'compute_local_real_energy')
-       if (hit .and. rc==0) then
-          compute_local_real_energy = e                     ! (last_imol(2) = imol since the post)
-          return
-       end if
+       if (.not.(hit .and. rc==0)) hit = .false.
+    else
+       hit = .false.
+    end if
+!$omp end critical (mw_energy_pending)
+    if (hit) then
+       compute_local_real_energy = e                        ! (last_imol(2) = imol since the post)
+       return
     end if
 
     if (stale(ils)) then
@@ -336,7 +347,7 @@ contains
     ! Only the FIRST question about a molecule is worth posting ahead: the host asks for the old energies of both lattices
     ! back to back, but it moves the molecule lattice by lattice in between the two "new energy" calls (mc_moves.F90:1076-
     ! 1083), so lattice 2's trial position does not exist yet when lattice 1's is evaluated.
-    if (ils==1 .and. num_lattices==2 .and. overlap_calls .and. last_imol(1)/=imol) then
+    if (ils==1 .and. num_lattices==2 .and. overlap_calls .and. .not.par .and. last_imol(1)/=imol) then
        if (.not.stale(2)) then
           r1 = ljr(:,1,imol,2)
           prev = last_imol(2)
