@@ -15,6 +15,7 @@
  *   mw_comms_sendrecv        comms_p2preal / comms_p2pint   comms_mpi.f90:168-222
  *   mw_comms_barrier         comms_barrier                  comms_mpi.f90:601-618
  *   mw_comms_finalize        Comms_Finalise                 comms_mpi.f90:569-599
+ *   mw_comms_abort           (the failure path of every routine: the reference stops on an MPI error)
  *
  * Bootstrap (no MPI, no launcher dependency): rank and size come from the environment -- MW_COMMS_RANK /
  * MW_COMMS_SIZE, else RANK / WORLD_SIZE as torchrun sets them -- and the RCCL unique id travels through a file:

@@ -2044,7 +2044,7 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
         // (tools/sweep_measurements.py n48wl_<walkers> / n48npt_<walkers>): 4 ahead wins up to 512 walkers (256 with volume moves),
         // 2 ahead up to 1024 (768), and past that look-ahead only takes places away from other walkers.
         auto all_resident = [&](int ahead) {
-            const int per_cu = ((withvol && L == 2) ? 12 : 16) / (L * ahead);
+            const int per_cu = ((L == 2 && ahead > 1) ? 12 : 16) / (L * ahead);   // (two lattices with look-ahead: the builds of <= 168 VGPRs)
             return (long long)count <= (long long)g.cu * per_cu;
         };
         spec = all_resident(4) ? 4 : (all_resident(2) ? 2 : 1);

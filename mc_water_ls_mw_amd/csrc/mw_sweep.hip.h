@@ -67,17 +67,21 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
 // lane and ONE instruction stream serves them all; likewise the move's exponentials.
 // -------------------------------------------------------------------------------------
 struct MuGridDev {                       // per walker, wave-uniform
-    double r_pos, a_pos, r_neg, a_neg, lr_pos, lr_neg, mu_lo, mu_hi;
+    double c_pos, c_neg, ilr_pos, ilr_neg, mu_lo, mu_hi;       // c = (1 - r) / a, ilr = 1 / log(r) of the two geometric bin progressions
     int nbins, start_bin, end_bin, eta_interp, in_window;
 };
 
-__device__ __forceinline__ int lane_mu_to_bin(const MuGridDev& g, double mu)          // mc_moves.F90:2187-2215, one mu per lane
+// mc_moves.F90:2187-2215, one mu per lane: bin = nbins/2 + 2 + int(log(1 - (mu - 0.5)(1 - r)/a) / log r) on the positive side.  The
+// two divisions are multiplications by per-walker constants and the logarithm is the engine's own (mw_common.hip.h) -- 45 vector
+// instructions where the expression as written costs 220; the bin differs from the reference's only for a mu within ~1e-15
+// (relative) of a bin boundary, where two libm implementations differ as well.
+__device__ __forceinline__ int lane_mu_to_bin(const MuGridDev& g, double mu)
 {
     const double a = fabs(mu);
     const bool pos = mu > 0.0;
-    const double r = pos ? g.r_pos : g.r_neg, aa = pos ? g.a_pos : g.a_neg, lr = pos ? g.lr_pos : g.lr_neg;
-    const double arg = 1.0 - (a - 0.5) * (1.0 - r) / aa;
-    const int q = (int)(log(arg) / lr);
+    const double c = pos ? g.c_pos : g.c_neg, ilr = pos ? g.ilr_pos : g.ilr_neg;
+    const double arg = __builtin_fma(-(a - 0.5), c, 1.0);
+    const int q = (int)(fast_log_pos(arg) * ilr);
     return a <= 0.5 ? g.nbins / 2 + 1 : (pos ? g.nbins / 2 + 2 + q : g.nbins / 2 - q);
 }
 
@@ -431,7 +435,8 @@ struct WalkerCtl {
     double beta, pressure, dref, av_binwidth, log_unbiased_norm, transP, ref1, ref2, wl_alpha, orig_wl_factor, mu_min, mu_max;
     double max_trans, dv_max;
     MuGridDev mg;                            // (mg.in_window changes at the top of a 'dd' cycle)
-    int record, samplerun, always_switch, npt, swetnam, dd, minu, eq_cycles, nbins, pad0;
+    int record, samplerun, always_switch, npt, swetnam, dd, minu, eq_cycles, nbins;
+    int tab_small;                           // every |weight| < 2^20 (the lattice switch's shortcut; kept up with every update)
     // the walker's state between moves
     double men0, men1, ls_mu, gauge, wlf, sumh, cur_min, lgv12, lgv21;
     unsigned long long acc, nsw, nvol_try, nvol_acc;
@@ -475,7 +480,7 @@ template <int NLAT, int SPEC, bool LDSPOS, bool LDSLIST, bool WITHVOL>
 #ifdef MW_SWEEP_WAVES_CAP     // diagnostic builds only (tools/variants.py): e.g. 5 -> 96 vector registers, a build that SPILLS, to show that one is still correct
 __global__ __launch_bounds__(64 * NLAT * SPEC) __attribute__((amdgpu_waves_per_eu(MW_SWEEP_WAVES_CAP, MW_SWEEP_WAVES_CAP)))
 #else
-__global__ __launch_bounds__(64 * NLAT * SPEC) __attribute__((amdgpu_waves_per_eu((WITHVOL && NLAT == 2 && SPEC > 1) ? 3 : 4, (WITHVOL && NLAT == 2 && SPEC > 1) ? 3 : 4)))
+__global__ __launch_bounds__(64 * NLAT * SPEC) __attribute__((amdgpu_waves_per_eu((NLAT == 2 && SPEC > 1) ? 3 : 4, (NLAT == 2 && SPEC > 1) ? 3 : 4)))
 #endif
 void k_sweep(double* pos, double* hmat, double* ivect,
              int* nivect, const uint32_t* __restrict__ listm, const uint32_t* __restrict__ list,
@@ -567,8 +572,8 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         C.wl_alpha = sp.wl_alpha; C.orig_wl_factor = sp.orig_wl_factor; C.mu_min = sp.mu_min; C.mu_max = sp.mu_max;
         C.max_trans = sp.max_trans; C.dv_max = sp.dv_max;
         if (wstep) { C.max_trans = wstep[2 * (size_t)wlk]; C.dv_max = wstep[2 * (size_t)wlk + 1]; }   // equilibration tuning, :1729-1732
-        C.mg.r_pos = sp.r_pos; C.mg.a_pos = sp.a_pos; C.mg.r_neg = sp.r_neg; C.mg.a_neg = sp.a_neg;
-        C.mg.lr_pos = log(sp.r_pos); C.mg.lr_neg = log(sp.r_neg);
+        C.mg.c_pos = (1.0 - sp.r_pos) / sp.a_pos; C.mg.c_neg = (1.0 - sp.r_neg) / sp.a_neg;
+        C.mg.ilr_pos = 1.0 / log(sp.r_pos); C.mg.ilr_neg = 1.0 / log(sp.r_neg);
         C.mg.mu_lo = sp.mu_lo; C.mg.mu_hi = sp.mu_hi; C.mg.nbins = nbins; C.mg.start_bin = sp.start_bin; C.mg.end_bin = sp.end_bin;
         C.mg.eta_interp = sp.eta_interp;
         if (wwin) {
@@ -602,7 +607,10 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 cmin = readlane_f64(dpp_wave_min(mn), 63);
             }
         }
-        if (lane == 0) { C.lgv12 = l12; C.lgv21 = l21; C.cur_min = cmin; }
+        bool sm = true;
+        if (L == 2) for (int b = lane; b < nbins; b += 64) sm = sm && fabs(sweight[b]) < 1048576.0;
+        const bool allsm = __ballot(!sm) == 0ull;
+        if (lane == 0) { C.lgv12 = l12; C.lgv21 = l21; C.cur_min = cmin; C.tab_small = allsm ? 1 : 0; }
     }
     __syncthreads();
 
@@ -691,8 +699,15 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                             sweight[b] = w - mn;
                         }
                         if (lane == 0 && !k_in) sweight[k - 1] = sweight[k - 1] + inc;
+                        wave_sync();
+                        bool sm = true;                                           // (the window was re-gauged: is every weight still below 2^20?)
+                        for (int b = lane; b < nbins; b += 64) sm = sm && fabs(sweight[b]) < 1048576.0;
+                        const bool allsm = __ballot(!sm) == 0ull;
+                        if (lane == 0) C.tab_small = allsm ? 1 : 0;
                     } else if (lane == 0) {
-                        sweight[k - 1] = k_in ? (wk + inc) - mn : wk + inc;
+                        const double w_upd = k_in ? (wk + inc) - mn : wk + inc;
+                        sweight[k - 1] = w_upd;
+                        if (!(fabs(w_upd) < 1048576.0)) C.tab_small = 0;
                     }
                     if (lane == 0) {
                         C.cur_min = 0.0;                                          // the lowest bin of the window is now exactly mn - mn
@@ -751,96 +766,468 @@ void k_sweep(double* pos, double* hmat, double* ivect,
     const unsigned long long sw_w0 = wall_clock64();
 #endif
 
-    // ---- the decision on a translation (wavefront 0), mc_moves.F90:1090-1209, for the move in slot s of the round ---------
-    // U: the move's uniforms; imol: its molecule; the energies come from the wavefronts of that slot through `sx`.
-    auto decide_trans = [&](int s, const double* U, int imol, unsigned long long movenum) -> bool {
-        [[maybe_unused]] const unsigned long long sw_d0 = MW_SW_NOW();
-        if (C.dd && C.within == 0) {                               // top of a cycle: the equilibration check of mc_cycle (:181-210)
-            const int cyc = C.cyc;
-            if (lane == 0) {
-                if (cyc < C.eq_cycles) C.mg.in_window = (C.ls_mu > C.mg.mu_lo && C.ls_mu < C.mg.mu_hi) ? 1 : 0;
-                else if (cyc == C.eq_cycles) { if (!C.mg.in_window) C.flag = C.flag | 2; }   // "Not all walkers have reached their designated window"
-                else C.mg.in_window = 1;                           // a restart
-            }
-            wave_sync();
-        }
-        const bool do_switch = L == 2 && C.always_switch && !(C.dd && C.cyc < C.eq_cycles);   // (:243-248: not while a 'dd' run equilibrates)
-        const double eo0 = sx[2 * (s * NLAT)], en0 = sx[2 * (s * NLAT) + 1];
-        const double eo1 = L == 2 ? sx[2 * (s * NLAT + 1)] : 0.0, en1 = L == 2 ? sx[2 * (s * NLAT + 1) + 1] : 0.0;
-        const int ls0 = C.ls;
-        const double beta = C.beta;
-        const double dE0 = en0 - eo0, dE1 = en1 - eo1;                            // :1090
-        const double bk0 = C.men0, bk1 = C.men1;                                  // :1013
-        const double mn0 = (bk0 - eo0) + en0, mn1 = (bk1 - eo1) + en1;            // :1016,1087
-        int minu_ls = ls0;
-        double mu_new = 0.0, mu_rev = 0.0, eta_new = 0.0, eta_rev = 0.0, diffkT;
-        int k_new = 0, k_rev = 0;
-        if (L == 1) {
-            diffkT = beta * dE0;                                                  // :1106
-        } else {
-            const double mu_cur = C.ls_mu;
-            {
+    // ---- the decisions on a round of translations (wavefront 0), mc_moves.F90:1090-1209 + mc_update_wl_bins + mc_lattice_switch ----
+    // One chain's speed is the length of this routine, and what a LONE wavefront pays for is not arithmetic (tools/lat_probe.hip on
+    // gfx950: a dependent v_fma_f64 6 cycles) but every trip through the scalar unit -- a value read from a lane and used again 25-30
+    // cycles, a compare that feeds a branch 60, a taken branch 20-25, a lane-0-only region 22 -- and every LDS round trip, 60-80.
+    // With the walker's state in LDS and every decision computed from scratch in scalar style a decision took 2.6 us where its
+    // evaluation took 1.2 (profiles/r04a_sweep_stamps.json).  So the round is decided in lanes, in three pieces:
+    //  * PRE-PHASE, once per round: everything that follows from the evaluated energies and the state at the round's start ALONE,
+    //    under the assumption that holds for as long as the round goes on anyway on small boxes -- the earlier moves of the round are
+    //    rejected, no lattice switch.  With a the round's first undecided move: lane 2a holds the current order parameter, lane 2s+1
+    //    the value move s takes it to if accepted, lane 2s+2 the value its rejection restores (the chain mu -> (mu + d) - d, a handful
+    //    of additions every lane runs for itself); ONE instruction stream gives all their bins (the engine's own log), the
+    //    interpolation of eta_weight reduced to {two table indices, one slope factor}, the reciprocal bin width of the Wang-Landau
+    //    visit, and the exponential of the lattice switch that would follow the move.
+    //  * the RUN (`run_of_moves`), once per round in the normal case: five moves in six are rejected and change nothing but the
+    //    tables -- the visited bin's weight and histogram entry -- so the table move s will find, IF the moves before it are such
+    //    rejections, follows from the pre-phase: every lane adds the earlier moves' increments to the weights it touches in the
+    //    chain's order (the very additions the moves would make), and every move's eta_weight pair, acceptance exponential and
+    //    switch test come out of one straight-line pass -- no loop, no value carried through a scalar.  The run up to the first
+    //    move that is accepted, switches lattice, needs the general routine (a bin at the window's minimum, a re-gauge, a wall, a
+    //    large weight) or whose evaluation no longer stands is committed at once, an accepted move of the routine kind with it.
+    //  * the SERIAL step, for the move the run stopped at when it is not of the routine kind, and for every move of the run options
+    //    the run does not cover (sample runs, 'dd' windows, MINU, Swetnam's increment): the reference's sequence as written.
+    // After an ACCEPTED move that leaves the round standing (large boxes) the pre-phase is run again for the moves that remain.
+    // eta_weight's interpolation is evaluated as  w(base) + [(mu - mu_bin(base)) 2 / (binwidth(hi) + binwidth(lo))] (w(hi) - w(lo)):
+    // the reference's  (mu - mu_bin) * (2 (w(hi) - w(lo)) / (bw + bw))  with the division taken out of the serial step (1e-16 relative).
+    // Floating-point contraction is OFF in here: a product that the run adds to a weight in one place and the serial step in another
+    // must round the same way wherever it is inlined (look-ahead = the sequential chain, bit for bit).
+    auto wave_fence = [&]() {                    // orders this wavefront's own LDS traffic for the compiler; LDS serves a wavefront in order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    __shared__ int bx_k[SPEC + 1];                // the run's exchange: bin, weight increment, histogram increment of every move's rejection
+    __shared__ double bx_inc[SPEC + 1], bx_vis[SPEC + 1], bx_dump[2];
+    auto decide_round = [&](int ntr, int ub, const double* U0, int mvbase) {
 #pragma clang fp contract(off)
-                const double d = (dE0 - dE1) * beta;                              // :1114 ... and what :1192 takes off again
-                mu_new = mu_cur + d;
-                mu_rev = mu_new - d;
+        constexpr double kHuge = 1.7976931348623157e308;                         // huge(1.0_dp)
+        unsigned accmask = 0u;
+        int nvalid = 0;
+        // the walker's state, in registers for the length of the round
+        double bk0 = C.men0, bk1 = L == 2 ? C.men1 : 0.0;                         // :1013
+        int ls_c = C.ls;
+        unsigned long long acc_d = 0ull;
+        if constexpr (L == 1) {
+            // one lattice: a move's acceptance depends on its own energies only -- every exponential of the round in one pass
+            const int sl = lane < SPEC ? lane : 0;
+            const double eo = sx[2 * sl], en = sx[2 * sl + 1];
+            const double beta = C.beta;
+            const double pex = exp_any(-(beta * (en - eo)));                      // :1106,1145
+            for (int s = 0; s < ntr; ++s) {
+                if (s > 0 && (scm[s] & accmask) != 0u) break;                     // that evaluation no longer stands: the next round starts with it
+                const double* U = U0 + 8 * s;
+                double pacc = readlane_f64(pex, s);
+                pacc = pacc > 1.0 ? 1.0 : pacc;
+                const bool ok = U[5] < pacc;                                      // (false for NaN)
+                const double eo_s = readlane_f64(eo, s), en_s = readlane_f64(en, s);
+                if (ok) { accmask |= 1u << s; ++acc_d; bk0 = (bk0 - eo_s) + en_s; }     // :1016,1150-1170
+                if (mvlog && lane == 0) {
+                    const int im = (int)__double_as_longlong(smv[(ub + s) * MVS + 3]);
+                    double* q = mvlog + ((size_t)blockIdx.x * nmoves + (size_t)(mvbase + s)) * 8;
+                    q[0] = (double)im; q[1] = ok ? 1.0 : 0.0; q[2] = eo_s; q[3] = en_s; q[4] = 0.0; q[5] = 0.0; q[6] = C.ls_mu; q[7] = beta * (en_s - eo_s);
+                }
+                ++nvalid;
             }
-            // lanes 0, 1, 2: the trial value, the value a rejection restores, the current one (its bin is carried)
-            const double mul = lane == 0 ? mu_new : (lane == 1 ? mu_rev : mu_cur);
-            int kl = lane_mu_to_bin(C.mg, mul);
-            if (C.k_valid && lane >= 2) kl = C.k_cur;
-            const double el = lane_eta(C.mg, sweight, smub, sbw, mul, kl);        // :1112-1116
-            eta_new = readlane_f64(el, 0); eta_rev = readlane_f64(el, 1);
-            const double eta_old = readlane_f64(el, 2);
-            k_new = __builtin_amdgcn_readlane(kl, 0); k_rev = __builtin_amdgcn_readlane(kl, 1);
-            diffkT = (ls0 == 1 ? dE0 : dE1) * beta + eta_new - eta_old;
-            if (C.minu)                                                           // :1119-1140
-                minu_ls = dev_minu_branch(C, ls0, mn0, mn1, svol[0], svol[1], ls0 == 1 ? bk0 : bk1, ls0 == 1 ? svol[0] : svol[1],
-                                          C.npt != 0, N, eta_new, eta_old, diffkT);
-        }
-        [[maybe_unused]] const unsigned long long sw_d1 = MW_SW_NOW();
-        MW_SW_ACC(10, sw_d1 - sw_d0);
-        // the move's exponentials in one stream: lane 0 the acceptance; lanes 1, 2 the lattice switch that follows an
-        // accepted / a rejected move (mc_lattice_switch, :1536-1594); lanes 3, 4 the unbiased histogram's factor (:1627-1629)
-        double dkA = 0.0, dkR = 0.0;
-        if (do_switch) {
-            dkA = switch_dk(mn0, mn1, minu_ls);
-            dkR = switch_dk(bk0, bk1, ls0);
-        }
-        const double lun = L == 2 ? C.log_unbiased_norm : 0.0;
-        const double xarg = lane == 0 ? -diffkT : (lane == 1 ? -dkA : (lane == 2 ? -dkR : (lane == 3 ? eta_new - lun : eta_rev - lun)));
-        const double ex = exp_any(xarg);
-        double pacc = readlane_f64(ex, 0);
-        pacc = pacc > 1.0 ? 1.0 : pacc;
-        const bool ok = U[5] < pacc;                                              // :1145-1146 (false for NaN)
-        double eta_fin, cmp_sw, ufac;
-        if (ok) {                                                                 // :1150-1170
+            if (lane == 0) { C.men0 = bk0; C.acc = C.acc + acc_d; }
+        } else {
+            double mu_c = C.ls_mu, cur_min = C.cur_min, wlf = C.wlf, gauge = C.gauge;   // (gauge: the minima subtracted so far, :1682-1685, summed move by move)
+            int k_c = C.k_cur, k_val = C.k_valid, in_win = C.mg.in_window, cyc = C.cyc, within = C.within, flag_d = 0;
+            unsigned long long nsw_d = 0ull;
+            const double beta = C.beta, lun = C.log_unbiased_norm, avbw = C.av_binwidth;
+            const int record = C.record, samplerun = C.samplerun, always_switch = C.always_switch, dd = C.dd, minu = C.minu, swet = C.swetnam;
+            const int nb = nbins, sb = C.mg.start_bin, eb = C.mg.end_bin, interp = C.mg.eta_interp;
+            const double mu_lo = C.mg.mu_lo, mu_hi = C.mg.mu_hi;
+            // per lane: what the pre-phase leaves for the run and the serial steps (lane 2a: the current value; 2s+1 / 2s+2: move s accepted / rejected)
+            double dEb = 0.0, mn0l = 0.0, mn1l = 0.0, mul = 0.0, c_m = 0.0, c_rb = 1.0, exs = 0.0;
+            int kl = 0, kc = 1, c_b = 1, c_hi = 2;
+            bool c_out = false;
+            auto all_weights_small = [&]() {
+                bool sm = true;
+                for (int b = lane; b < nb; b += 64) sm = sm && fabs(sweight[b]) < 1048576.0;
+                return __ballot(!sm) == 0ull;
+            };
+            bool tab_small = C.tab_small != 0;     // |weight| < 2^20 in every bin (the lattice switch's shortcut below): kept up with every update
+            int cur_lane = 0;
+            const int slot_l = lane >= 1 && lane <= 2 * SPEC ? (lane - 1) >> 1 : 0;      // this lane's move of the round
+            const bool newl = (lane & 1) != 0;                                            // ... its "accepted" (odd lane) or "rejected" candidate
+            auto prephase = [&](int a) {
+                [[maybe_unused]] const unsigned long long t0 = MW_SW_NOW();
+                // the chain of order parameters, every lane for itself (uniform reads of the round's energies: no value travels between lanes)
+                double mu_run = mu_c;
+                mul = mu_c;
+#pragma unroll
+                for (int j = 0; j < SPEC; ++j) {
+                    const double e0o = sx[2 * (j * NLAT)], e0n = sx[2 * (j * NLAT) + 1], e1o = sx[2 * (j * NLAT + 1)], e1n = sx[2 * (j * NLAT + 1) + 1];
+                    const double dj = ((e0n - e0o) - (e1n - e1o)) * beta;         // :1114 ... and what :1192 takes off again
+                    const double mu_n = mu_run + dj, mu_r = mu_n - dj;
+                    const bool act = j >= a && j < ntr;
+                    mul = (act && lane == 2 * j + 1) ? mu_n : ((act && lane == 2 * j + 2) ? mu_r : mul);
+                    mu_run = act ? mu_r : mu_run;
+                }
+                const double eo0 = sx[2 * (slot_l * NLAT)], en0 = sx[2 * (slot_l * NLAT) + 1];
+                const double eo1 = sx[2 * (slot_l * NLAT + 1)], en1 = sx[2 * (slot_l * NLAT + 1) + 1];
+                const double dE0 = en0 - eo0, dE1 = en1 - eo1;                    // :1090
+                dEb = (ls_c == 1 ? dE0 : dE1) * beta;
+                mn0l = (bk0 - eo0) + en0; mn1l = (bk1 - eo1) + en1;               // :1016,1087
+#ifdef MW_ABL_D_NOBIN
+                int kq = nb / 2 + 1 + (lane & 3);
+#else
+                int kq = lane_mu_to_bin(C.mg, mul);                               // :1112-1116
+#endif
+                kq = (k_val && lane == 2 * a) ? k_c : kq;                         // (the bin of the current value is carried)
+                kl = kq;
+                kc = kq < 1 ? 1 : (kq > nb ? nb : kq);                            // eta_weight (:893-964), see lane_eta
+                const bool up = (kc == sb) || (kc != eb && mul > smub[kc - 1]);
+                int hi = up ? kc + 1 : kc;
+                hi = hi > nb ? nb : (hi < 2 ? 2 : hi);
+                const int base = (up || kc == eb) ? kc : (kc > 1 ? kc - 1 : 1);
+                c_hi = hi;
+                c_b = interp ? base : kc;
+                c_m = (mul - smub[base - 1]) * (2.0 * fast_rcp(sbw[hi - 1] + sbw[hi - 2]));
+                c_out = mul < mu_lo || mul > mu_hi;
+                c_rb = fast_rcp(sbw[kc - 1]);                                     // (reciprocal + one correction: the divisions of :1618,1680 to an ulp)
+#ifdef MW_ABL_D_NOSWEXP
+                if (false) {
+#else
+                if (always_switch) {                                              // mc_lattice_switch's exponential after an accepted / a rejected move
+#endif
+                    const double dk = newl ? switch_dk(mn0l, mn1l, ls_c) : switch_dk(bk0, bk1, ls_c);
+                    exs = exp_any(-dk);
+                }
+                cur_lane = 2 * a;
+                MW_SW_ACC(10, MW_SW_NOW() - t0);
+            };
+            // eta_weight of a candidate from the three weights it touches (the serial step and the run: one expression)
+            auto eta_of = [&](double w_b, double w_h, double w_l) {
+                double val = interp ? __builtin_fma(c_m, w_h - w_l, w_b) : w_b;
+                val = c_out ? kHuge : val;
+                return in_win ? val : 0.0;                                        // (:913, G12: a 'dd' walker outside its window carries no weight)
+            };
+            // THE RUN (see the head of this routine).  Returns the first move it has NOT dealt with; `serial` says whether that move needs
+            // the serial step (otherwise the caller's own checks end the round or the run has simply reached the round's end).
+            // (Look-ahead builds only -- the handful of walkers whose speed is one chain's.  The builds that take one move at a time serve
+            //  thousands of walkers and are bound by the NUMBER of vector instructions issued: there the serial step, which skips what a
+            //  move does not need, issues ~100 fewer per move than the straight-line pass.  Both produce the same numbers, bit for bit.)
+            const bool run_on = SPEC > 1 && !samplerun && !swet && !dd && !minu;
+            bool need_pre = true;
+            auto run_of_moves = [&](int a, bool& serial) -> int {
+                [[maybe_unused]] const unsigned long long t0 = MW_SW_NOW();
+                const bool cand = lane >= 1 && lane <= 2 * SPEC && slot_l >= a && slot_l < ntr;
+                const bool kval = kl >= 1 && kl <= nb, kin = kl >= sb && kl <= eb;
+                const double incl = (avbw * wlf) * c_rb, visl = avbw * c_rb;      // :1680, :1618
+                // every rejection's visit, for the lanes of the later moves (the other lanes write a dump entry: no lane-masked region)
+                const int xi = (cand && !newl) ? slot_l : SPEC;
+                bx_k[xi] = kval ? kc : 0; bx_inc[xi] = incl; bx_vis[xi] = visl;
+                double w_b = sweight[c_b - 1], w_h = sweight[c_hi - 1], w_l = sweight[c_hi - 2];
+                double w_k = 0.0, h_k = 0.0;
+                if (record) { w_k = sweight[kc - 1]; h_k = shist[kc - 1]; }
+                const double u5 = U0[8 * slot_l + 5], u6 = U0[8 * slot_l + 6];
+                const unsigned depl = (scm[slot_l * NLAT] | scm[slot_l * NLAT + 1]) & accmask;
+                wave_fence();
+                // the rejections before this candidate, in the chain's order: `e` those before its eta_weight is looked up (for a
+                // "rejected" lane that includes its own move's: it is the NEXT move's current value), `o` those before its own visit
+                bool dup = false;                                                 // a later rejection of the run visits this lane's bin too
+                int kx[SPEC];
+                if (record) {
+#pragma unroll
+                    for (int j = 0; j < SPEC; ++j) {
+                        kx[j] = bx_k[j];
+                        const double ij = bx_inc[j], vj = bx_vis[j];
+                        const bool inr = cand && j >= a;
+                        const bool e = inr && (newl ? j < slot_l : j <= slot_l), o = inr && j < slot_l;
+                        w_b = (e && kx[j] == c_b) ? w_b + ij : w_b;
+                        w_h = (e && kx[j] == c_hi) ? w_h + ij : w_h;
+                        w_l = (e && kx[j] == c_hi - 1) ? w_l + ij : w_l;
+                        const bool hit = o && kx[j] == kc;
+                        w_k = hit ? w_k + ij : w_k;
+                        h_k = hit ? h_k + vj : h_k;
+                    }
+                }
+                // is this candidate's own visit the routine one?  the bin gains its increment, the window's minimum stays 0 (:1680-1685),
+                // no weight grows large
+                const double wn = w_k + incl;
+                const bool simple_l = !record || !kval || ((!kin || (w_k > 0.0 && wn >= 0.0)) && fabs(wn) < 1048576.0);
+                const double val = eta_of(w_b, w_h, w_l);
+                // what a move's new value replaces sits one lane down: the value the previous rejection restored, or the current one
+                const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(val), 0x138, 0xf, 0xf, false);      // wave_shr:1
+                const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(val), 0x138, 0xf, 0xf, false);
+                const double diffkT = dEb + val - __hiloint2double(hi, lo);      // :1116 (odd lanes)
+                const double ex = exp_any(-diffkT);
+                const double pacc = ex > 1.0 ? 1.0 : ex;
+                const bool okl = u5 < pacc;                                       // :1145-1146
+                bool swl = false, hard = false;                                   // the switch attempt after the move
+                if (always_switch) {
+                    const bool wall = in_win && c_out;
+                    const bool plain = !wall && (record || fabs(val) < 1048576.0);        // (record: every weight is small, and stays so)
+                    hard = !plain;
+                    const double cmp = exs > 1.0 ? 1.0 : exs;
+                    swl = plain && u6 < cmp;
+                }
+                const bool routine = simple_l && !swl && !hard;
+                // the first move of the run that does not go through as a routine rejection
+                const bool stopl = cand && (newl ? (depl != 0u || okl) : !routine);
+                const unsigned long long stops = __ballot(stopl);
+                const unsigned long long accs = __ballot(cand && newl && depl == 0u && okl && routine);
+                const unsigned long long deps = __ballot(cand && newl && depl != 0u);
+                const int lf = stops ? __ffsll((long long)stops) - 1 : 2 * ntr + 1;      // its lane
+                const int f = (lf - 1) >> 1;
+                const bool at_new = (lf & 1) != 0 && f < ntr;
+                const bool acc_f = at_new && ((accs >> lf) & 1ull) != 0ull;      // ... an accepted move of the routine kind: committed here too
+                serial = f < ntr && !acc_f && !(at_new && ((deps >> lf) & 1ull) != 0ull);
+                // commit: the rejections a .. f-1 (a bin visited twice keeps the later value), then the accepted move's visit
+                if (record) {
+#pragma unroll
+                    for (int j = 0; j < SPEC; ++j) dup = dup || (j > slot_l && j < f && kx[j] == kc);
+                    const bool wr = cand && !newl && slot_l < f && kval && !dup;
+                    double* pw = wr ? sweight + (kc - 1) : bx_dump;
+                    double* ph = wr ? shist + (kc - 1) : bx_dump + 1;
+                    *pw = wn; *ph = h_k + visl;
+                    if (acc_f) {
+                        wave_fence();
+                        const bool wa = lane == lf && kval;
+                        double* qw = wa ? sweight + (kc - 1) : bx_dump;
+                        double* qh = wa ? shist + (kc - 1) : bx_dump + 1;
+                        *qw = wn; *qh = h_k + visl;
+                    }
+                }
+                if (mvlog) {
+                    for (int j = a; j < (acc_f ? f + 1 : f); ++j) {
+                        const int lj = (acc_f && j == f) ? 2 * j + 1 : 2 * j + 2;
+                        const double dk_j = readlane_f64(diffkT, 2 * j + 1), mu_j = readlane_f64(mul, lj);
+                        if (lane == 0) {
+                            const int im = (int)__double_as_longlong(smv[(ub + j) * MVS + 3]);
+                            double* q = mvlog + ((size_t)blockIdx.x * nmoves + (size_t)(mvbase + j)) * 8;
+                            q[0] = (double)im; q[1] = (acc_f && j == f) ? 1.0 : 0.0;
+                            q[2] = sx[2 * (j * NLAT)]; q[3] = sx[2 * (j * NLAT) + 1]; q[4] = sx[2 * (j * NLAT + 1)]; q[5] = sx[2 * (j * NLAT + 1) + 1];
+                            q[6] = mu_j; q[7] = dk_j;
+                        }
+                    }
+                }
+                const int lz = acc_f ? lf : 2 * f;                                // the candidate the chain has reached
+                if (acc_f || f > a) {
+                    mu_c = readlane_f64(mul, lz); k_c = __builtin_amdgcn_readlane(kl, lz); k_val = 1; cur_lane = lz;
+                }
+                if (acc_f) {                                                      // :1150-1170
+                    bk0 = readlane_f64(mn0l, lf); bk1 = readlane_f64(mn1l, lf);
+                    ++acc_d; accmask |= 1u << f; need_pre = true;
+                }
+                wave_fence();
+                MW_SW_ACC(12, MW_SW_NOW() - t0); MW_SW_ACC(9, (unsigned long long)((acc_f ? f + 1 : f) - a)); MW_SW_ACC(16, 1ull);
+                return acc_f ? f + 1 : f;
+            };
+            int s = 0;
+            while (s < ntr) {                                                     // the decisions, in the chain's order
+                // (an evaluation that no longer stands ends the round: the next one starts with that move)
+                if (s > 0 && (((scm[s * NLAT] | scm[s * NLAT + 1]) & accmask) != 0u || ls_c != ls)) break;
+                if (need_pre) { prephase(s); need_pre = false; }
+                if constexpr (SPEC > 1) {
+                    if (run_on && (!record || (cur_min == 0.0 && tab_small))) {
+                        bool serial = false;
+                        const int f = run_of_moves(s, serial);
+                        nvalid += f - s; s = f;
+                        if (!serial) continue;                                    // (the loop's head ends the round, or goes on after an accepted move)
+                    }
+                }
+                [[maybe_unused]] const unsigned long long t1 = MW_SW_NOW();
+                const double* U = U0 + 8 * s;
+                if (dd && within == 0) {                                          // top of a cycle: the equilibration check of mc_cycle (:181-210)
+                    if (cyc < C.eq_cycles) in_win = (mu_c > mu_lo && mu_c < mu_hi) ? 1 : 0;
+                    else if (cyc == C.eq_cycles) { if (!in_win) flag_d |= 2; }    // "Not all walkers have reached their designated window"
+                    else in_win = 1;                                              // a restart
+                    if (lane == 0) C.mg.in_window = in_win;
+                    wave_fence();
+                }
+                const bool do_switch = always_switch && !(dd && cyc < C.eq_cycles);     // (:243-248: not while a 'dd' run equilibrates)
+                // the weights every candidate touches, as the earlier moves of the round have left them: one round trip
+                const double w_b = sweight[c_b - 1], w_h = sweight[c_hi - 1], w_l = sweight[c_hi - 2], w_k = sweight[kc - 1];
+                const double val = eta_of(w_b, w_h, w_l);
+                const int ln = 2 * s + 1, lr = 2 * s + 2;
+                const double eta_new = readlane_f64(val, ln), eta_rev = readlane_f64(val, lr), eta_old = readlane_f64(val, cur_lane);
+                double diffkT = readlane_f64(dEb, ln) + eta_new - eta_old;        // :1116
+                int minu_ls = ls_c;
+                double cmpA_minu = 0.0;
+                if (minu) {                                                       // :1119-1140
+                    const double mn0 = readlane_f64(mn0l, ln), mn1 = readlane_f64(mn1l, ln);
+                    minu_ls = dev_minu_branch(C, ls_c, mn0, mn1, svol[0], svol[1], ls_c == 1 ? bk0 : bk1, ls_c == 1 ? svol[0] : svol[1],
+                                              C.npt != 0, N, eta_new, eta_old, diffkT);
+                    if (minu_ls != ls_c && always_switch) cmpA_minu = exp_any(-switch_dk(mn0, mn1, minu_ls));
+                }
+                // lane 0: the acceptance; lanes 1, 2: the unbiased histogram's factor after an accepted / a rejected move (:1627-1629)
+                const double xarg = lane == 0 ? -diffkT : (lane == 1 ? eta_new - lun : eta_rev - lun);
+#ifdef MW_ABL_D_NOEXP
+                const double ex = 0.1 + 0.01 * xarg;
+#else
+                const double ex = exp_any(xarg);
+#endif
+                double pacc = readlane_f64(ex, 0);
+                pacc = pacc > 1.0 ? 1.0 : pacc;
+                const bool ok = U[5] < pacc;                                      // :1145-1146 (false for NaN)
+                const int cl = ok ? ln : lr;
+                double eta_fin, cmp_sw = 0.0, ufac = 0.0;
+                if (ok) {                                                         // :1150-1170
+                    ++acc_d; accmask |= 1u << s; need_pre = true;
+                    if (do_switch) cmp_sw = minu_ls != ls_c ? cmpA_minu : readlane_f64(exs, ln);
+                    ls_c = minu_ls;
+                    bk0 = readlane_f64(mn0l, ln); bk1 = readlane_f64(mn1l, ln);   // :1016,1087
+                    eta_fin = eta_new;
+                    if (samplerun) ufac = readlane_f64(ex, 1);
+                } else {                                                          // :1182-1195
+                    if (do_switch) cmp_sw = readlane_f64(exs, lr);
+                    eta_fin = eta_rev;
+                    if (samplerun) ufac = readlane_f64(ex, 2);
+                }
+                mu_c = readlane_f64(mul, cl);
+                k_c = __builtin_amdgcn_readlane(kl, cl); k_val = 1;
+                cur_lane = cl;
+                [[maybe_unused]] const unsigned long long t2 = MW_SW_NOW();
+                MW_SW_ACC(11, t2 - t1);
+                // ---- mc_update_wl_bins (:1597-1689) on the walker's tables --------------------------------------------------
+#ifdef MW_ABL_D_NOWL
+                if (false) {
+#else
+                if (record) {
+#endif
+                    const int k = k_c;
+                    if (k >= 1 && k <= nb) {
+                        const double rbk = readlane_f64(c_rb, cl);
+                        const double visit = avbw * rbk;                                          // :1618
+                        if (samplerun) {
+                            if (lane == 0) {
+                                shist[k - 1] = shist[k - 1] + visit;                              // :1621
+                                suhist[k - 1] = suhist[k - 1] + visit * ufac;                     // :1627-1629
+                            }
+                        } else {
+                            double inc = (avbw * wlf) * rbk;                                      // :1680
+                            if (swet) {                                           // :1636-1653
+                                const double sumh = C.sumh + 1.0;
+                                double a2 = 0.0;
+                                const double span = C.mu_max - C.mu_min - 1.0;
+                                int lane_s = lane;
+                                asm volatile("" : "+v"(lane_s));
+                                for (int b = lane_s; b < nb; b += 64) {
+                                    const double hb = shist[b] + (b == k - 1 ? visit : 0.0);      // this move's visit is already counted (:1621)
+                                    const double dev = hb * sbw[b] / sumh - sbw[b] / span;
+                                    a2 += dev * dev;
+                                }
+                                a2 = readlane_f64(dpp_wave_sum(a2), 63);
+                                double f = sqrt(a2 / (double)nb);
+                                f = log(f) * C.wl_alpha * (double)nb;
+                                wlf = f < C.orig_wl_factor ? f : C.orig_wl_factor;
+                                if (lane == 0) C.sumh = sumh;
+                                inc = (avbw * wlf) * rbk;
+                            }
+                            // weight(k) += av_binwidth*wl_factor/binwidth(k) -- whichever bin k is (:1680); then the minimum over the
+                            // walker's window is subtracted inside the window (:1682-1685; with 'dd' windows k may lie outside).
+                            // The minimum is TRACKED: it is 0 after the first update, and it only moves when the visited bin was
+                            // (one of) the lowest -- then, and only then, the window is scanned.
+                            const double wk = readlane_f64(w_k, cl);
+                            const bool k_in = k >= sb && k <= eb;
+                            double mn;
+                            bool scan = false;
+                            if (!k_in) mn = cur_min;
+                            else if (wk > cur_min) { const double wn = wk + inc; mn = wn < cur_min ? wn : cur_min; }
+                            else { scan = true; mn = kHuge; }
+                            if (scan) {
+                                for (int b = sb - 1 + lane; b < eb; b += 64) {
+                                    double w = sweight[b];
+                                    if (b == k - 1) w = w + inc;
+                                    mn = w < mn ? w : mn;
+                                }
+                                mn = readlane_f64(dpp_wave_min(mn), 63);
+                            }
+                            if (mn != 0.0) {
+                                wave_fence();
+                                for (int b = sb - 1 + lane; b < eb; b += 64) {
+                                    double w = sweight[b];
+                                    if (b == k - 1) w = w + inc;
+                                    sweight[b] = w - mn;
+                                }
+                                if (lane == 0 && !k_in) sweight[k - 1] = sweight[k - 1] + inc;
+                                wave_fence();
+                                tab_small = all_weights_small();                  // (the window was re-gauged: rare)
+                            } else {
+                                const double w_upd = k_in ? (wk + inc) - mn : wk + inc;
+                                if (lane == 0) sweight[k - 1] = w_upd;
+                                tab_small = tab_small && fabs(w_upd) < 1048576.0;
+                            }
+                            cur_min = 0.0;                                        // the lowest bin of the window is now exactly mn - mn
+                            gauge = gauge + mn;
+                            if (lane == 0) shist[k - 1] = shist[k - 1] + visit;
+                        }
+                        wave_fence();
+                    }
+                }
+                [[maybe_unused]] const unsigned long long t3 = MW_SW_NOW();
+                MW_SW_ACC(13, t3 - t2);
+                // ---- one mc_lattice_switch attempt (:1536-1594) -----------------------------------------------------------------
+                int sw = 0;
+#ifdef MW_ABL_D_NOSW
+                if (false) {
+#else
+                if (do_switch) {
+#endif
+                    // new_eta - old_eta of the switch (:1557-1558) = eta_weight(ls_mu) - eta_weight(ls_mu) with the weights as they are NOW,
+                    // added to the energy terms ONE AFTER THE OTHER (:1561-1563): (x + eta) - eta.  For a modest eta that is x to a rounding
+                    // residue below 1.2e-10 (|eta| < 2^20) and the exponential computed ahead (cmp_sw) stands.  A large eta absorbs x --
+                    // above all the hard wall of a walker OUTSIDE its order-parameter range, eta = huge(1.0_dp): the difference is then
+                    // exactly 0 and the reference always switches.  There the expression is evaluated as the reference writes it.
+                    double cmp = cmp_sw, ew = 0.0;
+                    const bool wall = in_win && (mu_c < mu_lo || mu_c > mu_hi);
+                    bool plain;
+                    if (samplerun || !record) { ew = eta_fin; plain = !wall && fabs(ew) < 1048576.0; }
+                    else if (tab_small) plain = !wall;                            // (every weight is small: so are the three the interpolation can touch)
+                    else {                                                        // a large weight somewhere: the three around the bin, as they are now
+                        const int k = k_c < 2 ? 2 : (k_c > nb - 1 ? nb - 1 : k_c);
+                        plain = !wall && fabs(sweight[k - 2]) < 1048576.0 && fabs(sweight[k - 1]) < 1048576.0 && fabs(sweight[k]) < 1048576.0;   // (interpolation stays between its nodes' weights)
+                    }
+                    if (!plain) {
+                        if (!(samplerun || !record)) ew = lane_eta(C.mg, sweight, smub, sbw, mu_c, k_c);
+                        double lesh;
+                        double d = switch_dk_terms(bk0, bk1, ls_c, lesh);
+                        d = d + ew;
+                        d = d - ew;
+                        d = d + lesh;
+                        cmp = exp_any(-d);                                        // (NaN for weights that are not finite: no switch)
+                    }
+                    cmp = cmp > 1.0 ? 1.0 : cmp;
+                    if (U[6] < cmp) {
+                        const double V1 = svol[0], V2 = svol[1];
+                        double mu = (bk0 + C.pressure * V1) - (bk1 + C.pressure * V2);            // :1581-1583
+                        mu = mu - C.dref;                                                         // :1584 (leshift)
+                        mu = mu * beta - (double)N * C.lgv12;
+                        sw = 1;
+                        mu_c = mu; ls_c = 3 - ls_c; ++nsw_d; k_val = 0;
+                    }
+                }
+                if (lane == 0) {
+                    if (mvlog) {
+                        const int im = (int)__double_as_longlong(smv[(ub + s) * MVS + 3]);
+                        double* q = mvlog + ((size_t)blockIdx.x * nmoves + (size_t)(mvbase + s)) * 8;
+                        q[0] = (double)im; q[1] = (ok ? 1.0 : 0.0) + 2.0 * sw;
+                        q[2] = sx[2 * (s * NLAT)]; q[3] = sx[2 * (s * NLAT) + 1]; q[4] = sx[2 * (s * NLAT + 1)]; q[5] = sx[2 * (s * NLAT + 1) + 1];
+                        q[6] = mu_c; q[7] = diffkT;
+                    }
+                }
+                if (dd) { const int w = within + 1; if (w == N) { within = 0; cyc = cyc + 1; } else within = w; }
+                MW_SW_ACC(14, MW_SW_NOW() - t3);
+                ++nvalid; ++s;
+            }
             if (lane == 0) {
-                C.acc = C.acc + 1; C.ls = minu_ls; C.men0 = mn0; C.men1 = mn1;
-                if (L == 2) { C.ls_mu = mu_new; C.k_cur = k_new; C.k_valid = 1; }
+                C.men0 = bk0; C.men1 = bk1; C.ls_mu = mu_c; C.cur_min = cur_min; C.wlf = wlf; C.gauge = gauge;
+                C.k_cur = k_c; C.k_valid = k_val; C.acc = C.acc + acc_d; C.nsw = C.nsw + nsw_d; C.tab_small = tab_small ? 1 : 0;
+                if (flag_d) C.flag = C.flag | flag_d;
+                if (dd) { C.cyc = cyc; C.within = within; }
             }
-            eta_fin = eta_new; cmp_sw = readlane_f64(ex, 1); ufac = readlane_f64(ex, 3);
-        } else {                                                                  // :1182-1195
-            if (L == 2 && lane == 0) { C.ls_mu = mu_rev; C.k_cur = k_rev; C.k_valid = 1; }
-            eta_fin = eta_rev; cmp_sw = readlane_f64(ex, 2); ufac = readlane_f64(ex, 4);
         }
-        wave_sync();
-        [[maybe_unused]] const unsigned long long sw_d2 = MW_SW_NOW();
-        MW_SW_ACC(11, sw_d2 - sw_d1);
-        int sw = 0;
-        if (L == 2) sw = post_move(eta_fin, cmp_sw, ufac, do_switch, U[6]);
-        [[maybe_unused]] const unsigned long long sw_d3 = MW_SW_NOW();
-        MW_SW_ACC(12, sw_d3 - sw_d2);
         if (lane == 0) {
-            if (mvlog) {
-                double* q = mvlog + ((size_t)blockIdx.x * nmoves + movenum) * 8;
-                q[0] = (double)imol; q[1] = (ok ? 1.0 : 0.0) + 2.0 * sw; q[2] = eo0; q[3] = en0; q[4] = eo1; q[5] = en1; q[6] = C.ls_mu; q[7] = diffkT;
-            }
-            if (C.dd) { const int w = C.within + 1; if (w == N) { C.within = 0; C.cyc = C.cyc + 1; } else C.within = w; }
+            C.ls = ls_c;
+            sdec[0] = nvalid; sdec[1] = ls_c;
+#pragma unroll
+            for (int s = 0; s < SPEC; ++s) sdec[4 + s] = (int)((accmask >> s) & 1u);
         }
-        wave_sync();
-        MW_SW_ACC(15, MW_SW_NOW() - sw_d3);
-        return ok;
+        wave_fence();
     };
 
     constexpr int kUB = sweep_batch(WITHVOL);
@@ -1052,8 +1439,12 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             }
             MoveRes res;
             unsigned cme = 0u;
+#ifdef MW_ABL_NOEVAL         // diagnostic build: no evaluation (energies 0) -- the decisions' share of a round
+            const bool fast = true; res.eo = 0.0; res.en = 1e-3 * (double)(i & 7); res.io = res.in_ = res.so = res.sn = 0u;
+#else
             const bool fast = move_energy_wave<true, SPEC - 1>(getpos, getiv, row, nnof, ws, sniv[l], i, nnof(i), row(i, lane & 31), xo, yo, zo,
                                                                pnx, pny, pnz, lane, res, oth, &cme);
+#endif
             cm |= cme;
             if (!fast) {
                 Override none; none.idx = -1; none.x = none.y = none.z = 0.0;
@@ -1068,25 +1459,11 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         wg_sync<NW>();                                 // every evaluation of the round is in (one wavefront: nothing of the walker's state is read ahead of it)
         [[maybe_unused]] const unsigned long long sw_b = MW_SW_NOW();
         MW_SW_ACC(0, sw_e - sw_r0); MW_SW_ACC(1, sw_b - sw_e);
-        if (wv == 0) {
-            unsigned accmask = 0u;
-            int nvalid = 0;
-            for (int s = 0; s < ntr; ++s) {            // the decisions, in the chain's order
-                if (s > 0) {
-                    const unsigned dep = scm[s * NLAT] | (L == 2 ? scm[s * NLAT + (L - 1)] : 0u);
-                    if ((dep & accmask) != 0u || C.ls != ls) break;     // that evaluation no longer stands: the next round starts with it
-                }
-                const int im = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(smv[(ub + s) * MVS + 3]));
-                const bool ok = decide_trans(s, U0 + 8 * s, im, (unsigned long long)(mv + s));
-                if (ok) accmask |= 1u << s;
-                ++nvalid;
-            }
-            if (lane == 0) {
-                sdec[0] = nvalid; sdec[1] = C.ls;
-#pragma unroll
-                for (int s = 0; s < SPEC; ++s) sdec[4 + s] = (int)((accmask >> s) & 1u);
-            }
-        }
+#ifdef MW_ABL_NODECIDE       // diagnostic build (tools/variants.py): every move rejected without a decision -- the evaluation's share of a round
+        if (wv == 0 && lane == 0) { sdec[0] = ntr; sdec[1] = ls; for (int s = 0; s < SPEC; ++s) sdec[4 + s] = 0; }
+#else
+        if (wv == 0) decide_round(ntr, ub, U0, mv);
+#endif
         [[maybe_unused]] const unsigned long long sw_d = MW_SW_NOW();
         MW_SW_ACC(2, sw_d - sw_b);
         if (NW > 1) wg_sync<NW>(); else wave_sync();

@@ -91,12 +91,12 @@ def test_comms_library_exports_every_declared_symbol():
     L = ctypes.CDLL(build.build_comms())
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mw_comms.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(mw_comms_[a-z_0-9]+)\s*\(", text)))
-    assert len(names) == 12
+    assert len(names) == 13
     for name in names:
         assert hasattr(L, name), f"libmw_comms.so does not export {name}"
     L.mw_comms_last_error.restype = ctypes.c_char_p
     assert L.mw_comms_barrier() != 0 and b"mw_comms_init first" in L.mw_comms_last_error()
-    assert L.mw_comms_finalize() == 0                       # nothing to tear down is not an error
+    assert L.mw_comms_finalize() == 0 and L.mw_comms_abort() == 0     # nothing to tear down is not an error
 
 
 def test_comms_bootstrap_skips_an_id_file_whose_writer_is_gone(tmp_path):

@@ -1,7 +1,11 @@
-"""CPU: what the compiler made of the Monte Carlo driver (k_sweep).  Its design point is a register budget -- four
-wavefronts per SIMD (<= 128 VGPRs; three, <= 168, only for two lattices + look-ahead + mc_volume) --
-and NO register spills to scratch: a build of this kernel that spilled vector registers faulted on the GPU (round 3), and
-which side of the budget the allocator lands on moves with unrelated code in the same translation unit."""
+"""CPU: what the compiler made of the Monte Carlo driver (k_sweep).  Its design point is a register budget: four wavefronts per
+SIMD (<= 128 VGPRs) for the builds that take one move at a time -- thousands of walkers, bound by instruction issue -- and three
+(<= 168) for two lattices with look-ahead, the handful of walkers whose speed is one chain's.  Which side of the budget the
+allocator lands on moves with unrelated code in the same translation unit, so the budget is pinned (`amdgpu_waves_per_eu`) and
+this test holds the code object to it.  A few spilled registers are a cost, not an error: round 3 recorded a GPU fault of a
+spilling build and forbade spills; round 4 ran the whole driver suite on a build capped at 80 registers (13-44 spilled per
+instantiation, tools/variants.py spill6): 107 tests green -- the fault of that day was k_cell_pairs' (DESIGN.md 3.3).  What is
+held here is the performance guard: no more than a handful of spilled vector registers in any build."""
 import os
 import re
 import struct
@@ -46,8 +50,8 @@ def test_sweep_kernels_keep_their_register_budget(tmp_path):
             continue
         seen += 1
         get = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1))     # noqa: E731
-        three = m.group(5) == "1" and m.group(1) == "2" and m.group(2) != "1"     # volume moves + two lattices + look-ahead
-        assert get("vgpr_spill_count") == 0 and get("private_segment_fixed_size") == 0, name
+        three = m.group(1) == "2" and m.group(2) != "1"                           # two lattices + look-ahead
+        assert get("vgpr_spill_count") <= 8, (name, get("vgpr_spill_count"))
         assert get("vgpr_count") <= (168 if three else 128), (name, get("vgpr_count"))
     assert seen == 36          # lattices x residency x with / without volume moves, + look-ahead 2 / 4 for walkers in global memory
                                # and for walkers entirely or partly in LDS

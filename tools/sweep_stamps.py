@@ -22,7 +22,7 @@ from mc_water_ls_mw_amd import lattice as lat  # noqa: E402
 from mc_water_ls_mw_amd.energy import EnergyModule, load_library  # noqa: E402
 from mc_water_ls_mw_amd.sweep import MuGrid, WalkerFarm  # noqa: E402
 
-PHASES = {0: "round: own evaluation", 1: "round: wait for the other wavefronts", 2: "round: decisions", 3: "round: commit + barrier",
+PHASES = {12: "bulk pass", 0: "round: own evaluation", 1: "round: wait for the other wavefronts", 2: "round: decisions", 3: "round: commit + barrier",
           6: "uniforms", 10: "decide: mu, bins, eta", 11: "decide: exp, accept, state", 12: "decide: post_move", 13: "post_move: WL update",
           14: "post_move: switch", 15: "decide: log + tail"}
 STAGES = {17: "eval: pass 0 gathers + in-range", 18: "eval: compaction, marks", 19: "eval: row fetch issue + pair terms + records",
@@ -70,6 +70,7 @@ def case(name, cells, nlat, walkers, nmoves, wl=False, npt=False, sigma=0.05, mu
                "moves_per_round": moves / max(rounds, 1.0), "kernel_us_per_move_stamped": st[7] / cyc_per_us / nmoves}
         for k, label in PHASES.items():
             rec[label + " [us/move]"] = st[k] / cyc_per_us / max(moves, 1.0)
+        rec["bulk: calls, moves committed, slots predicted, stop bits"] = [st[16], st[9], st[32], st[33]]
         rec["evaluation stages of wavefront 0 [us per evaluation]"] = {label: st[k] / cyc_per_us / max(rounds, 1.0) for k, label in STAGES.items()}
         out["look-ahead " + ahead] = rec
         em.energy_deinit()

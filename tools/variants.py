@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mc_water_ls_mw_amd import build as mwbuild  # noqa: E402
 
-KNOWN = {"stamps": ["-DMW_SWEEP_STAMPS"], "spill": ["-DMW_SWEEP_WAVES_CAP=5"]}
+KNOWN = {"stamps": ["-DMW_SWEEP_STAMPS"], "spill": ["-DMW_SWEEP_WAVES_CAP=5"],
+         "nodecide": ["-DMW_ABL_NODECIDE"], "noeval": ["-DMW_ABL_NOEVAL"]}
 
 
 def path(name):
