@@ -117,7 +117,7 @@ struct Ctx {
     int* d_winflag = nullptr;                    // [walker] walker_in_window
     double* d_wstep = nullptr;                   // [walker][2] max_trans, dv_max (bohr) when the walkers' step sizes differ (mw_sweep_steps)
     bool has_steps = false;
-    int sweep_log_ahead = 4;                     // look-ahead allowed when the move log is on (tests pin it to compare builds)
+    int sweep_log_ahead = 8;                     // look-ahead allowed when the move log is on (tests pin it to compare builds)
     bool has_windows = false;
     double* d_volume = nullptr;                  // [box] |det hmatrix|
     int* d_wls = nullptr;
@@ -570,7 +570,10 @@ static const void* sweep_kernel(int nlat, int residency, bool withvol, int spec)
          {MW_SWEEP_K(1, 4, true, false, false), MW_SWEEP_K(1, 4, true, false, true)}},
         {{MW_SWEEP_K(2, 2, true, false, false), MW_SWEEP_K(2, 2, true, false, true)},
          {MW_SWEEP_K(2, 4, true, false, false), MW_SWEEP_K(2, 4, true, false, true)}}};
+    static const void* const ahead8[2] = {            // eight moves in flight: ONE lattice, walkers in global memory (a 4096-molecule box or a few of them)
+        MW_SWEEP_K(1, 8, false, false, false), MW_SWEEP_K(1, 8, false, false, true)};
 #undef MW_SWEEP_K
+    if (spec == 8) return (nlat == 1 && residency == 0) ? ahead8[withvol ? 1 : 0] : nullptr;
     if (spec > 1 && residency == 0) return ahead[nlat - 1][spec == 4 ? 1 : 0][withvol ? 1 : 0];
     if (spec > 1 && residency == 1) return ahead_pos[nlat - 1][spec == 4 ? 1 : 0][withvol ? 1 : 0];
     if (spec > 1 && residency == 2) return ahead_lds[nlat - 1][spec == 4 ? 1 : 0][withvol ? 1 : 0];
@@ -760,6 +763,8 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
         HIPCHK(hipFuncSetAttribute(sweep_kernel(1 + (v & 1), (v >> 1) % 3, v >= 6, 1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
     for (int v = 0; v < 24; ++v)
         HIPCHK(hipFuncSetAttribute(sweep_kernel(1 + (v & 1), v >> 3, (v & 2) != 0, (v & 4) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+    for (int v = 0; v < 2; ++v)
+        HIPCHK(hipFuncSetAttribute(sweep_kernel(1, 0, v != 0, 8), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
     g.live = true;
     return 0;
 }
@@ -2048,10 +2053,13 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
             return (long long)count <= (long long)g.cu * per_cu;
         };
         spec = all_resident(4) ? 4 : (all_resident(2) ? 2 : 1);
-        if (const char* e = getenv("MW_SWEEP_AHEAD")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) spec = v; }
+        // eight in flight for one-lattice walkers in global memory (large boxes: consecutive moves seldom touch the same molecules)
+        const bool has8 = L == 1 && !ldspos;
+        if (has8 && all_resident(8)) spec = 8;
+        if (const char* e = getenv("MW_SWEEP_AHEAD")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || (v == 8 && has8)) spec = v; }
         if (want_log) spec = std::min(spec, g.sweep_log_ahead);
     }
-    const mw::SweepLds lay = mw::sweep_lds(L, L * spec, g.ivcap, g.N, g.sp.nbins, ldspos, ldslist, rstride, withvol, g.sp.samplerun != 0);
+    const mw::SweepLds lay = mw::sweep_lds(L, L * spec, g.ivcap, g.N, g.sp.nbins, ldspos, ldslist, rstride, withvol, g.sp.samplerun != 0, spec);
     const size_t static_lds = 1536;                  // cells and their backups, hand-over words, the walker's control block (generous bound)
     if (lay.total + static_lds > (size_t)160 * 1024 - 8 * 1024)
         return fail("mw_sweep: %u bytes of LDS per walker (image vectors %u, positions %u, list rows %u) exceed what a workgroup may have",

@@ -279,7 +279,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
                                                  double xn, double yn, double zn, int lane, MoveRes& res,
                                                  const int* oth = nullptr, unsigned* cmask = nullptr)
 {
-    unsigned cm = 0u;
+    unsigned cm = 0u;                  // (per lane until the end: one wave-wide OR per evaluation, not a ballot per gather step and slot)
 #ifdef MW_SWEEP_STAMPS
     unsigned long long mw_tprev = 0ull;
 #endif
@@ -296,7 +296,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     if (SELFIMG && __ballot(has && j == i) != 0ull) return false;
     if constexpr (NOTH > 0) {
 #pragma unroll
-        for (int o = 0; o < NOTH; ++o) if (__ballot(has && j == oth[o]) != 0ull) cm |= 1u << o;
+        for (int o = 0; o < NOTH; ++o) cm |= (has && j == oth[o]) ? 1u << o : 0u;
     }
     double xj, yj, zj, jvx, jvy, jvz;
     getpos(j, xj, yj, zj);
@@ -498,7 +498,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
         const int kk = (int)(e2 & kJMask), k2 = (int)(e2 >> kJBits);
         if constexpr (NOTH > 0) {
 #pragma unroll
-            for (int o = 0; o < NOTH; ++o) if (__ballot(valid && kk == oth[o]) != 0ull) cm |= 1u << o;
+            for (int o = 0; o < NOTH; ++o) cm |= (valid && kk == oth[o]) ? 1u << o : 0u;
         }
         double xk, yk, zk, kvx, kvy, kvz;
         getpos(kk, xk, yk, zk);
@@ -557,7 +557,16 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     res.eo = eo; res.en = en;
     res.io = (unsigned int)__popc(mo_) + nto; res.in_ = (unsigned int)__popc(mn_) + ntn;
     res.so = so; res.sn = sn;
-    if constexpr (NOTH > 0) *cmask = cm;
+    if constexpr (NOTH > 0) {          // OR over the lanes, on the DPP network
+        unsigned v = cm;
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);      // row_shr:4
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);      // row_shr:8
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);      // row_bcast:15 into rows 1 and 3
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);      // row_bcast:31 into rows 2 and 3
+        *cmask = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+    }
     MW_STAMP(7);
     return true;
 }

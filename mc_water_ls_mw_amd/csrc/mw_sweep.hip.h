@@ -278,7 +278,7 @@ __device__ __forceinline__ void wave_sync()
 
 // moves per batch of uniforms (Philox calls are lanes of one pass): 16, or 8 for the builds with volume moves -- 512 B of LDS that an
 // NPT walker of the reference's examples does not have (sweep_lds); the smaller batch costs the translation-only build ~2 %
-__host__ __device__ constexpr int sweep_batch(bool withvol) { return withvol ? 8 : 16; }
+__host__ __device__ constexpr int sweep_batch(bool withvol, int spec = 1) { return spec > (withvol ? 8 : 16) ? spec : (withvol ? 8 : 16); }
 constexpr unsigned kSweepScratch = (unsigned)((sizeof(WaveScratch) + 15) & ~(size_t)15);
 constexpr unsigned kSweepScratchVol = (unsigned)(((kSweepQCap + 1) * 64 * sizeof(uint32_t)) > kSweepScratch ? ((kSweepQCap + 1) * 64 * sizeof(uint32_t)) : kSweepScratch);
 static_assert(kSweepScratchVol == kSweepScratch, "the builds with volume moves take no more LDS per wavefront than the others");
@@ -288,14 +288,14 @@ static_assert(kSweepScratchVol == kSweepScratch, "the builds with volume moves t
 // LDS stays within 160 KiB / 8 = 20480 B (mw_sweep_translation_launch).
 struct SweepLds { unsigned iv, pos, tab, uni, mv, scr, row, nn, total, scr_bytes; };
 __host__ __device__ inline SweepLds sweep_lds(int L, int nw, int ivcap, int N, int nbins, bool ldspos, bool ldslist, int rstride, bool withvol,
-                                              bool samplerun)
+                                              bool samplerun, int spec = 1)
 {
     SweepLds o;
     unsigned p = 0;
     o.iv = p;  p += (unsigned)L * ivcap * 24u;                         // image vectors [L][ivcap][3]
     o.pos = p; p += ldspos ? (unsigned)L * N * 24u : 0u;               // positions     [L][N][3]     (small systems)
     o.tab = p; p += L == 2 ? (samplerun ? 5u : 4u) * nbins * 8u : 0u;  // weight, mu_bin, binwidth, histogram; unbiased_hist in a sample run only
-    o.uni = p; p += (unsigned)sweep_batch(withvol) * 8u * 8u;          // uniforms of a batch of moves [kUB][8]
+    o.uni = p; p += (unsigned)sweep_batch(withvol, spec) * 8u * 8u;    // uniforms of a batch of moves [kUB][8]
     o.mv = o.uni;                                                      // a translation's molecule + displacement {x, y, z, imol}: written over its
                                                                        // spent uniforms u0..u3 (a volume move keeps its own: it reads them again)
     p = (p + 15u) & ~15u;
@@ -513,7 +513,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
     const int wlk = walker0 + blockIdx.x;
     const int box0 = wlk * L;
     const int nbins = sp.nbins;
-    const SweepLds lay = sweep_lds(L, NW, ivcap, N, nbins, LDSPOS, LDSLIST, rstride, WITHVOL, sp.samplerun != 0);
+    const SweepLds lay = sweep_lds(L, NW, ivcap, N, nbins, LDSPOS, LDSLIST, rstride, WITHVOL, sp.samplerun != 0, SPEC);
     double* siv = reinterpret_cast<double*>(smem_raw + lay.iv);
     double* spos = reinterpret_cast<double*>(smem_raw + lay.pos);
     double* sweight = reinterpret_cast<double*>(smem_raw + lay.tab);
@@ -1230,7 +1230,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         wave_fence();
     };
 
-    constexpr int kUB = sweep_batch(WITHVOL);
+    constexpr int kUB = sweep_batch(WITHVOL, SPEC);
     int mv = 0, ubase = -kUB;                    // next move of the chain (counted within the launch); first move of the uniforms' window
     while (mv < nmoves) {
         [[maybe_unused]] const unsigned long long sw_u0 = MW_SW_NOW();

@@ -680,7 +680,7 @@ def test_lookahead_is_the_sequential_chain(case, monkeypatch):
 
     ref = run(1)
     assert 20 < ref[0][0][:, 1].astype(int).__and__(1).sum() < 380         # moves are accepted and rejected
-    for ahead in (2, 4):
+    for ahead in (2, 4) + ((8,) if case.startswith("ih1000") else ()):     # (eight in flight: one-lattice walkers in global memory)
         got = run(ahead)
         assert np.array_equal(got[0], ref[0])
         for a, b in zip(got[1], ref[1]):
@@ -808,9 +808,9 @@ def test_lookahead_on_awkward_boxes(kind, so, monkeypatch):
 @pytest.mark.parametrize("residency", [0, 1, 2])
 @pytest.mark.parametrize("npt", [False, True])
 def test_every_build_of_the_driver_runs_the_same_chain(nlat, residency, npt, monkeypatch):
-    """The 36 instantiations of k_sweep -- lattices x where a walker's data live x with / without volume moves x 1, 2 or 4 moves in
-    flight -- each actually launched (mw_sweep_last_launch says which build a launch took) and, for the same walkers, 2 and 4 moves
-    in flight reproduce the one-move-at-a-time chain bit for bit."""
+    """The 38 instantiations of k_sweep -- lattices x where a walker's data live x with / without volume moves x 1, 2 or 4 moves in
+    flight, and 8 for one-lattice walkers in global memory -- each actually launched (mw_sweep_last_launch says which build a launch
+    took) and, for the same walkers, 2, 4 (and 8) moves in flight reproduce the one-move-at-a-time chain bit for bit."""
     from mc_water_ls_mw_amd import lattice as lat
     from mc_water_ls_mw_amd.energy import load_boxes
     from mc_water_ls_mw_amd.sweep import MuGrid, WalkerFarm
@@ -847,7 +847,7 @@ def test_every_build_of_the_driver_runs_the_same_chain(nlat, residency, npt, mon
 
     ref = run(1)
     assert 5 < int((ref[0][0][:, 1].astype(int) & 1).sum()) < 195
-    for ahead in (2, 4):
+    for ahead in (2, 4) + ((8,) if nlat == 1 and residency == 0 else ()):
         got = run(ahead)
         assert np.array_equal(got[0], ref[0], equal_nan=True)
         assert all(np.array_equal(a, b) for a, b in zip(got[1], ref[1])) and got[2] == ref[2]
