@@ -306,6 +306,156 @@ def secondary_measurements(device):
     return out
 
 
+# ---- the production driver (k_sweep, the replica farm) in the driver-run line --------------------------------------
+def load_sweep_counters():
+    """profiles/sweep_counters.json: SQ_INSTS_VALU per move of k_sweep per case (tools/sweep_counters.sh: rocprofv3 --pmc over this
+    binary; the count is exact for a given chain), keyed by case name."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "sweep_counters.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+def sweep_roofline(case, moves, kernel_ms, counters):
+    """k_sweep against the ceiling that binds it, FP64 VALU issue (every counter pass of rounds 3-4: VALU busy 0.5-0.7, HBM traffic
+    ~50 B per move on the LDS-resident cases): wave64 vector instructions per move from the committed counter pass of this case
+    x moves of this run / the LIVE in-kernel time, against 1024 SIMDs x 2.4 GHz / 4."""
+    c = counters.get(case)
+    r = {"kernel": "k_sweep", "case": case, "bound": "valu" if c else "unknown: no counter summary for this case under profiles/",
+         "achieved": None, "peak": VALU_F64_PEAK / 1e9, "unit": "G wave64-instructions/s (FP64 VALU issue)", "frac": None, "traffic": None,
+         "kernel_ms": kernel_ms}
+    if c and kernel_ms:
+        r["valu_insts_per_move"] = c["SQ_INSTS_VALU_per_move"]
+        r["achieved"] = c["SQ_INSTS_VALU_per_move"] * moves / (kernel_ms * 1e-3) / 1e9
+        r["frac"] = r["achieved"] / r["peak"]
+        r["traffic"] = c.get("hbm_bytes_per_move")
+        r["counters_tag"] = counters.get("tag")
+    return r
+
+
+def chain_self_check(device, name):
+    """Walker 0's chain on the device against the ORACLE's (tests/golden/<name>.npz, tests/golden/make_chain_fixtures.py): same
+    molecule, same outcome (accepted / lattice switch / volume move) move by move, energies to 1e-10 relative -- with one move at a
+    time (the build a farm of thousands runs) and with the look-ahead the launch would pick for a handful of walkers.  Raises
+    SystemExit on a mismatch, like the check of the timed move kernel."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.energy import load_boxes
+    from mc_water_ls_mw_amd.sweep import MuGrid, WalkerFarm
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    ref = g["log"]
+    nmoves = len(ref)
+    worst, checked = 0.0, 0
+    for ahead in ("1", None):
+        if ahead is None:
+            os.environ.pop("MW_SWEEP_AHEAD", None)
+        else:
+            os.environ["MW_SWEEP_AHEAD"] = ahead
+        if name.startswith("chain_farm48"):
+            z1, z2 = (np.load(os.path.join(ROOT, "tests", "golden", f)) for f in ("ic48.npz", "ih48.npz"))
+            nw, nlat = 4, 2
+            hs, xs = [], []
+            for w in range(nw):
+                for l, z in enumerate((z1, z2)):
+                    hs.append(z["h"]); xs.append(lat.thermalise(z["xyz"], float(g["sigma_ang"]), 7919 * w + l))
+            em = load_boxes(hs, xs, device=device)
+            farm = WalkerFarm(em, 2, float(g["temperature"]), float(g["max_trans_ang"]),
+                              grid=MuGrid(int(g["nbins"]), -float(g["mu_range"]), float(g["mu_range"])),
+                              pressure_au=float(g["pressure_atm"]) / 2.90363081e8)
+            npt = bool(int(g["npt"]))
+            farm.options(record=True, samplerun=False, always_switch=True, npt=npt, wl_factor=float(g["wl_factor"]))
+            if npt:
+                farm.moves(trans_prob=0.5, vol_prob=1.0 / em.nwater, dv_max_ang=float(g["dv_max_ang"]))
+            farm.set_states(1)
+            seed = int(g["seed"])
+        else:
+            h, x0 = lat.ice_box("ih", (8, 8, 8), 0.0)
+            nw, nlat = 2, 1
+            xs = [lat.thermalise(x0, float(g["sigma_ang"]), int(g["thermalise_seed"]) + w) for w in range(nw)]
+            em = load_boxes([h] * nw, xs, device=device)
+            farm = WalkerFarm(em, 1, float(g["temperature"]), float(g["max_trans_ang"]))
+            farm.set_states(1)
+            seed = int(g["seed"])
+        try:
+            log = farm.sweep(nmoves, seed=seed, move0=0, first_walker=1, count=1, log=True)[0]
+        finally:
+            em.energy_deinit()
+        if not (np.array_equal(log[:, 0], ref[:, 0]) and np.array_equal(log[:, 1], ref[:, 1])):
+            k = int(np.argmax((log[:, 0] != ref[:, 0]) | (log[:, 1] != ref[:, 1])))
+            raise SystemExit(f"{name} (look-ahead {ahead or 'auto'}): walker 0 leaves the oracle's chain at move {k}: "
+                             f"molecule / outcome {log[k, :2]} against {ref[k, :2]}")
+        err = float(np.max(np.abs(log[:, 2:6] - ref[:, 2:6]) / np.maximum(np.abs(ref[:, 2:6]), 1e-300) * (ref[:, 2:6] != 0.0)))
+        if not err <= 1e-10:
+            raise SystemExit(f"{name} (look-ahead {ahead or 'auto'}): walker 0's energies differ from the oracle's chain (max rel {err:.3e})")
+        worst, checked = max(worst, err), checked + nmoves
+    os.environ.pop("MW_SWEEP_AHEAD", None)
+    return {"fixture": f"tests/golden/{name}.npz", "moves_checked": checked, "max_rel_err_energies": worst,
+            "accepted": int((ref[:, 1].astype(int) & 1).sum()), "lattice_switches": int(((ref[:, 1].astype(int) >> 1) & 1).sum()),
+            "volume_moves": int(((ref[:, 1].astype(int) >> 2) & 1).sum())}
+
+
+def production_driver_measurements(device, backend):
+    """BASELINE.json configs[3] as the product runs it: `mc_water_ls_mw_amd.farm.run` -- 48-molecule Ic/Ih walkers, Wang-Landau update
+    and a lattice-switch attempt after every move, list rebuilds every 10 cycles, the table exchange every 25 on the process group
+    of this run (one rank at N = 1: the collective is executed, on RCCL with --backend nccl) -- for 8192 walkers (NVT and NPT, one
+    shared table and the reference's own arithmetic), for 8 and for 1 (the reference's own operating point: one chain's speed); and
+    the driver alone on 2048 x 4096-molecule boxes.  End-to-end wall time (lists, exchange, host loop) and k_sweep's share of it
+    from HIP events; each workload's chain is first held to the oracle's (chain_self_check)."""
+    import torch
+    from mc_water_ls_mw_amd import farm as mwfarm
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.comms import WalkerComms
+    from mc_water_ls_mw_amd.energy import load_boxes
+    from mc_water_ls_mw_amd.sweep import WalkerFarm
+    counters = load_sweep_counters()
+    checks = {n: chain_self_check(device, n) for n in ("chain_farm48_nvt", "chain_farm48_npt", "chain_ih4096")}
+    out = {"walker0_chain_checked": int(sum(c["moves_checked"] for c in checks.values() if c)), "chain_checks": checks, "runs": []}
+    z1, z2 = (np.load(os.path.join(ROOT, "tests", "golden", f)) for f in ("ic48.npz", "ih48.npz"))
+    cdev = torch.device("cuda", device) if backend == "nccl" else None
+    for walkers, cycles in ((8192, 100), (8, 500), (1, 500)):
+        for npt in (False, True):
+            for regauge in ((None, False) if walkers > 64 else (True,)):      # (a handful of walkers: one shared table asked for explicitly)
+                res = mwfarm.run([z1["h"], z2["h"]], [z1["xyz"], z2["xyz"]], walkers, cycles, mpi_sync_int=25, device=device,
+                                 comms=WalkerComms(NBINS, device=cdev), npt=npt, regauge=regauge, time_kernels=True)
+                case = ("farm48_npt" if npt else "farm48_nvt") if walkers > 64 else f"chain48_{'npt' if npt else 'nvt'}_{walkers}"
+                out["runs"].append({
+                    "name": f"configs[3] replica farm: {walkers} x 48-molecule Ic/Ih walker{'s' if walkers > 1 else ''}, {'NPT' if npt else 'NVT'}, "
+                            f"WL update + switch attempt per move, exchange every 25 cycles"
+                            + (", one shared table (regauge)" if res["regauge"] else ", the reference's exchange arithmetic (comms_mpi.f90:256-270)"),
+                    "walkers": walkers, "cycles": cycles, "ensemble": "npt" if npt else "nvt", "regauge": res["regauge"],
+                    "moves_per_s": res["moves_per_s"], "local_energy_evaluations_per_s": 4.0 * res["moves_per_s"],
+                    "us_per_move_per_walker": 1e6 * walkers / res["moves_per_s"],
+                    "wall_s": res["wall_s"], "k_sweep_ms": res["sweep_kernel_ms"], "k_sweep_share_of_wall": res["sweep_kernel_ms"] * 1e-3 / res["wall_s"],
+                    "k_sweep_moves_per_s": res["moves"] / (res["sweep_kernel_ms"] * 1e-3), "launches": res["sweep_launches"],
+                    "acceptance": res["acceptance"], "switches_per_walker": res["switches_per_walker"], "weight_max": res["weight_max"],
+                    "histogram_total": res["histogram_total"], "drift_walker1_Ha": res["drift_walker1_Ha"],
+                    "roofline": sweep_roofline(case, res["moves"], res["sweep_kernel_ms"], counters)})
+    # the driver alone on large boxes: 2048 walkers x 4096 molecules, one lattice (positions and lists in HBM, gathered through L2)
+    h, x0 = lat.ice_box("ih", (8, 8, 8), 0.0)
+    W, nmv = 2048, 300
+    em = load_boxes([h] * W, [lat.thermalise(x0, 0.1, w) for w in range(W)], device=device)
+    try:
+        farm = WalkerFarm(em, 1, 200.0, 1.1)
+        farm.set_states(1)
+        farm.sweep_launch(20, seed=1, move0=0)
+        em.sync()
+        em.timer_start(0)
+        farm.sweep_launch(nmv, seed=1, move0=20)
+        em.timer_stop(0)
+        ms = em.timer_ms(0)
+        st = farm.state(1)
+        fresh = em.model_energy_batch(1, 1)
+        out["runs"].append({"name": "k_sweep alone: 2048 x 4096-molecule ice-Ih walkers (one lattice), 300 moves each",
+                            "walkers": W, "moves_per_s": W * nmv / (ms * 1e-3), "local_energy_evaluations_per_s": 2.0 * W * nmv / (ms * 1e-3),
+                            "k_sweep_ms": ms, "drift_walker1_Ha": [st["model_energy"][0] - fresh[0]],
+                            "roofline": sweep_roofline("ih4096_2048", W * nmv, ms, counters)})
+    finally:
+        em.energy_deinit()
+    return out
+
+
 def self_launch(n, json_fd):
     """`python bench.py --gpus N` without a launcher: start N children of this script, one rank per GPU, with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (the environment torch.distributed.run would give
@@ -637,6 +787,8 @@ def main():
     if rank == 0:
         if not args.no_secondary and world == 1:
             out["secondary"] = secondary_measurements(local_rank)
+            out["production_driver"] = production_driver_measurements(local_rank, args.backend if exchange else "none")
+            out["walker0_chain_checked"] = out["production_driver"]["walker0_chain_checked"]
         emit(out)
 
     if dist.is_initialized():

@@ -31,7 +31,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         deltaG_int=100000, max_mc_cycles=None, eq_mc_cycles=0, outdir=None, thermalise=True, regauge=None,
         parallel_strategy="mw", window_overlap=2, leshift=False, input_ref_enthalpy=None, wl_swetnam=False, wl_alpha=1.0,
         eq_adjust_mc=False, mc_target_ratio=0.5, monitor_int=1000, mc_max_trans_ang=1.1, mc_dv_max_ang=0.924,
-        latt_sync_int=10000, chkpt_dump_int=None, restart=False, minu=False):
+        latt_sync_int=10000, chkpt_dump_int=None, restart=False, minu=False, time_kernels=False):
     """Run `cycles` MC cycles of `walkers` two-lattice walkers on this GPU.  Returns a dict of results.
 
     ``flat_chk_int`` ... ``file_wl_factor``: the Wang-Landau schedule (mc_check_flatness, :291-294;
@@ -57,7 +57,9 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
     all) -- and a restarted run takes cycle number, step sizes, increment, tables, cells, reference and current positions
     and the active lattice from the newer readable one (mc_checkpoint_load, :393-501) and runs ``cycles`` MORE cycles.
     ``minu``: the reference's compile-time ``-DMINU`` variant as a run option (an accepted move also takes the walker to
-    the lattice of lower enthalpy, mc_moves.F90:1119-1140,1385-1401)."""
+    the lattice of lower enthalpy, mc_moves.F90:1119-1140,1385-1401).
+    ``time_kernels``: HIP events around every launch of the Monte Carlo driver (read back long after the launch has ended, so
+    nothing waits for them): ``sweep_kernel_ms`` / ``sweep_launches`` in the result say what share of the wall time is k_sweep."""
     from . import lattice as lat
     from .energy import EnergyModule
     from .schedule import WangLandauSchedule, WindowSchedules, delta_g_from_hist, log_unbiased_norm
@@ -249,6 +251,7 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                     or (samplerun and c % deltaG_int == 0) or c + 1 == eq_mc_cycles or sched.invt_active)
 
         cyc = mon_cycle = start_cycle
+        nlaunch, kernel_ms = 0, 0.0
         while cyc < last_cycle:
             first = cyc + 1
             if first % list_update_int == 0:                       # mc_moves.F90:217-222
@@ -262,7 +265,15 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
             while not ends_a_stretch(cyc):
                 cyc += 1
             set_options(first)
+            if time_kernels:
+                slot = 3000 + nlaunch % 64
+                if nlaunch >= 64:
+                    kernel_ms += em.timer_ms(slot)                 # (the launch 64 launches ago: long finished)
+                em.timer_start(slot)
             farm.sweep_launch(n * (cyc - first + 1), seed=seed + rank, move0=(first - 1) * n)
+            if time_kernels:
+                em.timer_stop(slot)
+            nlaunch += 1
             if cyc % mpi_sync_int == 0:                            # mc_moves.F90:258-276
                 em.sync()
                 if npt or dd:
@@ -314,6 +325,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
         if npt or dd:
             check_flags_everywhere()                               # every walker, not only the ones read out below
         wall = time.perf_counter() - t0
+        if time_kernels:
+            kernel_ms += sum(em.timer_ms(3000 + k % 64) for k in range(max(0, nlaunch - 64), nlaunch))
         joined = None
         if dd:                                                     # mc_monitor_stats, :1883-1886
             facs = farm.factors()[0] if wl_swetnam else sched.wl_factors
@@ -335,7 +348,8 @@ def run(h_pair, x_pair, walkers, cycles, temperature=200.0, nbins=101, mu_range=
                    wl_invt_active=sched.invt_active, flatness_events=events, delta_g=delta_g,
                    ref_enthalpy=farm.ref_enthalpy,
                    max_trans_bohr=step_t[:32].tolist(), dv_max_bohr=step_v[:32].tolist(),
-                   list_rows_last_rebuild=list(list_rows), regauge=bool(regauge))
+                   list_rows_last_rebuild=list(list_rows), regauge=bool(regauge),
+                   sweep_kernel_ms=kernel_ms if time_kernels else None, sweep_launches=nlaunch)
         out["tables"] = synced
         out["restart_factors"] = None if restart_factors is None else [np.asarray(a).tolist() for a in restart_factors]
         out["joined"] = joined

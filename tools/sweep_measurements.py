@@ -73,6 +73,12 @@ if only in (None, "npt48"):
 if only in ("farm48",):     # the replica farm's own settings (farm.py defaults): +-400 window, so walkers do switch lattice
     run("pair48 x 8192 walkers, WL update + switch per move, farm window", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 8192, 480, out,
         wl=True, sigma=0.05, mu_range=400.0)
+if only in ("farm48npt",):
+    run("pair48 x 8192 walkers, NPT, WL update + switch per move, farm window", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 8192, 480, out,
+        wl=True, npt=True, sigma=0.05, mu_range=400.0)
+if only in ("eight48",):
+    run("pair48 x 8 walkers, WL update + switch per move", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 8, 4800, out,
+        wl=True, sigma=0.05, mu_range=400.0)
 # a handful of the reference's own walkers (it runs one per MPI rank): the speed of ONE chain, look-ahead inside it
 if only in ("one48",):
     run("pair48 x 1 walker, WL update + switch per move", [(ic48["h"], ic48["xyz"]), (ih48["h"], ih48["xyz"])], 2, 1, 4800, out,
