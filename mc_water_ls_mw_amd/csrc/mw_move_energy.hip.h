@@ -271,7 +271,9 @@ __device__ unsigned long long g_lat_stamps[16];
 // NOTH > 0 (the Monte Carlo driver's look-ahead, mw_sweep.hip.h): `oth` holds the molecules that moves EARLIER in the chain
 // are trying to move at the same time (-1: none); bit o of `cmask` comes back set when this evaluation read the position of
 // oth[o] -- it is then only valid if that earlier move is rejected.  (The molecule's own index is the caller's to compare.)
-template <bool SELFIMG = true, int NOTH = 0, typename PosFn, typename IvFn, typename RowFn, typename NnFn>
+// COUNTS = false (the Monte Carlo driver, which has no use for them): the interaction and slot counts of `res` are left unset and
+// their bookkeeping -- a counter per item, a prefix sum's upper half, a wave-wide integer sum -- falls away.
+template <bool SELFIMG = true, int NOTH = 0, bool COUNTS = true, typename PosFn, typename IvFn, typename RowFn, typename NnFn>
 __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn row, NnFn nnof,
                                                  WaveScratch* __restrict__ ws, int niv,
                                                  int i, int n_i, uint32_t e,
@@ -324,7 +326,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     // The rows of the in-range j are laid end to end (slots 0..T-1).  An inclusive prefix sum over the 32
     // slot lanes of each half gives every j its first slot, and in its upper 16 bits the list slots each
     // evaluation visits (half 0: old position, half 1: trial position).
-    const int mine = (inu ? nnj : 0) | ((in ? nnj : 0) << 16);
+    const int mine = (inu ? nnj : 0) | (COUNTS ? ((in ? nnj : 0) << 16) : 0);
     int inc = mine;
     inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);        // row_shr:1
     inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);        // row_shr:2
@@ -467,11 +469,11 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
                 const double rao = ws->rinvo[ia], ran = ws->rinvn[ia], gao = ws->go[ia], gan = ws->gn[ia];
                 if (fl & 1) {
                     const double ct = (((xo - pax) * box_ + (yo - pay) * boy_ + (zo - paz) * boz_) * rao) * rbo;   // :316,320,341,365
-                    if (ct < 0.99) { const double d = ct - kCos0; t3o += gao * (gbo * (d * d)); ++nto; }          // :367-368,385-387
+                    if (ct < 0.99) { const double d = ct - kCos0; t3o += gao * (gbo * (d * d)); if constexpr (COUNTS) ++nto; }    // :367-368,385-387
                 }
                 if (fl & 2) {
                     const double ct = (((xn - pax) * bnx + (yn - pay) * bny + (zn - paz) * bnz) * ran) * rbn;
-                    if (ct < 0.99) { const double d = ct - kCos0; t3n += gan * (gbn * (d * d)); ++ntn; }
+                    if (ct < 0.99) { const double d = ct - kCos0; t3n += gan * (gbn * (d * d)); if constexpr (COUNTS) ++ntn; }
                 }
             }
         }
@@ -552,11 +554,13 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     // Wave sums on the DPP network (no LDS round trips): afterwards lane 63 holds the totals.
     double eo, en;                                                                                 // :397
     dpp_wave_sum2(kLamEps * t3o + (half == 0 ? accp : 0.0), kLamEps * t3n + (half == 1 ? accp : 0.0), eo, en);
-    const unsigned int cs = (unsigned int)__builtin_amdgcn_readlane(dpp_wave_sum_i32((int)(nto | (ntn << 16))), 63);
-    nto = cs & 0xffffu; ntn = cs >> 16;
     res.eo = eo; res.en = en;
-    res.io = (unsigned int)__popc(mo_) + nto; res.in_ = (unsigned int)__popc(mn_) + ntn;
-    res.so = so; res.sn = sn;
+    if constexpr (COUNTS) {
+        const unsigned int cs = (unsigned int)__builtin_amdgcn_readlane(dpp_wave_sum_i32((int)(nto | (ntn << 16))), 63);
+        nto = cs & 0xffffu; ntn = cs >> 16;
+        res.io = (unsigned int)__popc(mo_) + nto; res.in_ = (unsigned int)__popc(mn_) + ntn;
+        res.so = so; res.sn = sn;
+    }
     if constexpr (NOTH > 0) {          // OR over the lanes, on the DPP network
         unsigned v = cm;
         v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1

@@ -894,7 +894,9 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 if (always_switch) {                                              // mc_lattice_switch's exponential after an accepted / a rejected move
 #endif
                     const double dk = newl ? switch_dk(mn0l, mn1l, ls_c) : switch_dk(bk0, bk1, ls_c);
-                    exs = exp_any(-dk);
+                    // (one move at a time: every move takes the serial step, whose own exponential stream has lanes to spare -- the
+                    //  argument waits there; with look-ahead the serial step is the exception and the exponential is taken here)
+                    exs = SPEC == 1 ? -dk : exp_any(-dk);
                 }
                 cur_lane = 2 * a;
                 MW_SW_ACC(10, MW_SW_NOW() - t0);
@@ -1054,13 +1056,16 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                                               C.npt != 0, N, eta_new, eta_old, diffkT);
                     if (minu_ls != ls_c && always_switch) cmpA_minu = exp_any(-switch_dk(mn0, mn1, minu_ls));
                 }
-                // lane 0: the acceptance; lanes 1, 2: the unbiased histogram's factor after an accepted / a rejected move (:1627-1629)
-                const double xarg = lane == 0 ? -diffkT : (lane == 1 ? eta_new - lun : eta_rev - lun);
+                // lane 0: the acceptance; lanes 61, 62: the unbiased histogram's factor after an accepted / a rejected move (:1627-1629);
+                // one move at a time: lanes 1, 2 the lattice switch's exponentials, whose arguments the pre-phase left there
+                double xarg = lane == 0 ? -diffkT : (lane == 61 ? eta_new - lun : eta_rev - lun);
+                if constexpr (SPEC == 1) xarg = (lane == 1 || lane == 2) ? exs : xarg;
 #ifdef MW_ABL_D_NOEXP
                 const double ex = 0.1 + 0.01 * xarg;
 #else
                 const double ex = exp_any(xarg);
 #endif
+                if constexpr (SPEC == 1) exs = ex;
                 double pacc = readlane_f64(ex, 0);
                 pacc = pacc > 1.0 ? 1.0 : pacc;
                 const bool ok = U[5] < pacc;                                      // :1145-1146 (false for NaN)
@@ -1072,11 +1077,11 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                     ls_c = minu_ls;
                     bk0 = readlane_f64(mn0l, ln); bk1 = readlane_f64(mn1l, ln);   // :1016,1087
                     eta_fin = eta_new;
-                    if (samplerun) ufac = readlane_f64(ex, 1);
+                    if (samplerun) ufac = readlane_f64(ex, 61);
                 } else {                                                          // :1182-1195
                     if (do_switch) cmp_sw = readlane_f64(exs, lr);
                     eta_fin = eta_rev;
-                    if (samplerun) ufac = readlane_f64(ex, 2);
+                    if (samplerun) ufac = readlane_f64(ex, 62);
                 }
                 mu_c = readlane_f64(mul, cl);
                 k_c = __builtin_amdgcn_readlane(kl, cl); k_val = 1;
@@ -1442,7 +1447,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
 #ifdef MW_ABL_NOEVAL         // diagnostic build: no evaluation (energies 0) -- the decisions' share of a round
             const bool fast = true; res.eo = 0.0; res.en = 1e-3 * (double)(i & 7); res.io = res.in_ = res.so = res.sn = 0u;
 #else
-            const bool fast = move_energy_wave<true, SPEC - 1>(getpos, getiv, row, nnof, ws, sniv[l], i, nnof(i), row(i, lane & 31), xo, yo, zo,
+            const bool fast = move_energy_wave<true, SPEC - 1, false>(getpos, getiv, row, nnof, ws, sniv[l], i, nnof(i), row(i, lane & 31), xo, yo, zo,
                                                                pnx, pny, pnz, lane, res, oth, &cme);
 #endif
             cm |= cme;
