@@ -105,3 +105,26 @@ def test_two_rank_restart_continues_the_synchronised_run(tmp_path):
     assert rest["ranks_agree"] is True and full["ranks_agree"] is True
     assert rest["weight_max"] == pytest.approx(full["weight_max"], rel=1e-9) and full["weight_max"] > 0
     assert rest["histogram_total"] == pytest.approx(full["histogram_total"], rel=1e-12)
+
+
+def test_every_rank_stops_when_one_ranks_checkpoints_are_a_dump_behind(tmp_path):
+    """Two ranks x two walkers, checkpoints at cycles 10 and 20 (files .1 and .2 in turn); rank 1's newer files are removed, so it
+    would restart from cycle 10 and rank 0 from cycle 20.  The ranks agree before either stops (farm.run: every rank takes part in
+    the broadcast of rank 0's cycle and in one get_max of "something is wrong here"): BOTH end with the message, at once -- a rank
+    that raised alone left the other waiting in the collective until the launcher's watchdog gave up."""
+    import glob
+    import time
+    common = ["-m", "mc_water_ls_mw_amd.farm", "--walkers", "2", "--sync", "10", "--backend", "gloo", "--share-device"]
+    _launch(common + ["--cycles", "20", "--chkpt", "10", "--outdir", str(tmp_path)])
+    newer = sorted(glob.glob(os.path.join(str(tmp_path), "checkpoint00[23].dat.2")))       # walkers 2, 3 = rank 1
+    assert len(newer) == 2 and len(glob.glob(os.path.join(str(tmp_path), "checkpoint*.dat.*"))) == 8
+    for f in newer:
+        os.remove(f)
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + common + ["--cycles", "10", "--restart", "--outdir", str(tmp_path)]
+    t0 = time.monotonic()
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and time.monotonic() - t0 < 120
+    assert "rank 1 restarts from cycle 10, rank 0 from 20: checkpoint files out of step" in out.stderr
+    assert "rank 0: another rank's checkpoint files are out of step" in out.stderr
