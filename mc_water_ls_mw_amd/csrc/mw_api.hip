@@ -572,8 +572,11 @@ static const void* sweep_kernel(int nlat, int residency, bool withvol, int spec)
          {MW_SWEEP_K(2, 4, true, false, false), MW_SWEEP_K(2, 4, true, false, true)}}};
     static const void* const ahead8[2] = {            // eight moves in flight: ONE lattice, walkers in global memory (a 4096-molecule box or a few of them)
         MW_SWEEP_K(1, 8, false, false, false), MW_SWEEP_K(1, 8, false, false, true)};
+    static const void* const ahead6[2] = {            // six moves in flight: TWO lattices entirely in LDS (twelve wavefronts of the 168-register builds fill a CU:
+        MW_SWEEP_K(2, 6, true, true, false), MW_SWEEP_K(2, 6, true, true, true)};          // one walker per CU -- the reference's handful of 48-molecule walkers)
 #undef MW_SWEEP_K
     if (spec == 8) return (nlat == 1 && residency == 0) ? ahead8[withvol ? 1 : 0] : nullptr;
+    if (spec == 6) return (nlat == 2 && residency == 2) ? ahead6[withvol ? 1 : 0] : nullptr;
     if (spec > 1 && residency == 0) return ahead[nlat - 1][spec == 4 ? 1 : 0][withvol ? 1 : 0];
     if (spec > 1 && residency == 1) return ahead_pos[nlat - 1][spec == 4 ? 1 : 0][withvol ? 1 : 0];
     if (spec > 1 && residency == 2) return ahead_lds[nlat - 1][spec == 4 ? 1 : 0][withvol ? 1 : 0];
@@ -763,8 +766,10 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
         HIPCHK(hipFuncSetAttribute(sweep_kernel(1 + (v & 1), (v >> 1) % 3, v >= 6, 1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
     for (int v = 0; v < 24; ++v)
         HIPCHK(hipFuncSetAttribute(sweep_kernel(1 + (v & 1), v >> 3, (v & 2) != 0, (v & 4) ? 4 : 2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
-    for (int v = 0; v < 2; ++v)
+    for (int v = 0; v < 2; ++v) {
         HIPCHK(hipFuncSetAttribute(sweep_kernel(1, 0, v != 0, 8), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+        HIPCHK(hipFuncSetAttribute(sweep_kernel(2, 2, v != 0, 6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+    }
     g.live = true;
     return 0;
 }
@@ -1207,13 +1212,19 @@ int mw_local_energy_patched(int ils, int imol, const double r_imol[3], int imol_
                        reinterpret_cast<unsigned long long*>(g.d_pin + 8), seq);
     HIPCHK(hipGetLastError());
     // The kernel is the only thing in flight on this stream: wait for its completion word in host-visible memory
-    // (a few microseconds less than a stream synchronisation); if it does not show up within about a second, fall
+    // (a few microseconds less than a stream synchronisation); if it does not show up within a second, fall
     // back to the synchronisation, which also reports a fault.
     volatile unsigned long long* done = reinterpret_cast<volatile unsigned long long*>(g.h_pin + 8);
     bool seen = false;
-    for (long spin = 0; spin < 200000000L; ++spin) {
+    std::chrono::steady_clock::time_point t_first{};
+    for (long spin = 1;; ++spin) {                       // (a wall clock, like the served path: one second, whatever the host's speed)
         if (*done == seq) { seen = true; break; }
         __builtin_ia32_pause();
+        if ((spin & 0xffff) == 0) {
+            const auto now = std::chrono::steady_clock::now();
+            if (t_first == std::chrono::steady_clock::time_point{}) t_first = now;
+            else if (std::chrono::duration<double>(now - t_first).count() > 1.0) break;
+        }
     }
     if (!seen) HIPCHK(hipStreamSynchronize(g.stream));
     *e = g.h_pin[0];
@@ -2056,7 +2067,11 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
         // eight in flight for one-lattice walkers in global memory (large boxes: consecutive moves seldom touch the same molecules)
         const bool has8 = L == 1 && !ldspos;
         if (has8 && all_resident(8)) spec = 8;
-        if (const char* e = getenv("MW_SWEEP_AHEAD")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || (v == 8 && has8)) spec = v; }
+        // six for two-lattice walkers entirely in LDS, while there is a CU for each (a round ends with its first accepted move: 3.1 moves
+        // per round of four at 16 % acceptance, 4.0 per round of six)
+        const bool has6 = L == 2 && ldslist;
+        if (has6 && all_resident(6)) spec = 6;
+        if (const char* e = getenv("MW_SWEEP_AHEAD")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || (v == 8 && has8) || (v == 6 && has6)) spec = v; }
         if (want_log) spec = std::min(spec, g.sweep_log_ahead);
     }
     const mw::SweepLds lay = mw::sweep_lds(L, L * spec, g.ivcap, g.N, g.sp.nbins, ldspos, ldslist, rstride, withvol, g.sp.samplerun != 0, spec);

@@ -748,7 +748,7 @@ def test_lookahead_with_random_run_options(seed, monkeypatch):
             em.energy_deinit()
 
     ref = run(1)
-    for ahead in (2, 4):
+    for ahead in (2, 4) + ((6,) if seed % 4 == 1 else ()):         # (six in flight: the walkers entirely in LDS)
         got = run(ahead)
         assert np.array_equal(got[0], ref[0], equal_nan=True)
         assert all(np.array_equal(a, b) for a, b in zip(got[1], ref[1])) and got[2] == ref[2] and got[4] == ref[4]
@@ -808,8 +808,8 @@ def test_lookahead_on_awkward_boxes(kind, so, monkeypatch):
 @pytest.mark.parametrize("residency", [0, 1, 2])
 @pytest.mark.parametrize("npt", [False, True])
 def test_every_build_of_the_driver_runs_the_same_chain(nlat, residency, npt, monkeypatch):
-    """The 38 instantiations of k_sweep -- lattices x where a walker's data live x with / without volume moves x 1, 2 or 4 moves in
-    flight, and 8 for one-lattice walkers in global memory -- each actually launched (mw_sweep_last_launch says which build a launch
+    """The 40 instantiations of k_sweep -- lattices x where a walker's data live x with / without volume moves x 1, 2 or 4 moves in
+    flight, 8 for one-lattice walkers in global memory, 6 for two-lattice walkers entirely in LDS -- each actually launched (mw_sweep_last_launch says which build a launch
     took) and, for the same walkers, 2, 4 (and 8) moves in flight reproduce the one-move-at-a-time chain bit for bit."""
     from mc_water_ls_mw_amd import lattice as lat
     from mc_water_ls_mw_amd.energy import load_boxes
@@ -847,7 +847,7 @@ def test_every_build_of_the_driver_runs_the_same_chain(nlat, residency, npt, mon
 
     ref = run(1)
     assert 5 < int((ref[0][0][:, 1].astype(int) & 1).sum()) < 195
-    for ahead in (2, 4) + ((8,) if nlat == 1 and residency == 0 else ()):
+    for ahead in (2, 4) + ((8,) if nlat == 1 and residency == 0 else ()) + ((6,) if nlat == 2 and residency == 2 else ()):
         got = run(ahead)
         assert np.array_equal(got[0], ref[0], equal_nan=True)
         assert all(np.array_equal(a, b) for a, b in zip(got[1], ref[1])) and got[2] == ref[2]
