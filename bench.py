@@ -704,6 +704,16 @@ def main():
     ms_full = float(np.mean([em.timer_ms(2 * k) for k in range(nk)]))
     ms_moves = float(np.mean([em.timer_ms(2 * k + 1) for k in range(nk)]))
     e_walker0 = em.model_energy_fetch(1, 1)[0]
+    # The step's full-box launch also leaves every molecule's moments behind for the step's move kernel (its moment path, DESIGN.md
+    # 3.2): ~50 us of stores on top of the evaluation.  The kernel of configs[1] by itself -- compute_model_energy of every walker,
+    # nothing else -- is timed here, outside the step loop, and is what `roofline_model_energy` describes.
+    for _ in range(5):
+        em.model_energy_launch(1, W)
+    for k in range(20):                              # one event pair per launch, like the step loop's (an average over a bracket of
+        em.timer_start(4010 + k)                     # back-to-back launches lets their tails and heads overlap: 7 % less per launch)
+        em.model_energy_launch(1, W)
+        em.timer_stop(4010 + k)
+    ms_full_plain = float(np.mean([em.timer_ms(4010 + k) for k in range(20)]))
     moves_err = None
     if gold is not None and n_gold:    # what the LAST timed k_move_energy launch left on the device, against the reference's values
         eo, en = em.moves_fetch()
@@ -737,7 +747,7 @@ def main():
                 raise SystemExit(f"walker 0 energy {e_walker0!r} differs from the golden vector {ref!r}")
         dominant = "k_model_energy" if ms_full >= ms_moves else "k_move_energy"
         counters = load_counters(W, M)
-        rl = {"k_model_energy": kernel_roofline("k_model_energy", bytes_full, ms_full, W * N_MOL, counters, copy_gbs),
+        rl = {"k_model_energy": kernel_roofline("k_model_energy", bytes_full, ms_full_plain, W * N_MOL, counters, copy_gbs),
               "k_move_energy": kernel_roofline("k_move_energy", bytes_moves, ms_moves, W * M, counters, copy_gbs)}
         entries_bytes = W * N_MOL * (24 + 4) + 8 * entries         # N*(24 + 4 + 8*nbar)
         out = {
@@ -764,7 +774,11 @@ def main():
                 "k_model_energy": {"avg_ms": ms_full, "interactions_per_launch": i_full,
                                    "interactions_per_s": i_full / (ms_full * 1e-3),
                                    "algorithmic_GBps": bytes_full / (ms_full * 1e-3) / 1e9,
-                                   "atoms_per_s": W * N_MOL / (ms_full * 1e-3)},
+                                   "atoms_per_s": W * N_MOL / (ms_full * 1e-3),
+                                   "note": "inside the step: the evaluation + every molecule's moments for the step's move kernel "
+                                           "(96 B per molecule written); `plain_avg_ms` is the evaluation alone, timed after the step loop",
+                                   "plain_avg_ms": ms_full_plain, "plain_interactions_per_s": i_full / (ms_full_plain * 1e-3),
+                                   "plain_algorithmic_GBps": bytes_full / (ms_full_plain * 1e-3) / 1e9},
                 "k_move_energy": {"avg_ms": ms_moves, "interactions_per_launch": i_moves,
                                    "interactions_per_s": i_moves / (ms_moves * 1e-3),
                                    "algorithmic_GBps": bytes_moves / (ms_moves * 1e-3) / 1e9,

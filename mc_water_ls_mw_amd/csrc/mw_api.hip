@@ -66,6 +66,9 @@ struct Ctx {
     int cu = 0, nsplit_max = 0;
     hipStream_t stream = nullptr;
     double* d_pos = nullptr;
+    double* d_mom = nullptr;           // [box][N][kMomStride]: per-molecule moments (k_model_energy's by-product) for the single-move kernel's moment path
+    int mom_first = 0, mom_count = 0;  // the boxes whose moments the LAST full-box launch left valid (cleared by everything that may move a molecule)
+    int m_boxlo = 0, m_boxhi = -1, m_minreq = 0;   // the uploaded requests: their boxes (0-based range) and the fewest requests any of them has
     double* d_ivect = nullptr;
     int* d_nivect = nullptr;
     uint32_t* d_list = nullptr;    // slot-major   [box][S][N]
@@ -177,6 +180,8 @@ struct ExclusiveGuard {
         g_mu.lock();
         if (g_depth++ == 0) {
             g_gate.lock(); g_epoch.fetch_add(1, std::memory_order_relaxed);
+            g.mom_count = 0;            // moments of an earlier entry point's full-box pass: positions may have moved since (only a pass
+                                        // inside THIS entry point -- mw_step_launch -- makes them valid for its move kernel)
             if (g.srv_running) rc = server_stop();
             // A request posted ahead (mw_local_energy_post) that the server never got to -- it left between the post and this
             // entry point -- is CANCELLED: marked as answered, so that the server started by the next single call does not
@@ -382,22 +387,35 @@ Geo model_geo(int count)
     return ge;
 }
 
-int launch_model_energy(int first, int count)
+int launch_model_energy(int first, int count, bool with_mom = false, bool write_energy = true)
 {
     const Geo ge = model_geo(count);
+    double* mom = nullptr;
+    if (with_mom && ge.lds) {
+        if (!g.d_mom) HIPCHK(hipMalloc(&g.d_mom, (size_t)g.nbox * g.N * mw::kMomStride * sizeof(double)));
+        mom = g.d_mom;
+    }
+    const int wen = write_energy ? 1 : 0;
     // whole boxes staged in LDS, one workgroup per box: the workgroups are persistent, one per compute unit (its LDS holds
     // one), each taking every g.cu-th box and reading its next box while the current one's tail drains
     static const bool persist = !(std::getenv("MW_MODEL_PERSIST") && std::getenv("MW_MODEL_PERSIST")[0] == '0');   // 0: one workgroup per box (A/B only)
     dim3 grid(ge.nsplit, persist && ge.lds && ge.nsplit == 1 ? std::min(count, g.cu) : count);
     const int box0 = first - 1;
-    if (ge.lds)
+    if (ge.lds && mom)
+        hipLaunchKernelGGL((mw::k_model_energy<true, 1024, kFullLayout, false, true>), grid, dim3(1024), ge.shmem, g.stream, g.d_pos, g.d_ivect,
+                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk, count,
+                           mom, wen);
+    else if (ge.lds)
         hipLaunchKernelGGL((mw::k_model_energy<true, 1024, kFullLayout>), grid, dim3(1024), ge.shmem, g.stream, g.d_pos, g.d_ivect,
-                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk, count);
+                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk, count,
+                           (double*)nullptr, wen);
     else
         hipLaunchKernelGGL((mw::k_model_energy<false, 256, kFullLayout, true>), grid, dim3(256), ge.shmem, g.stream, g.d_pos, g.d_ivect,
-                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk, count);
+                           g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk, count,
+                           mom, wen);
     HIPCHK(hipGetLastError());
-    if (ge.nsplit > 1) {           // split boxes: the partials of box b live at [b*nsplit .. b*nsplit+nsplit); unsplit boxes wrote their energy themselves
+    if (mom) { g.mom_first = first; g.mom_count = count; }
+    if (ge.nsplit > 1 && write_energy) {           // split boxes: the partials of box b live at [b*nsplit .. b*nsplit+nsplit); unsplit boxes wrote their energy themselves
         hipLaunchKernelGGL(mw::k_sum_partials, dim3(count), dim3(64), 0, g.stream, g.d_partial, g.d_cpartial,
                            g.d_energy, g.d_counts, box0, count, ge.nsplit);
         HIPCHK(hipGetLastError());
@@ -514,7 +532,7 @@ void release_all()
                     g.d_nivect, g.d_list, g.d_listm, g.d_nn, g.d_stats, g.d_order, g.d_nns, g.d_cmax, g.d_cin, g.d_grid,
                     g.d_usegrid, g.d_cellid, g.d_shift, g.d_sorted, g.d_wrel, g.d_wpos, g.d_wsh, g.d_ccount, g.d_cstart, g.d_ccursor, g.d_partial,
                     g.d_cpartial, g.d_energy, g.d_counts, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.d_mperm, g.d_mdecl,
-                    g.d_mwork};
+                    g.d_mwork, g.d_mom};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g.h_pin) (void)hipHostFree(g.h_pin);
     if (g.h_stage) (void)hipHostFree(g.h_stage);
@@ -752,6 +770,8 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
     g.h_ivect.assign(nb * g.ivcap * 3, 0.0);
     g.h_nivect.assign(nb, 0);
     // the LDS-staged kernel asks for more than the default 64 KiB of dynamic LDS
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_model_energy<true, 1024, kFullLayout, false, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_model_energy<true, 1024, kFullLayout>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_list_order),
@@ -761,6 +781,8 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_move_energy<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_move_energy<true, mw::kLayoutSoA, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mw::k_move_energy<true, mw::kLayoutSoA, false, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
     for (int v = 0; v < 12; ++v)   // the sweep driver's dynamic LDS (image vectors of small or sheared cells, staged positions and rows) can pass 64 KiB
         HIPCHK(hipFuncSetAttribute(sweep_kernel(1 + (v & 1), (v >> 1) % 3, v >= 6, 1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
@@ -1295,9 +1317,13 @@ int mw_moves_upload(int n, const int* ils, const int* imol, const double* trial_
     std::vector<int> start((size_t)g.nbox + 1, 0);
     int used_boxes = 0;
     g.m_noself = true;
+    g.m_boxlo = g.nbox; g.m_boxhi = -1; g.m_minreq = n;
     for (int b = 0; b < g.nbox; ++b) {
         start[(size_t)b + 1] = start[b] + cnt[(size_t)b + 1];
-        if (cnt[(size_t)b + 1]) { ++used_boxes; if (!g.h_usegrid[(size_t)b]) g.m_noself = false; }
+        if (cnt[(size_t)b + 1]) {
+            ++used_boxes; if (!g.h_usegrid[(size_t)b]) g.m_noself = false;
+            g.m_boxlo = std::min(g.m_boxlo, b); g.m_boxhi = std::max(g.m_boxhi, b); g.m_minreq = std::min(g.m_minreq, cnt[(size_t)b + 1]);
+        }
     }
     std::vector<int> perm((size_t)n), i0((size_t)n), fill(start.begin(), start.end() - 1);
     std::vector<double> tr(trial_xyz ? (size_t)3 * n : 0);
@@ -1373,20 +1399,36 @@ static int launch_moves(int mode)
     const size_t iv_bytes = kMoveScratch + mw::lds_vec_bytes((size_t)g.ivcap);
     const int kmode = mode | (g.mdecl_par << 2);                          // this launch's count word of the declined list (zeroed by the
     g.mdecl_par ^= 1;                                                     // previous launch's k_move_fallback, or at allocation)
-    if (g.mlds && g.m_noself)
+    // The moment path (mw_move_energy.hip.h): boxes staged in LDS, no self-images, and enough requests per box to pay for the
+    // full-box pass that makes the moments (one pass costs what ~300 requests save; MW_MOVE_MOMENTS=0 | 1 overrides the count rule).
+    // The moments must be those of the positions as they are NOW: they are taken from the last full-box launch only when nothing
+    // that can move a molecule has run since (mw_step_launch: the full-box pass of the same step), else made here.
+    static const char* momenv = std::getenv("MW_MOVE_MOMENTS");
+    const bool mom_ok = g.mlds && g.m_noself && model_geo(1).lds && g.m_boxhi >= g.m_boxlo;
+    const bool fresh = g.d_mom && g.mom_count > 0 && g.mom_first - 1 <= g.m_boxlo && g.m_boxhi < g.mom_first - 1 + g.mom_count;
+    // (a request saves ~0.3 ns of the launch; a box's moments cost 0.13 us as a by-product of the step's full-box pass, 0.32 us as a
+    //  pass of their own: 512 / 1280 requests per box)
+    const bool use_mom = mom_ok && (momenv ? momenv[0] != '0' : g.m_minreq >= (fresh ? 512 : 1280));
+    if (use_mom) {
+        if (!fresh && launch_model_energy(g.m_boxlo + 1, g.m_boxhi - g.m_boxlo + 1, true, false)) return 1;
+        hipLaunchKernelGGL((mw::k_move_energy<true, mw::kLayoutSoA, false, true>), dim3(g.mwork_n), dim3(1024),
+                           iv_bytes + mw::lds_vec_bytes((size_t)g.N) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
+                           g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
+                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode, (const double*)g.d_mom);
+    } else if (g.mlds && g.m_noself)
         hipLaunchKernelGGL((mw::k_move_energy<true, mw::kLayoutSoA, false>), dim3(g.mwork_n), dim3(1024),
                            iv_bytes + mw::lds_vec_bytes((size_t)g.N) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
-                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode);
+                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode, (const double*)nullptr);
     else if (g.mlds)
         hipLaunchKernelGGL(mw::k_move_energy<true>, dim3(g.mwork_n), dim3(1024),
                            iv_bytes + mw::lds_vec_bytes((size_t)g.N) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
-                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode);
+                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode, (const double*)nullptr);
     else
         hipLaunchKernelGGL(mw::k_move_energy<false>, dim3(g.mwork_n), dim3(1024), iv_bytes, g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
-                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode);
+                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode, (const double*)nullptr);
     HIPCHK(hipGetLastError());
     // the requests the fused routine declined (none on ice): plain routine, one wavefront each
     hipLaunchKernelGGL(mw::k_move_fallback, dim3(std::min(1024, (g.mn + 3) / 4)), dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_listm, g.d_nn,
@@ -1414,7 +1456,10 @@ int mw_step_launch(int first_ils, int count, int timer_slot)
             if (!g.ev[s][0]) { HIPCHK(hipEventCreate(&g.ev[s][0])); HIPCHK(hipEventCreate(&g.ev[s][1])); }
         HIPCHK(hipEventRecord(g.ev[timer_slot][0], g.stream));
     }
-    if (launch_model_energy(first_ils, count)) return 1;
+    // (the step's full-box pass leaves every molecule's moments behind when the step's move kernel will take the moment path)
+    static const char* momenv = std::getenv("MW_MOVE_MOMENTS");
+    const bool want_mom = g.mn > 0 && g.mlds && g.m_noself && (momenv ? momenv[0] != '0' : g.m_minreq >= 512);
+    if (launch_model_energy(first_ils, count, want_mom, true)) return 1;
     if (timed) { HIPCHK(hipEventRecord(g.ev[timer_slot][1], g.stream)); HIPCHK(hipEventRecord(g.ev[timer_slot + 1][0], g.stream)); }
     if (launch_moves(3)) return 1;
     if (timed) HIPCHK(hipEventRecord(g.ev[timer_slot + 1][1], g.stream));

@@ -164,6 +164,14 @@ __device__ __forceinline__ void pair_terms(double r2, double& rinv, double& e1, 
     g  = t4 * t2;
 }
 
+// Per-molecule MOMENTS of the in-range neighbourhood, the by-product of the full-box pass that the single-move kernel's moment
+// path consumes (mw_move_energy.hip.h, move_energy_mom_wave): with g_k = exp(gamma sigma/(r_jk - a sigma)) and u_k the unit vector
+// from j to its in-range neighbour k,
+//   [0] S0 = sum g_k   [1..3] S1 = sum g_k u_k   [4..9] S2 = sum g_k u_k u_k^T (xx, yy, zz, xy, xz, yz)   [10] the number of in-range neighbours
+// -- what the i--j--k triplet sum of a molecule i next to j needs of j's other neighbours:
+//   sum_k g_k (u_i . u_k - c0)^2 = u_i^T S2 u_i - 2 c0 u_i . S1 + c0^2 S0.
+constexpr int kMomStride = 12;   // doubles per molecule (96 bytes: six 16-byte stores / loads; 128-byte records -- whole lines -- measured no faster)
+
 // ---- staged vectors in LDS ------------------------------------------------------------
 // LDS layout of the staged positions and image vectors (what a random gather costs the LDS: MI355X_MICROARCH.md,
 // LDS table -- the plain [N][3] layout makes the compiler fuse x,y into ds_read2_b64, which runs at HALF the rate of

@@ -76,7 +76,7 @@ __device__ __forceinline__ uint32_t list_load(ListRsrc rs, uint32_t column_bytes
 template <int BLOCK, bool BATCH4, bool LEAN = false, int QCAP = kQCap, typename PosFn, typename IvFn>
 __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32_t col_next, int mol, int n, int nmax, int c0min,
                                                int N, int S, uint32_t* __restrict__ queue, PosFn getpos, IvFn getiv,
-                                               uint32_t (&cur)[8])
+                                               uint32_t (&cur)[8], double* __restrict__ mom_out = nullptr)
 {
     double xi, yi, zi;
     getpos(mol, xi, yi, zi);
@@ -208,6 +208,11 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
     const double F2 = Sxx * Sxx + Syy * Syy + Szz * Szz + 2.0 * (Sxy * Sxy + Sxz * Sxz + Syz * Syz);
     const double F1 = S1x * S1x + S1y * S1y + S1z * S1z;
     const double T = 0.5 * ((F2 - Q) - 2.0 * kCos0 * (F1 - Q) + kCos0 * kCos0 * (S0 * S0 - Q));
+    if (mom_out) {               // (per lane: this molecule's moments, or nullptr; 16-byte stores: a divergent store costs its 64 addresses, whatever their width)
+        double2* m2 = reinterpret_cast<double2*>(mom_out);
+        m2[0] = make_double2(S0, S1x); m2[1] = make_double2(S1y, S1z); m2[2] = make_double2(Sxx, Syy);
+        m2[3] = make_double2(Szz, Sxy); m2[4] = make_double2(Sxz, Syz); m2[5] = make_double2((double)cnt, 0.0);
+    }
     AtomSum out;
     out.e  = 0.5 * e2 + kLamEps * T;                                                   // :464,483
     out.cnt = cnt;
@@ -229,14 +234,17 @@ constexpr int kStageTicket = 64 * 12;    // doubles of the next box per staging 
 // draws staging tickets (768 doubles of the next box each) and holds them in registers -- free now that its evaluation
 // is over -- until the slowest wavefront arrives at the barrier; then the registers go to LDS.  The HBM round trip of
 // the staging overlaps the workgroup's tail instead of following it; so do the first list reads of the next box.
-template <bool LDSPOS, int BLOCK, int LAYOUT, bool BATCH4 = false>
+// MOMOUT: the build that also leaves every molecule's moments behind (`mom`); the plain build carries none of its registers.
+template <bool LDSPOS, int BLOCK, int LAYOUT, bool BATCH4 = false, bool MOMOUT = false>
 __global__ __launch_bounds__(BLOCK)
 void k_model_energy(const double* __restrict__ pos, const double* __restrict__ ivect,
                     const int* __restrict__ nivect, const uint32_t* __restrict__ list,
                     const int* __restrict__ order, const int* __restrict__ nns, const int* __restrict__ cmax,
                     double* __restrict__ partial, unsigned long long* __restrict__ cpartial,
                     double* __restrict__ energy, unsigned long long* __restrict__ counts,
-                    int N, int S, int ivcap, int box0, int nsplit, int chunk, int count)
+                    int N, int S, int ivcap, int box0, int nsplit, int chunk, int count,
+                    double* __restrict__ mom = nullptr,   // [box][N][kMomStride]: every molecule's moments too (the single-move kernel's moment path)
+                    int write_energy = 1)                 // 0: a pass for the moments only -- energies and counts of the boxes stay as they are
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double gsum[kMaxGroups];                  // per group of 64 columns: summed in group order at the end,
@@ -318,8 +326,9 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
                 if (tn < a1) { col_next = (uint32_t)tn * 4u; n_next = NNS[tn]; mol_next = ORD[tn]; }
             }
             const int cm = __builtin_amdgcn_readfirstlane(CM[grp]);
+            double* mo = (MOMOUT && act) ? mom + ((size_t)b * N + mol) * kMomStride : nullptr;
             AtomSum a = atom_energy<BLOCK, BATCH4>(rs, col, col_next, mol, act ? (n_cur & 0xff) : 0, cm & 0xff, cm >> 8, N, S,
-                                           queue, getpos, getiv, cur);
+                                           queue, getpos, getiv, cur, mo);
             if (act) { np += (unsigned int)a.cnt; nt += (unsigned int)(a.cnt * (a.cnt - 1) / 2); }
             const double ge = dpp_wave_sum(act ? a.e : 0.0);             // fixed tree; total in lane 63
             if (lane == 63) gsum[grp - g0] = ge;
@@ -361,7 +370,8 @@ void k_model_energy(const double* __restrict__ pos, const double* __restrict__ i
             double e = 0.0; unsigned long long p = 0, t = 0;
             for (int k = 0; k < G; ++k) e += gsum[k];
             for (int w = 0; w < BLOCK / 64; ++w) { p += red_p[w]; t += red_t[w]; }
-            if (nsplit == 1) {                           // one workgroup per box: model_energy(ils) and its counts directly
+            if (!write_energy) {
+            } else if (nsplit == 1) {                    // one workgroup per box: model_energy(ils) and its counts directly
                 energy[b] = e; counts[2 * b] = p; counts[2 * b + 1] = t;
             } else {                                     // a split box: k_sum_partials adds the partials in split order
                 const size_t o = (size_t)(b) * nsplit + split;

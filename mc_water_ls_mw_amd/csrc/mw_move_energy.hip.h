@@ -575,6 +575,158 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
     return true;
 }
 
+// -------------------------------------------------------------------------------------
+// THE MOMENT PATH of the batched single-move kernel (round 4).  The i--j--k triplets -- the rows of all in-range neighbours j
+// scanned slot by slot, ~115 distance tests and ~25 rsqrt / exp per evaluation, two thirds of the fused routine's instructions --
+// are sums over j's OTHER neighbours, and those sums do not depend on where i sits:
+//   sum_{k != i} g_jk (u_ji . u_jk - c0)^2 = u^T S2' u - 2 c0 u . S1' + c0^2 S0',     u = unit vector j -> i,
+// with S0', S1', S2' the moments of j's in-range neighbourhood (mw_common.hip.h: kMomStride; computed for every molecule of the box
+// by the full-box pass, k_model_energy's `mom` output) less i's own contribution at its mirrored position.  A request then costs
+// pass 0 (i's own row, as before), one item per in-range neighbour and geometry for the i--j--k sums (a 96-byte read and ~60
+// multiply-adds) and the j--i--k pairs: O(neighbours) like the full-box kernel, instead of O(neighbours^2).
+//
+// The reference's local-energy path drops a triplet slot whose cos(theta) >= 0.99 (molint.F90:367-371; the rule that removes the
+// k == i self term) -- a moment sum cannot drop a term.  But a third body k with cos(theta_ijk) >= 0.99 lies within the cutoff of
+// i itself (|ik|^2 = a^2 + b^2 - 2ab cos < max(a, b)^2 for an angle below 8.2 degrees), i.e. k is one of i's OWN in-range neighbours:
+// the pair pass, which walks all pairs (a, b) of those anyway, tests both of them as centres -- is b within the cutoff of a, and
+// cos(theta_iab) >= 0.99 (less a 1e-9 margin, on squares: no square root)? -- and a request with such a triplet is DECLINED to the
+// plain routine, like the other cases the fused routine does not take.  On ice, and in any physical configuration of this model,
+// there is none.  For boxes whose cells are at least three list radii wide only (SELFIMG = false: an image of i is never a third
+// body of i's neighbours, so each neighbour holds exactly one contribution of i).
+// -------------------------------------------------------------------------------------
+template <typename PosFn, typename IvFn, typename NnFn>
+__device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, NnFn nnof, const double* __restrict__ MOM,
+                                                     WaveScratch* __restrict__ ws, int i, int n_i, uint32_t e,
+                                                     double xo, double yo, double zo, double xn, double yn, double zn,
+                                                     int lane, MoveRes& res)
+{
+    // ---- pass 0: as move_energy_wave -- lanes 0..31 slot l of i's row against the OLD position, lanes 32..63 against the TRIAL one
+    if (n_i > 32) return false;
+    const int half = lane >> 5, sl = lane & 31;
+    const bool has = sl < n_i;
+    const int j = has ? (int)(e & kJMask) : 0, kimg = has ? (int)(e >> kJBits) : 0;
+    double xj, yj, zj, jvx, jvy, jvz;
+    getpos(j, xj, yj, zj);
+    getiv(kimg, jvx, jvy, jvz);
+    const int nnj = has ? nnof(j) : 0;
+    const double qx = xj + jvx, qy = yj + jvy, qz = zj + jvz;                 // molint.F90:269
+    const double rix = half ? xn : xo, riy = half ? yn : yo, riz = half ? zn : zo;
+    const double ax = qx - rix, ay = qy - riy, az = qz - riz;                 // :272
+    const double r2 = ax * ax + ay * ay + az * az;
+    const bool in = has && (r2 < kRcSq);                                      // :276
+    const unsigned long long B = __ballot(in);
+    const unsigned int mo_ = (unsigned int)B, mn_ = (unsigned int)(B >> 32);
+    const unsigned int U = mo_ | mn_;
+    const int cntU = __popc(U);
+    if (cntU > kCap) return false;
+    const bool inu = (U >> sl) & 1u;
+    const int rank = half ? (int)__builtin_amdgcn_mbcnt_hi(U, 0u) : (int)__builtin_amdgcn_mbcnt_lo(U, 0u);
+    // j's moments: requested NOW, by the lane that holds j and this geometry, and used after the pair terms (whose rsqrt /
+    // reciprocal / exp the read hides behind)
+    double M[12];
+    {
+        const double2* Mj = reinterpret_cast<const double2*>(MOM + (size_t)(in ? j : i) * kMomStride);   // (a lane without an in-range j reads i's own: harmless, unused)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { const double2 v = Mj[c]; M[2 * c] = v.x; M[2 * c + 1] = v.y; }
+    }
+    double rinv = 0.0, e1 = 0.0, g = 0.0;
+    if (in) pair_terms(r2, rinv, e1, g);
+    const double qq = kSigSq * rinv * rinv;
+    const double accp = in ? (kAeps * (kBigB * (qq * qq) - 1.0)) * e1 : 0.0;  // :294-297 (old in lanes 0..31, trial in 32..63)
+    const int flg = (int)((mo_ >> sl) & 1u) | (int)(((mn_ >> sl) & 1u) << 1);
+    if (inu) {                                            // the in-range neighbours' records by rank, for the pair pass
+        if (half == 0) {
+            ws->q[0][rank] = qx; ws->q[1][rank] = qy; ws->q[2][rank] = qz;
+            ws->rinvo[rank] = rinv; ws->go[rank] = g;
+            ws->flag[rank] = flg;
+        } else {
+            ws->rinvn[rank] = rinv; ws->gn[rank] = g;
+        }
+    }
+    // list slots each evaluation visits (n_i + the rows of its in-range neighbours): what prices its algorithmic bytes
+    const unsigned int slots = (unsigned int)__builtin_amdgcn_readlane(dpp_wave_sum_i32((in ? nnj : 0) << (half ? 16 : 0)), 63);
+
+    // ---- i--j--k: one item per in-range neighbour and geometry, in the lane that holds them ---------------------------------
+    // i's own term inside j's moments belongs to the OLD position (the one the full-box pass saw): lanes of the trial geometry take
+    // the old 1/r and g from the lane 32 below
+    const int lsrc = (lane & 31) << 2;
+    const double g_old = __hiloint2double(__builtin_amdgcn_ds_bpermute(lsrc, __double2hiint(g)), __builtin_amdgcn_ds_bpermute(lsrc, __double2loint(g)));
+    const double r_old = __hiloint2double(__builtin_amdgcn_ds_bpermute(lsrc, __double2hiint(rinv)), __builtin_amdgcn_ds_bpermute(lsrc, __double2loint(rinv)));
+    double t3 = 0.0;
+    unsigned int nt = 0u;
+    if (in) {
+        double S0 = M[0], S1x = M[1], S1y = M[2], S1z = M[3];
+        double Sxx = M[4], Syy = M[5], Szz = M[6], Sxy = M[7], Sxz = M[8], Syz = M[9];
+        double cn = M[10];
+        if ((mo_ >> sl) & 1u) {      // j's moments hold i at its mirrored (old) position: that term is not a third body
+            const double ux = (xo - qx) * r_old, uy = (yo - qy) * r_old, uz = (zo - qz) * r_old;   // unit vector j -> i (old)
+            const double hx = g_old * ux, hy = g_old * uy, hz = g_old * uz;
+            S0 -= g_old; S1x -= hx; S1y -= hy; S1z -= hz;
+            Sxx -= hx * ux; Syy -= hy * uy; Szz -= hz * uz; Sxy -= hx * uy; Sxz -= hx * uz; Syz -= hy * uz;
+            cn -= 1.0;
+        }
+        const double vx = -ax * rinv, vy = -ay * rinv, vz = -az * rinv;                            // unit vector j -> i, this geometry
+        const double wx = Sxx * vx + Sxy * vy + Sxz * vz, wy = Sxy * vx + Syy * vy + Syz * vz, wz = Sxz * vx + Syz * vy + Szz * vz;
+        const double quad = vx * wx + vy * wy + vz * wz, lin = vx * S1x + vy * S1y + vz * S1z;
+        t3 = g * ((quad - 2.0 * kCos0 * lin) + kCos0 * kCos0 * S0);                                // :324-343,385-387 summed over k
+        nt = (unsigned int)(cn + 0.5);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- j--i--k: the pairs (a < b) of in-range neighbours (:302-318), and the triplets the 0.99 rule could touch ----------------
+    double t3o = 0.0, t3n = 0.0;
+    unsigned int nto = 0u, ntn = 0u;
+    bool hard = false;
+    const int npairs = cntU * (cntU - 1) / 2;
+    for (int base = 0; base < npairs; base += 64) {
+        const int p = base + lane;
+        if (p < npairs) {
+            int b = (int)((1.0f + __builtin_amdgcn_sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+            if (b * (b - 1) / 2 > p) --b;
+            if ((b + 1) * b / 2 <= p) ++b;
+            const int ia = p - b * (b - 1) / 2;
+            const int fl = ws->flag[ia] & ws->flag[b];
+            const double pax = ws->q[0][ia], pay = ws->q[1][ia], paz = ws->q[2][ia];
+            const double pbx = ws->q[0][b], pby = ws->q[1][b], pbz = ws->q[2][b];
+            const double dx = pbx - pax, dy = pby - pay, dz = pbz - paz;      // a -> b
+            const double r2ab = dx * dx + dy * dy + dz * dz;
+            const bool abin = r2ab < kRcSq;                                   // b is a third body of a's (and a of b's)
+            constexpr double kC2 = (0.99 - 1e-9) * (0.99 - 1e-9);
+            if (fl & 1) {
+                const double Ax = xo - pax, Ay = yo - pay, Az = zo - paz, Bx = xo - pbx, By = yo - pby, Bz = zo - pbz;
+                const double rao = ws->rinvo[ia], rbo = ws->rinvo[b];
+                const double ct = ((Ax * Bx + Ay * By + Az * Bz) * rao) * rbo;                     // :316,365
+                if (ct < 0.99) { const double d = ct - kCos0; t3o += ws->go[ia] * (ws->go[b] * (d * d)); ++nto; }
+                const double da = Ax * dx + Ay * dy + Az * dz, db = -(Bx * dx + By * dy + Bz * dz);  // (a->i).(a->b), (b->i).(b->a)
+                hard = hard || (abin && ((da > 0.0 && (da * rao) * (da * rao) >= kC2 * r2ab) || (db > 0.0 && (db * rbo) * (db * rbo) >= kC2 * r2ab)));
+            }
+            if (fl & 2) {
+                const double Ax = xn - pax, Ay = yn - pay, Az = zn - paz, Bx = xn - pbx, By = yn - pby, Bz = zn - pbz;
+                const double ran = ws->rinvn[ia], rbn = ws->rinvn[b];
+                const double ct = ((Ax * Bx + Ay * By + Az * Bz) * ran) * rbn;
+                if (ct < 0.99) { const double d = ct - kCos0; t3n += ws->gn[ia] * (ws->gn[b] * (d * d)); ++ntn; }
+                const double da = Ax * dx + Ay * dy + Az * dz, db = -(Bx * dx + By * dy + Bz * dz);
+                hard = hard || (abin && ((da > 0.0 && (da * ran) * (da * ran) >= kC2 * r2ab) || (db > 0.0 && (db * rbn) * (db * rbn) >= kC2 * r2ab)));
+            }
+        }
+    }
+    const bool decline = __ballot(hard) != 0ull;
+    __builtin_amdgcn_wave_barrier();                          // scratch is reused by the wave's next request
+    if (decline) return false;
+
+    double eo, en;                                                                                 // :397
+    dpp_wave_sum2(kLamEps * (t3o + (half == 0 ? t3 : 0.0)) + (half == 0 ? accp : 0.0),
+                  kLamEps * (t3n + (half == 1 ? t3 : 0.0)) + (half == 1 ? accp : 0.0), eo, en);
+    const unsigned int cs = (unsigned int)__builtin_amdgcn_readlane(
+        dpp_wave_sum_i32((int)((nto + (half == 0 ? nt : 0u)) | ((ntn + (half == 1 ? nt : 0u)) << 16))), 63);
+    res.eo = eo; res.en = en;
+    res.io = (unsigned int)__popc(mo_) + (cs & 0xffffu); res.in_ = (unsigned int)__popc(mn_) + (cs >> 16);
+    res.so = (unsigned int)n_i + (slots & 0xffffu); res.sn = (unsigned int)n_i + (slots >> 16);
+    return true;
+}
+
 // One workgroup per work item {box, first request, last request+1}: the requests are
 // sorted by box on upload, so the workgroup stages that box's positions in LDS once
 // (LDSPOS) and its 16 wavefronts then serve the item's requests from LDS gathers.
@@ -583,7 +735,8 @@ constexpr int kMoveChunk = 2048;   // requests per work item when the box is sta
 
 // (LAYOUT: SoA measures 1.4 % faster than the paired layout here -- 1288 vs 1306 us, tools/kbench -- now that the scan
 // reads one vector less per slot; the full-box kernel keeps the paired layout, where it is the faster one)
-template <bool LDSPOS, int LAYOUT = kLayoutSoA, bool SELFIMG = true>
+// MOMPATH = true (with LDSPOS, SELFIMG = false): the moment path above; `mom` = the box moments [box][N][kMomStride] of the launch's boxes.
+template <bool LDSPOS, int LAYOUT = kLayoutSoA, bool SELFIMG = true, bool MOMPATH = false>
 __global__ __launch_bounds__(1024)
 void k_move_energy(const double* __restrict__ pos, const double* __restrict__ ivect,
                    const int* __restrict__ nivect, const uint32_t* __restrict__ listm,
@@ -594,8 +747,9 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
                    unsigned int* __restrict__ counts,   // [nreq][4]: inter_old, slots_old, inter_new, slots_new
                    int* __restrict__ declined,          // [0], [1] = number of requests left to k_move_fallback (the word of this launch's parity,
                                                         // mode bit 2), then {request, box} pairs
-                   int N, int ivcap, int mode)
+                   int N, int ivcap, int mode, const double* __restrict__ mom = nullptr)
 {
+    static_assert(!MOMPATH || (LDSPOS && !SELFIMG), "the moment path serves boxes staged in LDS whose cells hold no self-images");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int4 w = work[blockIdx.x];
     const int b = w.x;
@@ -679,7 +833,9 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
         if (mode & 2) { xn = tx; yn = ty; zn = tz; }
 
         MoveRes r;
-        const bool fast = move_energy_wave<SELFIMG>(getpos, getiv, row, nnof, ws, niv, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r);
+        bool fast;
+        if constexpr (MOMPATH) fast = move_energy_mom_wave(getpos, getiv, nnof, mom + (size_t)b * N * kMomStride, ws, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r);
+        else fast = move_energy_wave<SELFIMG>(getpos, getiv, row, nnof, ws, niv, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r);
         if (!fast) {
             // a request the fused routine declines (a row longer than 32 entries, more than kCap in-range neighbours, a
             // molecule that neighbours its own image -- never on ice) is left to k_move_fallback: with the plain routine

@@ -457,3 +457,46 @@ def test_single_call_paths_agree(tmp_path):
     dev = np.array([float.fromhex(v) for v in results["device"]])
     lau = np.array([float.fromhex(v) for v in results["launch"]])         # another evaluation order (plain routine): last-bit differences
     assert np.all(np.abs(dev - lau) <= 1e-12 * np.abs(dev))
+
+
+@pytest.mark.parametrize("moments", ["1", "0"])
+def test_moment_path_of_the_move_kernel_and_the_triplets_it_must_decline(moments, c_oracle, monkeypatch):
+    """The batched single-move kernel's MOMENT path (i--j--k triplets from the per-molecule moments the full-box pass leaves behind,
+    mw_move_energy.hip.h) against the oracle, next to the scanning path (MW_MOVE_MOMENTS=0) on the same requests: a 1536-molecule
+    Ic box, thermal -- and with one molecule pushed ALMOST BEHIND a neighbour's neighbour, so that triplets with cos(theta) >= 0.99
+    exist: the reference drops those terms (molint.F90:367-371), a moment sum cannot, and the requests that touch them must come
+    out right all the same (declined to the plain routine).  Energies to 1e-10, interaction and slot counts exact."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.energy import load_boxes
+    monkeypatch.setenv("MW_MOVE_MOMENTS", moments)
+    z = load_golden("ic1536")
+    h = z["h"]
+    x = lat.thermalise(z["xyz"], 0.1, 77)
+    iv = c_oracle.ivects(h)
+    nn, jn, vn = c_oracle.neighbours(x, iv)
+    # molecule a, its nearest neighbour b (central image), and a third molecule c placed on the line a -> b, 1.45 |ab| from a
+    a = 100
+    cands = [(np.linalg.norm(x[jn[a, s] - 1] - x[a]), jn[a, s] - 1) for s in range(nn[a]) if vn[a, s] == 1]
+    dab, b = min(cands)
+    c = next(k for k in range(len(x)) if k not in (a, b) and np.linalg.norm(x[k] - x[a]) > 15.0)
+    x = x.copy()
+    x[c] = x[a] + 1.45 * (x[b] - x[a]) + np.array([0.02, -0.01, 0.015])
+    nn, jn, vn = c_oracle.neighbours(x, iv)
+    em = load_boxes([h], [x])
+    try:
+        rng = np.random.default_rng(5)
+        imol = np.concatenate([np.array([a + 1, b + 1, c + 1] * 3), rng.integers(1, len(x) + 1, 1600)]).astype(np.int32)
+        trial = x[imol - 1] + rng.normal(0.0, 0.4, (len(imol), 3))
+        trial[:3] = x[imol[:3] - 1]                                       # (unmoved: old == new, the dropped terms on both sides)
+        eo, en = em.delta_energy_batch(1, imol, trial)
+        ro, rn = c_oracle.trial_moves(imol, trial, x, iv, nn, jn, vn)
+        assert np.all(np.abs(eo - ro) <= RTOL * np.abs(ro)) and np.all(np.abs((en - eo) - (rn - ro)) <= DE_ATOL)
+        # the pushed molecule really does make such triplets: with the 0.99 rule ignored, b's local energy would be off by far more than the tolerance
+        _, counts_b = c_oracle.local_energy(b + 1, x, iv, nn, jn, vn, counts=True)
+        io, so, inw, sn = em.moves_counts()
+        ref_i = sum(int(c_oracle.local_energy(int(i), x, iv, nn, jn, vn, counts=True)[1].sum()) for i in imol[:64])
+        eo64, _ = em.delta_energy_batch(1, imol[:64], x[imol[:64] - 1])
+        assert em.moves_counts()[0] == ref_i and em.moves_counts()[2] == ref_i          # old = new: the same interactions, counted exactly
+        assert np.all(np.abs(eo64 - ro[:64]) <= RTOL * np.abs(ro[:64]))
+    finally:
+        em.energy_deinit()
