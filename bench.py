@@ -707,13 +707,12 @@ def main():
     # The step's full-box launch also leaves every molecule's moments behind for the step's move kernel (its moment path, DESIGN.md
     # 3.2): ~50 us of stores on top of the evaluation.  The kernel of configs[1] by itself -- compute_model_energy of every walker,
     # nothing else -- is timed here, outside the step loop, and is what `roofline_model_energy` describes.
-    for _ in range(5):
-        em.model_energy_launch(1, W)
-    for k in range(20):                              # one event pair per launch, like the step loop's (an average over a bracket of
-        em.timer_start(4010 + k)                     # back-to-back launches lets their tails and heads overlap: 7 % less per launch)
+    for k in range(24):                              # one event pair per launch, each launch behind a launch of the move kernels -- the
+        em.moves_launch()                            # conditions the kernel has inside a step (a bracket of back-to-back launches lets their
+        em.timer_start(4010 + k)                     # tails and heads overlap: 7 % less per launch; launches on an idle GPU: 8 % more)
         em.model_energy_launch(1, W)
         em.timer_stop(4010 + k)
-    ms_full_plain = float(np.mean([em.timer_ms(4010 + k) for k in range(20)]))
+    ms_full_plain = float(np.mean([em.timer_ms(4010 + k) for k in range(4, 24)]))
     moves_err = None
     if gold is not None and n_gold:    # what the LAST timed k_move_energy launch left on the device, against the reference's values
         eo, en = em.moves_fetch()

@@ -682,33 +682,42 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
     const int npairs = cntU * (cntU - 1) / 2;
     for (int base = 0; base < npairs; base += 64) {
         const int p = base + lane;
-        if (p < npairs) {
-            int b = (int)((1.0f + __builtin_amdgcn_sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+        const bool live = p < npairs;
+        int ia = 0, b = 1;
+        if (live) {
+            b = (int)((1.0f + __builtin_amdgcn_sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
             if (b * (b - 1) / 2 > p) --b;
             if ((b + 1) * b / 2 <= p) ++b;
-            const int ia = p - b * (b - 1) / 2;
-            const int fl = ws->flag[ia] & ws->flag[b];
-            const double pax = ws->q[0][ia], pay = ws->q[1][ia], paz = ws->q[2][ia];
-            const double pbx = ws->q[0][b], pby = ws->q[1][b], pbz = ws->q[2][b];
-            const double dx = pbx - pax, dy = pby - pay, dz = pbz - paz;      // a -> b
-            const double r2ab = dx * dx + dy * dy + dz * dz;
-            const bool abin = r2ab < kRcSq;                                   // b is a third body of a's (and a of b's)
+            ia = p - b * (b - 1) / 2;
+        }
+        const int fl = live ? (ws->flag[ia] & ws->flag[b]) : 0;
+        const double pax = ws->q[0][ia], pay = ws->q[1][ia], paz = ws->q[2][ia];
+        const double pbx = ws->q[0][b], pby = ws->q[1][b], pbz = ws->q[2][b];
+        const double rao = ws->rinvo[ia], rbo = ws->rinvo[b], ran = ws->rinvn[ia], rbn = ws->rinvn[b];
+        const double Aox = xo - pax, Aoy = yo - pay, Aoz = zo - paz, Box = xo - pbx, Boy = yo - pby, Boz = zo - pbz;
+        const double Anx = xn - pax, Any = yn - pay, Anz = zn - paz, Bnx = xn - pbx, Bny = yn - pby, Bnz = zn - pbz;
+        if (fl & 1) {
+            const double ct = ((Aox * Box + Aoy * Boy + Aoz * Boz) * rao) * rbo;                   // :316,365
+            if (ct < 0.99) { const double d = ct - kCos0; t3o += ws->go[ia] * (ws->go[b] * (d * d)); ++nto; }
+        }
+        if (fl & 2) {
+            const double ct = ((Anx * Bnx + Any * Bny + Anz * Bnz) * ran) * rbn;
+            if (ct < 0.99) { const double d = ct - kCos0; t3n += ws->gn[ia] * (ws->gn[b] * (d * d)); ++ntn; }
+        }
+        // a and b as each other's third bodies: only when they lie within the cutoff of each other -- on ice a molecule's in-range
+        // neighbours do not (first shell 2.76 A, its members 4.5 A apart, cutoff 4.31 A), so the wavefront usually skips this
+        const double dx = pbx - pax, dy = pby - pay, dz = pbz - paz;          // a -> b
+        const double r2ab = dx * dx + dy * dy + dz * dz;
+        const bool abin = fl != 0 && r2ab < kRcSq;
+        if (__ballot(abin) != 0ull) {
             constexpr double kC2 = (0.99 - 1e-9) * (0.99 - 1e-9);
-            if (fl & 1) {
-                const double Ax = xo - pax, Ay = yo - pay, Az = zo - paz, Bx = xo - pbx, By = yo - pby, Bz = zo - pbz;
-                const double rao = ws->rinvo[ia], rbo = ws->rinvo[b];
-                const double ct = ((Ax * Bx + Ay * By + Az * Bz) * rao) * rbo;                     // :316,365
-                if (ct < 0.99) { const double d = ct - kCos0; t3o += ws->go[ia] * (ws->go[b] * (d * d)); ++nto; }
-                const double da = Ax * dx + Ay * dy + Az * dz, db = -(Bx * dx + By * dy + Bz * dz);  // (a->i).(a->b), (b->i).(b->a)
-                hard = hard || (abin && ((da > 0.0 && (da * rao) * (da * rao) >= kC2 * r2ab) || (db > 0.0 && (db * rbo) * (db * rbo) >= kC2 * r2ab)));
+            if (abin && (fl & 1)) {
+                const double da = Aox * dx + Aoy * dy + Aoz * dz, db = -(Box * dx + Boy * dy + Boz * dz);    // (a->i).(a->b), (b->i).(b->a)
+                hard = hard || (da > 0.0 && (da * rao) * (da * rao) >= kC2 * r2ab) || (db > 0.0 && (db * rbo) * (db * rbo) >= kC2 * r2ab);
             }
-            if (fl & 2) {
-                const double Ax = xn - pax, Ay = yn - pay, Az = zn - paz, Bx = xn - pbx, By = yn - pby, Bz = zn - pbz;
-                const double ran = ws->rinvn[ia], rbn = ws->rinvn[b];
-                const double ct = ((Ax * Bx + Ay * By + Az * Bz) * ran) * rbn;
-                if (ct < 0.99) { const double d = ct - kCos0; t3n += ws->gn[ia] * (ws->gn[b] * (d * d)); ++ntn; }
-                const double da = Ax * dx + Ay * dy + Az * dz, db = -(Bx * dx + By * dy + Bz * dz);
-                hard = hard || (abin && ((da > 0.0 && (da * ran) * (da * ran) >= kC2 * r2ab) || (db > 0.0 && (db * rbn) * (db * rbn) >= kC2 * r2ab)));
+            if (abin && (fl & 2)) {
+                const double da = Anx * dx + Any * dy + Anz * dz, db = -(Bnx * dx + Bny * dy + Bnz * dz);
+                hard = hard || (da > 0.0 && (da * ran) * (da * ran) >= kC2 * r2ab) || (db > 0.0 && (db * rbn) * (db * rbn) >= kC2 * r2ab);
             }
         }
     }
