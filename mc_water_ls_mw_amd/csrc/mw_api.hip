@@ -135,6 +135,7 @@ struct Ctx {
     int* d_mimol = nullptr;
     double *d_mtrial = nullptr, *d_meold = nullptr, *d_menew = nullptr;
     unsigned int* d_mcnt = nullptr;
+    unsigned int* d_mtot = nullptr; int mtot_cap = 0, mtot_n = 0;   // [work item][4]: the counts of the requests the move kernel's moment path served (d_mcnt holds 0 for those)
     int* d_mperm = nullptr;        // sorted request -> caller's index
     int* d_mdecl = nullptr;        // [0], [1] counts (alternate launches), then {request, box} of the requests k_move_energy left to k_move_fallback
     int mdecl_par = 0;             // which count word the next launch uses (the fallback kernel zeroes the other)
@@ -532,7 +533,7 @@ void release_all()
                     g.d_nivect, g.d_list, g.d_listm, g.d_nn, g.d_stats, g.d_order, g.d_nns, g.d_cmax, g.d_cin, g.d_grid,
                     g.d_usegrid, g.d_cellid, g.d_shift, g.d_sorted, g.d_wrel, g.d_wpos, g.d_wsh, g.d_ccount, g.d_cstart, g.d_ccursor, g.d_partial,
                     g.d_cpartial, g.d_energy, g.d_counts, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.d_mperm, g.d_mdecl,
-                    g.d_mwork, g.d_mom};
+                    g.d_mwork, g.d_mom, g.d_mtot};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g.h_pin) (void)hipHostFree(g.h_pin);
     if (g.h_stage) (void)hipHostFree(g.h_stage);
@@ -1396,6 +1397,13 @@ int mw_moves_upload(int n, const int* ils, const int* imol, const double* trial_
 static int launch_moves(int mode)
 {
     if (g.mn == 0) return 0;
+    if (g.mwork_n > g.mtot_cap) {
+        HIPCHK(hipStreamSynchronize(g.stream));
+        if (g.d_mtot) HIPCHK(hipFree(g.d_mtot));
+        g.mtot_cap = 2 * g.mwork_n;
+        HIPCHK(hipMalloc(&g.d_mtot, (size_t)g.mtot_cap * 4 * sizeof(unsigned int)));
+    }
+    g.mtot_n = 0;
     const size_t iv_bytes = kMoveScratch + mw::lds_vec_bytes((size_t)g.ivcap);
     const int kmode = mode | (g.mdecl_par << 2);                          // this launch's count word of the declined list (zeroed by the
     g.mdecl_par ^= 1;                                                     // previous launch's k_move_fallback, or at allocation)
@@ -1414,21 +1422,22 @@ static int launch_moves(int mode)
         hipLaunchKernelGGL((mw::k_move_energy<true, mw::kLayoutSoA, false, true>), dim3(g.mwork_n), dim3(1024),
                            iv_bytes + mw::lds_vec_bytes((size_t)g.N) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
-                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode, (const double*)g.d_mom);
+                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode, (const double*)g.d_mom, g.d_mtot);
+        g.mtot_n = g.mwork_n;
     } else if (g.mlds && g.m_noself)
         hipLaunchKernelGGL((mw::k_move_energy<true, mw::kLayoutSoA, false>), dim3(g.mwork_n), dim3(1024),
                            iv_bytes + mw::lds_vec_bytes((size_t)g.N) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
-                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode, (const double*)nullptr);
+                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode, (const double*)nullptr, (unsigned int*)nullptr);
     else if (g.mlds)
         hipLaunchKernelGGL(mw::k_move_energy<true>, dim3(g.mwork_n), dim3(1024),
                            iv_bytes + mw::lds_vec_bytes((size_t)g.N) + (((size_t)g.N + 7) & ~(size_t)7) + (size_t)g.mchunk * sizeof(int), g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
-                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode, (const double*)nullptr);
+                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode, (const double*)nullptr, (unsigned int*)nullptr);
     else
         hipLaunchKernelGGL(mw::k_move_energy<false>, dim3(g.mwork_n), dim3(1024), iv_bytes, g.stream,
                            g.d_pos, g.d_ivect, g.d_nivect, g.d_listm, g.d_nn, g.d_mwork, g.d_mimol, g.d_mtrial, g.d_mperm,
-                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode, (const double*)nullptr);
+                           g.d_meold, g.d_menew, g.d_mcnt, g.d_mdecl, g.N, g.ivcap, kmode, (const double*)nullptr, (unsigned int*)nullptr);
     HIPCHK(hipGetLastError());
     // the requests the fused routine declined (none on ice): plain routine, one wavefront each
     hipLaunchKernelGGL(mw::k_move_fallback, dim3(std::min(1024, (g.mn + 3) / 4)), dim3(256), 0, g.stream, g.d_pos, g.d_ivect, g.d_listm, g.d_nn,
@@ -1485,12 +1494,18 @@ int mw_moves_counts(long long out[4])
     out[0] = out[1] = out[2] = out[3] = 0;
     if (g.mn == 0) return 0;
     std::vector<unsigned int> c((size_t)g.mn * 4);
+    unsigned long long tot[4] = {0, 0, 0, 0};
+    std::vector<unsigned int> it((size_t)g.mtot_n * 4);
     HIPCHK(hipMemcpyAsync(c.data(), g.d_mcnt, sizeof(unsigned int) * 4 * g.mn, hipMemcpyDeviceToHost, g.stream));
+    if (g.mtot_n) HIPCHK(hipMemcpyAsync(it.data(), g.d_mtot, sizeof(unsigned int) * 4 * g.mtot_n, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
+    for (int k = 0; k < g.mtot_n; ++k) for (int q = 0; q < 4; ++q) tot[q] += it[4 * (size_t)k + q];
     for (int m = 0; m < g.mn; ++m) {
         if (g.mmode & 1) { out[0] += c[4 * (size_t)m]; out[1] += c[4 * (size_t)m + 1]; }
         if (g.mmode & 2) { out[2] += c[4 * (size_t)m + 2]; out[3] += c[4 * (size_t)m + 3]; }
     }
+    if (g.mmode & 1) { out[0] += (long long)tot[0]; out[1] += (long long)tot[1]; }      // (the moment path's requests: summed on the device)
+    if (g.mmode & 2) { out[2] += (long long)tot[2]; out[3] += (long long)tot[3]; }
     return 0;
 }
 

@@ -594,11 +594,14 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
 // there is none.  For boxes whose cells are at least three list radii wide only (SELFIMG = false: an image of i is never a third
 // body of i's neighbours, so each neighbour holds exactly one contribution of i).
 // -------------------------------------------------------------------------------------
+// `ptab[p]` = (a | b << 8) of the p-th pair a < b (a table in LDS: decoding p costs a dozen instructions otherwise).  The interaction
+// and slot counts are ADDED, lane by lane, to `acc` = {interactions old, slots old, interactions new, slots new}: the caller sums
+// them over the lanes once per work item instead of once per request.
 template <typename PosFn, typename IvFn, typename NnFn>
 __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, NnFn nnof, const double* __restrict__ MOM,
-                                                     WaveScratch* __restrict__ ws, int i, int n_i, uint32_t e,
+                                                     WaveScratch* __restrict__ ws, const unsigned short* __restrict__ ptab, int i, int n_i, uint32_t e,
                                                      double xo, double yo, double zo, double xn, double yn, double zn,
-                                                     int lane, MoveRes& res)
+                                                     int lane, MoveRes& res, unsigned int (&acc)[4])
 {
     // ---- pass 0: as move_energy_wave -- lanes 0..31 slot l of i's row against the OLD position, lanes 32..63 against the TRIAL one
     if (n_i > 32) return false;
@@ -643,8 +646,6 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
             ws->rinvn[rank] = rinv; ws->gn[rank] = g;
         }
     }
-    // list slots each evaluation visits (n_i + the rows of its in-range neighbours): what prices its algorithmic bytes
-    const unsigned int slots = (unsigned int)__builtin_amdgcn_readlane(dpp_wave_sum_i32((in ? nnj : 0) << (half ? 16 : 0)), 63);
 
     // ---- i--j--k: one item per in-range neighbour and geometry, in the lane that holds them ---------------------------------
     // i's own term inside j's moments belongs to the OLD position (the one the full-box pass saw): lanes of the trial geometry take
@@ -675,50 +676,37 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- j--i--k: the pairs (a < b) of in-range neighbours (:302-318), and the triplets the 0.99 rule could touch ----------------
-    double t3o = 0.0, t3n = 0.0;
-    unsigned int nto = 0u, ntn = 0u;
+    // ---- j--i--k: the pairs (a < b) of in-range neighbours (:302-318), one item per pair AND geometry (item t: pair t >> 1, geometry
+    // t & 1), and the triplets the 0.99 rule could touch ---------------------------------------------------------------------------
+    double t3p = 0.0;
+    unsigned int ntp = 0u;
     bool hard = false;
-    const int npairs = cntU * (cntU - 1) / 2;
-    for (int base = 0; base < npairs; base += 64) {
-        const int p = base + lane;
-        const bool live = p < npairs;
-        int ia = 0, b = 1;
-        if (live) {
-            b = (int)((1.0f + __builtin_amdgcn_sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
-            if (b * (b - 1) / 2 > p) --b;
-            if ((b + 1) * b / 2 <= p) ++b;
-            ia = p - b * (b - 1) / 2;
-        }
-        const int fl = live ? (ws->flag[ia] & ws->flag[b]) : 0;
+    const int gq = lane & 1;                                  // this lane's geometry in the pair pass
+    const double rqx = gq ? xn : xo, rqy = gq ? yn : yo, rqz = gq ? zn : zo;
+    const double* rinvq = gq ? ws->rinvn : ws->rinvo;
+    const double* gvq = gq ? ws->gn : ws->go;
+    const int nitems = cntU * (cntU - 1);                     // 2 x pairs
+    for (int base = 0; base < nitems; base += 64) {
+        const int t = base + lane;
+        const bool live = t < nitems;
+        const unsigned int ab = live ? (unsigned int)ptab[t >> 1] : 0x0100u;
+        const int ia = (int)(ab & 0xffu), b = (int)(ab >> 8);
+        const bool act = live && (((ws->flag[ia] & ws->flag[b]) >> gq) & 1);
         const double pax = ws->q[0][ia], pay = ws->q[1][ia], paz = ws->q[2][ia];
         const double pbx = ws->q[0][b], pby = ws->q[1][b], pbz = ws->q[2][b];
-        const double rao = ws->rinvo[ia], rbo = ws->rinvo[b], ran = ws->rinvn[ia], rbn = ws->rinvn[b];
-        const double Aox = xo - pax, Aoy = yo - pay, Aoz = zo - paz, Box = xo - pbx, Boy = yo - pby, Boz = zo - pbz;
-        const double Anx = xn - pax, Any = yn - pay, Anz = zn - paz, Bnx = xn - pbx, Bny = yn - pby, Bnz = zn - pbz;
-        if (fl & 1) {
-            const double ct = ((Aox * Box + Aoy * Boy + Aoz * Boz) * rao) * rbo;                   // :316,365
-            if (ct < 0.99) { const double d = ct - kCos0; t3o += ws->go[ia] * (ws->go[b] * (d * d)); ++nto; }
-        }
-        if (fl & 2) {
-            const double ct = ((Anx * Bnx + Any * Bny + Anz * Bnz) * ran) * rbn;
-            if (ct < 0.99) { const double d = ct - kCos0; t3n += ws->gn[ia] * (ws->gn[b] * (d * d)); ++ntn; }
-        }
+        const double ra = rinvq[ia], rb = rinvq[b];
+        const double Ax = rqx - pax, Ay = rqy - pay, Az = rqz - paz, Bx = rqx - pbx, By = rqy - pby, Bz = rqz - pbz;
+        const double ct = ((Ax * Bx + Ay * By + Az * Bz) * ra) * rb;                               // :316,365
+        if (act && ct < 0.99) { const double d = ct - kCos0; t3p += gvq[ia] * (gvq[b] * (d * d)); ++ntp; }   // :367-368,385-387
         // a and b as each other's third bodies: only when they lie within the cutoff of each other -- on ice a molecule's in-range
         // neighbours do not (first shell 2.76 A, its members 4.5 A apart, cutoff 4.31 A), so the wavefront usually skips this
         const double dx = pbx - pax, dy = pby - pay, dz = pbz - paz;          // a -> b
         const double r2ab = dx * dx + dy * dy + dz * dz;
-        const bool abin = fl != 0 && r2ab < kRcSq;
+        const bool abin = act && r2ab < kRcSq;
         if (__ballot(abin) != 0ull) {
             constexpr double kC2 = (0.99 - 1e-9) * (0.99 - 1e-9);
-            if (abin && (fl & 1)) {
-                const double da = Aox * dx + Aoy * dy + Aoz * dz, db = -(Box * dx + Boy * dy + Boz * dz);    // (a->i).(a->b), (b->i).(b->a)
-                hard = hard || (da > 0.0 && (da * rao) * (da * rao) >= kC2 * r2ab) || (db > 0.0 && (db * rbo) * (db * rbo) >= kC2 * r2ab);
-            }
-            if (abin && (fl & 2)) {
-                const double da = Anx * dx + Any * dy + Anz * dz, db = -(Bnx * dx + Bny * dy + Bnz * dz);
-                hard = hard || (da > 0.0 && (da * ran) * (da * ran) >= kC2 * r2ab) || (db > 0.0 && (db * rbn) * (db * rbn) >= kC2 * r2ab);
-            }
+            const double da = Ax * dx + Ay * dy + Az * dz, db = -(Bx * dx + By * dy + Bz * dz);    // (a->i).(a->b), (b->i).(b->a)
+            hard = hard || (abin && ((da > 0.0 && (da * ra) * (da * ra) >= kC2 * r2ab) || (db > 0.0 && (db * rb) * (db * rb) >= kC2 * r2ab)));
         }
     }
     const bool decline = __ballot(hard) != 0ull;
@@ -726,13 +714,14 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
     if (decline) return false;
 
     double eo, en;                                                                                 // :397
-    dpp_wave_sum2(kLamEps * (t3o + (half == 0 ? t3 : 0.0)) + (half == 0 ? accp : 0.0),
-                  kLamEps * (t3n + (half == 1 ? t3 : 0.0)) + (half == 1 ? accp : 0.0), eo, en);
-    const unsigned int cs = (unsigned int)__builtin_amdgcn_readlane(
-        dpp_wave_sum_i32((int)((nto + (half == 0 ? nt : 0u)) | ((ntn + (half == 1 ? nt : 0u)) << 16))), 63);
+    dpp_wave_sum2(kLamEps * ((gq == 0 ? t3p : 0.0) + (half == 0 ? t3 : 0.0)) + (half == 0 ? accp : 0.0),
+                  kLamEps * ((gq == 1 ? t3p : 0.0) + (half == 1 ? t3 : 0.0)) + (half == 1 ? accp : 0.0), eo, en);
     res.eo = eo; res.en = en;
-    res.io = (unsigned int)__popc(mo_) + (cs & 0xffffu); res.in_ = (unsigned int)__popc(mn_) + (cs >> 16);
-    res.so = (unsigned int)n_i + (slots & 0xffffu); res.sn = (unsigned int)n_i + (slots >> 16);
+    // this request's interactions (in-range pairs + triplet slots that contribute) and list slots (n_i + the rows of its in-range
+    // neighbours: what prices its algorithmic bytes), left in the lanes that know them
+    const unsigned int ci = (in ? 1u : 0u) + nt, cs = (in ? (unsigned int)nnj : 0u) + (sl == 0 ? (unsigned int)n_i : 0u);
+    acc[0] += (half == 0 ? ci : 0u) + (gq == 0 ? ntp : 0u); acc[1] += half == 0 ? cs : 0u;
+    acc[2] += (half == 1 ? ci : 0u) + (gq == 1 ? ntp : 0u); acc[3] += half == 1 ? cs : 0u;
     return true;
 }
 
@@ -756,9 +745,20 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
                    unsigned int* __restrict__ counts,   // [nreq][4]: inter_old, slots_old, inter_new, slots_new
                    int* __restrict__ declined,          // [0], [1] = number of requests left to k_move_fallback (the word of this launch's parity,
                                                         // mode bit 2), then {request, box} pairs
-                   int N, int ivcap, int mode, const double* __restrict__ mom = nullptr)
+                   int N, int ivcap, int mode, const double* __restrict__ mom = nullptr,
+                   unsigned int* __restrict__ mtot = nullptr)   // MOMPATH: [work item][4] = {interactions old, slots old, interactions new, slots new} of the item's served requests
 {
     static_assert(!MOMPATH || (LDSPOS && !SELFIMG), "the moment path serves boxes staged in LDS whose cells hold no self-images");
+    __shared__ unsigned short s_ptab[MOMPATH ? kCap * (kCap - 1) / 2 : 1];           // pair p -> (a | b << 8), a < b
+    if constexpr (MOMPATH) {
+        for (int p = threadIdx.x; p < kCap * (kCap - 1) / 2; p += 1024) {
+            int b = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+            if (b * (b - 1) / 2 > p) --b;
+            if ((b + 1) * b / 2 <= p) ++b;
+            s_ptab[p] = (unsigned short)((p - b * (b - 1) / 2) | (b << 8));
+        }
+    }
+    unsigned int acc[4] = {0u, 0u, 0u, 0u};
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int4 w = work[blockIdx.x];
     const int b = w.x;
@@ -843,7 +843,7 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
 
         MoveRes r;
         bool fast;
-        if constexpr (MOMPATH) fast = move_energy_mom_wave(getpos, getiv, nnof, mom + (size_t)b * N * kMomStride, ws, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r);
+        if constexpr (MOMPATH) fast = move_energy_mom_wave(getpos, getiv, nnof, mom + (size_t)b * N * kMomStride, ws, s_ptab, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r, acc);
         else fast = move_energy_wave<SELFIMG>(getpos, getiv, row, nnof, ws, niv, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r);
         if (!fast) {
             // a request the fused routine declines (a row longer than 32 entries, more than kCap in-range neighbours, a
@@ -856,10 +856,25 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
             }
         } else if (lane == 0) {
             const size_t o = (size_t)perm[m];
+            if constexpr (MOMPATH) { r.io = r.so = r.in_ = r.sn = 0u; }       // (the counts of served requests go to `mtot`, summed per work item)
             if (mode & 1) { e_old[o] = r.eo; counts[4 * o] = r.io; counts[4 * o + 1] = r.so; }
             if (mode & 2) { e_new[o] = r.en; counts[4 * o + 2] = r.in_; counts[4 * o + 3] = r.sn; }
         }
         cur = nxt; i = i_nx; e = e_nx; tx = tx_nx; ty = ty_nx; tz = tz_nx;
+    }
+    if constexpr (MOMPATH) {         // the item's counts: lanes -> wavefront -> workgroup, ONE plain store per item (thousands of wavefronts adding to
+        __shared__ unsigned int s_tot[16][4];                              // four global words serialise: +0.3 ms on a 0.9 ms launch)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int tot = dpp_wave_sum_i32((int)acc[c]);
+            if (lane == 63) s_tot[wave][c] = (unsigned int)tot;
+        }
+        __syncthreads();
+        if (tid < 4) {
+            unsigned int t = 0u;
+            for (int wv = 0; wv < 16; ++wv) t += s_tot[wv][tid];
+            mtot[4 * (size_t)blockIdx.x + tid] = t;
+        }
     }
 }
 
