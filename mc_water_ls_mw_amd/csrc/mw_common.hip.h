@@ -167,10 +167,11 @@ __device__ __forceinline__ void pair_terms(double r2, double& rinv, double& e1, 
 // Per-molecule MOMENTS of the in-range neighbourhood, the by-product of the full-box pass that the single-move kernel's moment
 // path consumes (mw_move_energy.hip.h, move_energy_mom_wave): with g_k = exp(gamma sigma/(r_jk - a sigma)) and u_k the unit vector
 // from j to its in-range neighbour k,
-//   [0] S0 = sum g_k   [1..3] S1 = sum g_k u_k   [4..9] S2 = sum g_k u_k u_k^T (xx, yy, zz, xy, xz, yz)   [10] the number of in-range neighbours
+//   [0] S0 = sum g_k   [1..3] S1 = sum g_k u_k   [4..8] S2 = sum g_k u_k u_k^T (xx, yy, xy, xz, yz; zz = S0 - xx - yy: the u_k are unit
+//   vectors)   [9] the number of in-range neighbours
 // -- what the i--j--k triplet sum of a molecule i next to j needs of j's other neighbours:
 //   sum_k g_k (u_i . u_k - c0)^2 = u_i^T S2 u_i - 2 c0 u_i . S1 + c0^2 S0.
-constexpr int kMomStride = 12;   // doubles per molecule (96 bytes: six 16-byte stores / loads; 128-byte records -- whole lines -- measured no faster)
+constexpr int kMomStride = 10;   // doubles per molecule (80 bytes: five 16-byte stores / loads -- the full-box pass that writes them is bound by those bytes)
 
 // ---- staged vectors in LDS ------------------------------------------------------------
 // LDS layout of the staged positions and image vectors (what a random gather costs the LDS: MI355X_MICROARCH.md,

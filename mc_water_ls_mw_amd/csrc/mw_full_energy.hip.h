@@ -211,7 +211,7 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
     if (mom_out) {               // (per lane: this molecule's moments, or nullptr; 16-byte stores: a divergent store costs its 64 addresses, whatever their width)
         double2* m2 = reinterpret_cast<double2*>(mom_out);
         m2[0] = make_double2(S0, S1x); m2[1] = make_double2(S1y, S1z); m2[2] = make_double2(Sxx, Syy);
-        m2[3] = make_double2(Szz, Sxy); m2[4] = make_double2(Sxz, Syz); m2[5] = make_double2((double)cnt, 0.0);
+        m2[3] = make_double2(Sxy, Sxz); m2[4] = make_double2(Syz, (double)cnt);
     }
     AtomSum out;
     out.e  = 0.5 * e2 + kLamEps * T;                                                   // :464,483

@@ -626,11 +626,11 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
     const int rank = half ? (int)__builtin_amdgcn_mbcnt_hi(U, 0u) : (int)__builtin_amdgcn_mbcnt_lo(U, 0u);
     // j's moments: requested NOW, by the lane that holds j and this geometry, and used after the pair terms (whose rsqrt /
     // reciprocal / exp the read hides behind)
-    double M[12];
+    double M[10];
     {
         const double2* Mj = reinterpret_cast<const double2*>(MOM + (size_t)(in ? j : i) * kMomStride);   // (a lane without an in-range j reads i's own: harmless, unused)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) { const double2 v = Mj[c]; M[2 * c] = v.x; M[2 * c + 1] = v.y; }
+        for (int c = 0; c < 5; ++c) { const double2 v = Mj[c]; M[2 * c] = v.x; M[2 * c + 1] = v.y; }
     }
     double rinv = 0.0, e1 = 0.0, g = 0.0;
     if (in) pair_terms(r2, rinv, e1, g);
@@ -657,8 +657,9 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
     unsigned int nt = 0u;
     if (in) {
         double S0 = M[0], S1x = M[1], S1y = M[2], S1z = M[3];
-        double Sxx = M[4], Syy = M[5], Szz = M[6], Sxy = M[7], Sxz = M[8], Syz = M[9];
-        double cn = M[10];
+        double Sxx = M[4], Syy = M[5], Sxy = M[6], Sxz = M[7], Syz = M[8];
+        double Szz = (S0 - Sxx) - Syy;                       // (trace of sum g u u^T = sum g)
+        double cn = M[9];
         if ((mo_ >> sl) & 1u) {      // j's moments hold i at its mirrored (old) position: that term is not a third body
             const double ux = (xo - qx) * r_old, uy = (yo - qy) * r_old, uz = (zo - qz) * r_old;   // unit vector j -> i (old)
             const double hx = g_old * ux, hy = g_old * uy, hz = g_old * uz;
