@@ -124,6 +124,16 @@ __device__ __forceinline__ void dev_recipmatrix(const double* __restrict__ h, do
     for (int i = 0; i < 9; ++i) rc[i] *= f;
 }
 
+// Diagnostic build only (-DMW_SWEEP_STAMPS, tools/sweep_stamps.py): cycles of walker 0's first wavefront per phase of a round,
+// summed over the launch into g_sweep_stamps[0..15] (mw_move_energy.hip.h holds the array and the stages of one evaluation).
+#ifdef MW_SWEEP_STAMPS
+#define MW_SW_NOW() ((blockIdx.x == 0 && wv == 0) ? (unsigned long long)clock64() : 0ull)
+#define MW_SW_ACC(k, d) do { if (blockIdx.x == 0 && wv == 0 && lane == 0) g_sweep_stamps[k] += (d); } while (0)
+#else
+#define MW_SW_NOW() 0ull
+#define MW_SW_ACC(k, d) do { } while (0)
+#endif
+
 constexpr int kSweepQCap = 9;                             // in-range queue of a volume move's full-box energy: sized to fit the scratch record
 // -------------------------------------------------------------------------------------
 // Volume move of one walker by its wavefront: mc_volume (mc_moves.F90:1216-1534; ref_ljr,
@@ -324,6 +334,7 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
     constexpr int L = NLAT;
     const bool active = wv < NLAT;
     const int l = active ? wv : 0;                                                 // this wavefront's lattice
+    [[maybe_unused]] const unsigned long long tv0 = MW_SW_NOW();
     // the old cell of this lattice, kept in LDS (c.sbk: [lattice][hmatrix 9 | recip 9 | new recip 9]): eighteen wave-uniform
     // doubles are thirty-six vector registers, held across the full-box energy evaluation
     double* bk_h = c.sbk + 27 * l;
@@ -353,10 +364,13 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
     double new_e = 0.0;
     int bad = 0;
     bool rescaled = false;
+    [[maybe_unused]] const unsigned long long tv1 = MW_SW_NOW();
+    MW_SW_ACC(34, tv1 - tv0);
     if (active && !bad0) {
         dev_rescale(c, l, bk_r, c.shmat + 9 * l, lane);
         rescaled = true;
         wave_sync();
+        MW_SW_ACC(35, MW_SW_NOW() - tv1);
         const int niv = dev_compute_ivects(c.shmat + 9 * l, c.siv + (size_t)l * c.ivcap * 3,
                                            c.ivect_g + (size_t)l * c.ivcap * 3, c.ivcap, lane);
         if (lane == 0) {
@@ -368,9 +382,12 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
             if (niv >= 0) { c.sniv[l] = niv; c.nivect_g[l] = niv; }
         }
         wave_sync();
+        [[maybe_unused]] const unsigned long long tv2 = MW_SW_NOW();
         if (niv < 0) bad = 1;
         else new_e = dev_wave_model_energy(c, l, lane);
+        MW_SW_ACC(36, MW_SW_NOW() - tv2); MW_SW_ACC(37, tv2 - tv1);
     }
+    [[maybe_unused]] const unsigned long long tv3 = MW_SW_NOW();
     if (active && lane == 0) { sx[l] = new_e; sdec[2 + l] = bad; }
     wg_sync<NW>();
     int ok = 0, anybad = 0;
@@ -380,6 +397,8 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
         if (lane == 0) { sdec[0] = ok; sdec[1] = anybad; }
     }
     wg_sync<NW>();
+    [[maybe_unused]] const unsigned long long tv4 = MW_SW_NOW();
+    MW_SW_ACC(38, tv4 - tv3);
     ok = sdec[0]; anybad = sdec[1];
     if (active && !ok) {                                                                         // :1426-1530
         if (lane < 9) bk_n[lane] = c.srecip[l * 9 + lane];
@@ -400,6 +419,7 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
         c.vol_g[l] = c.svol[l];
     }
     wg_sync<NW>();
+    MW_SW_ACC(39, MW_SW_NOW() - tv4); MW_SW_ACC(40, 1ull); MW_SW_ACC(41, MW_SW_NOW() - tv0);
     return anybad ? -1 : ok;
 }
 
@@ -420,16 +440,6 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
 //    not in registers: a wave-uniform double costs two VECTOR registers, and thirty of them held across the energy
 //    evaluation were the difference between two and four wavefronts per SIMD.
 // =====================================================================================
-// Diagnostic build only (-DMW_SWEEP_STAMPS, tools/sweep_stamps.py): cycles of walker 0's first wavefront per phase of a round,
-// summed over the launch into g_sweep_stamps[0..15] (mw_move_energy.hip.h holds the array and the stages of one evaluation).
-#ifdef MW_SWEEP_STAMPS
-#define MW_SW_NOW() ((blockIdx.x == 0 && wv == 0) ? (unsigned long long)clock64() : 0ull)
-#define MW_SW_ACC(k, d) do { if (blockIdx.x == 0 && wv == 0 && lane == 0) g_sweep_stamps[k] += (d); } while (0)
-#else
-#define MW_SW_NOW() 0ull
-#define MW_SW_ACC(k, d) do { } while (0)
-#endif
-
 struct WalkerCtl {
     // the launch's parameters as this walker sees them (its own window, step sizes, increment)
     double beta, pressure, dref, av_binwidth, log_unbiased_norm, transP, ref1, ref2, wl_alpha, orig_wl_factor, mu_min, mu_max;
@@ -1278,6 +1288,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             if (ntr == s && mv + s < nmoves && !(WITHVOL && !(U0[8 * s + 7] < C.transP))) ++ntr;
 
         if (ntr == 0) {                                                           // mc_moves.F90:232-235: a volume move
+            [[maybe_unused]] const unsigned long long tvm = MW_SW_NOW();
             if constexpr (WITHVOL) {
                 // Everything the volume move addresses is worked out HERE, from a lane number and a box number the compiler
                 // cannot see through: hoisted out of the move loop, these loop-invariant addresses are what pushed the build
@@ -1388,6 +1399,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 if (L == 2) { wg_sync<NW>(); ls = sdec[1]; }       // (MINU or the switch may have changed the active lattice)
                 else wave_sync();
             }
+            MW_SW_ACC(42, MW_SW_NOW() - tvm);
             mv += 1;
             continue;
         }

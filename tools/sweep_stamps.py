@@ -71,6 +71,9 @@ def case(name, cells, nlat, walkers, nmoves, wl=False, npt=False, sigma=0.05, mu
         for k, label in PHASES.items():
             rec[label + " [us/move]"] = st[k] / cyc_per_us / max(moves, 1.0)
         rec["bulk: calls, moves committed, slots predicted, stop bits"] = [st[16], st[9], st[32], st[33]]
+        nv = max(st[40], 1.0)
+        rec["volume move [us per volume move]: count, set-up, rescale, ivects+recip, full-box energy, decide, restore+mirror, total in routine, total in branch"] = \
+            [st[40]] + [st[k] / cyc_per_us / nv for k in (34, 35, 37, 36, 38, 39, 41, 42)]
         rec["evaluation stages of wavefront 0 [us per evaluation]"] = {label: st[k] / cyc_per_us / max(rounds, 1.0) for k, label in STAGES.items()}
         out["look-ahead " + ahead] = rec
         em.energy_deinit()
