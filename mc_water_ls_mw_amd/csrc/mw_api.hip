@@ -118,6 +118,7 @@ struct Ctx {
     double* d_wwin = nullptr;                    // [walker][4] start_bin, end_bin, mu_lo, mu_hi ('dd' windows); used when has_windows
     double *d_wfac = nullptr, *d_wsum = nullptr; // [walker] Wang-Landau increment, Swetnam's visit total
     int* d_winflag = nullptr;                    // [walker] walker_in_window
+    double* d_wmom = nullptr; size_t wmom_cap = 0;   // the driver's moment scratch (doubles), grown on demand
     double* d_wstep = nullptr;                   // [walker][2] max_trans, dv_max (bohr) when the walkers' step sizes differ (mw_sweep_steps)
     bool has_steps = false;
     int sweep_log_ahead = 8;                     // look-ahead allowed when the move log is on (tests pin it to compare builds)
@@ -533,7 +534,7 @@ void release_all()
                     g.d_nivect, g.d_list, g.d_listm, g.d_nn, g.d_stats, g.d_order, g.d_nns, g.d_cmax, g.d_cin, g.d_grid,
                     g.d_usegrid, g.d_cellid, g.d_shift, g.d_sorted, g.d_wrel, g.d_wpos, g.d_wsh, g.d_ccount, g.d_cstart, g.d_ccursor, g.d_partial,
                     g.d_cpartial, g.d_energy, g.d_counts, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.d_mperm, g.d_mdecl,
-                    g.d_mwork, g.d_mom, g.d_mtot};
+                    g.d_mwork, g.d_mom, g.d_mtot, g.d_wmom};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g.h_pin) (void)hipHostFree(g.h_pin);
     if (g.h_stage) (void)hipHostFree(g.h_stage);
@@ -2143,10 +2144,27 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
     const double* wwin = g.has_windows ? (const double*)g.d_wwin : (const double*)nullptr;
     const double* wstep = g.has_steps ? (const double*)g.d_wstep : (const double*)nullptr;
     int w0 = first_walker - 1;
+    // the moment path of walkers entirely in LDS (mw_sweep.hip.h): 2 x L x N x kMomStride doubles of scratch per walker of the launch
+    // (MW_SWEEP_MOMENTS=0: the row-scanning evaluation instead)
+    double* wmom = nullptr;
+    {
+        const char* e = getenv("MW_SWEEP_MOMENTS");
+        if (ldslist && !(e && e[0] == '0')) {
+            const size_t need = (size_t)count * 2 * L * g.N * mw::kMomStride;
+            if (need > g.wmom_cap) {
+                HIPCHK(hipStreamSynchronize(g.stream));
+                if (g.d_wmom) HIPCHK(hipFree(g.d_wmom));
+                g.d_wmom = nullptr; g.wmom_cap = 0;
+                HIPCHK(hipMalloc(&g.d_wmom, need * sizeof(double)));
+                g.wmom_cap = need;
+            }
+            wmom = g.d_wmom;
+        }
+    }
     void* args[] = {&g.d_pos, &g.d_hmat, &g.d_ivect, &g.d_nivect, &g.d_listm, &g.d_list, &g.d_nn, &g.d_order, &g.d_nns, &g.d_cmax,
                     &g.d_energy, &g.d_wls, &g.d_wmu, &g.d_wacc, &g.d_wswitch, &g.d_wshift, &g.sp, &g.d_wweight, &g.d_whist, &g.d_wuhist,
                     &g.d_sw_mubin, &g.d_sw_binwidth, &g.d_volume, &g.d_wvol, &g.d_wflag, &g.N, &g.S, &g.ivcap, &nmoves, &seed, &move0,
-                    &w0, &dlog, &rstride, &wwin, &g.d_wfac, &g.d_wsum, &g.d_winflag, &wstep};
+                    &w0, &dlog, &rstride, &wwin, &g.d_wfac, &g.d_wsum, &g.d_winflag, &wstep, &wmom};
     HIPCHK(hipLaunchKernel(kern, dim3(count), dim3(64 * L * spec), args, lay.total, g.stream));
     HIPCHK(hipGetLastError());
     g.last_sweep[0] = L; g.last_sweep[1] = spec; g.last_sweep[2] = ldslist ? 2 : (ldspos ? 1 : 0); g.last_sweep[3] = withvol ? 1 : 0;

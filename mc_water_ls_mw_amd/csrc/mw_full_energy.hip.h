@@ -3,6 +3,7 @@
 #pragma once
 
 #include "mw_common.hip.h"
+#include <type_traits>
 
 namespace mw {
 
@@ -73,11 +74,17 @@ __device__ __forceinline__ uint32_t list_load(ListRsrc rs, uint32_t column_bytes
 // in flight, so the HBM latency of the list stream hides behind the LDS gathers and distance tests.
 // LEAN = true (the Monte Carlo driver's volume moves, where this routine is a guest in a kernel sized for something else):
 // no chunk-ahead list prefetch and no double-buffered gathers -- twenty vector registers fewer, `cur` / `col_next` unused.
-template <int BLOCK, bool BATCH4, bool LEAN = false, int QCAP = kQCap, typename PosFn, typename IvFn>
+// `ent` (LEAN only): where a lane's list entries come from when not from the slot-major list in global memory -- the Monte Carlo driver's
+// small walkers keep their rows in LDS (`ent(s)` = entry s of this lane's molecule, 0 past its end; then rs / col are unused).
+struct ListFromGlobal { static constexpr bool kGlobal = true; __device__ uint32_t operator()(int) const { return 0u; } };
+template <int BLOCK, bool BATCH4, bool LEAN = false, int QCAP = kQCap, typename PosFn, typename IvFn, typename EntFn = ListFromGlobal>
 __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32_t col_next, int mol, int n, int nmax, int c0min,
                                                int N, int S, uint32_t* __restrict__ queue, PosFn getpos, IvFn getiv,
-                                               uint32_t (&cur)[8], double* __restrict__ mom_out = nullptr)
+                                               uint32_t (&cur)[8], double* __restrict__ mom_out = nullptr, EntFn ent = ListFromGlobal())
 {
+    constexpr bool kEnt = !std::is_same<EntFn, ListFromGlobal>::value;
+    static_assert(!kEnt || LEAN, "list entries from a functor: the lean variant only");
+    auto entry = [&](int s) -> uint32_t { if constexpr (kEnt) return ent(s); else return list_load(rs, col, s, N, S); };
     double xi, yi, zi;
     getpos(mol, xi, yi, zi);
 
@@ -87,7 +94,7 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
         uint32_t nxt[8];
         if constexpr (LEAN) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) cur[u] = list_load(rs, col, s0 + u, N, S);
+            for (int u = 0; u < 8; ++u) cur[u] = entry(s0 + u);
         } else {
             const bool last = s0 + 8 >= nmax;                 // wave-uniform
             const uint32_t pc = last ? col_next : col;        // whose chunk comes next
@@ -200,7 +207,7 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
         int seen = 0;
         for (int s = 0; s < n; ++s) {
             double v[6];
-            gather(list_load(rs, col, s, N, S), v);
+            gather(entry(s), v);
             const double dx = (v[0] + v[3]) - xi, dy = (v[1] + v[4]) - yi, dz = (v[2] + v[5]) - zi;
             if (dx * dx + dy * dy + dz * dz < kRcSq) { if (seen >= QCAP) accumulate(v); ++seen; }
         }

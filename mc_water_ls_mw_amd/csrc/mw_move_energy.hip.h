@@ -597,21 +597,47 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
 // `ptab[p]` = (a | b << 8) of the p-th pair a < b (a table in LDS: decoding p costs a dozen instructions otherwise).  The interaction
 // and slot counts are ADDED, lane by lane, to `acc` = {interactions old, slots old, interactions new, slots new}: the caller sums
 // them over the lanes once per work item instead of once per request.
-template <typename PosFn, typename IvFn, typename NnFn>
+//
+// SWEEP = true: the Monte Carlo driver's small walkers (mw_sweep.hip.h), whose cells are narrower than three list radii and whose
+// moments change under the routine's feet.  (1) A neighbour j that is in range through TWO of its images holds two contributions of
+// i -- images of i as each other's third bodies at j; one trial move in twenty of the reference's 48-molecule Ih cell, 7.7 A wide --
+// which the pair pass, meeting every pair of in-range entries anyway, finds and accounts for (see there).  A molecule that lists an
+// image of itself (a cell narrower than the list radius) is declined.  (2) No pair table (the driver's LDS is counted in bytes): pair
+// p of the triangular numbering is decoded arithmetically.  (3) No counts.
+// (4) The record of rank r keeps its molecule (ws->qown[r]) and `cnt_u` returns the number of records: the caller's
+// moments_commit() brings the moments up to date from them when the move is accepted.  (5) Look-ahead (NOTH > 0, as
+// move_energy_wave): bit o of `cmask` comes back set when the evaluation read the position of oth[o] OR the moments of a molecule
+// that lists oth[o] -- `lmask[j]` = the molecules of j's row as a bit mask (N <= 64), fetched with j's position.
+template <bool SWEEP = false, int NOTH = 0, typename PosFn, typename IvFn, typename NnFn>
 __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, NnFn nnof, const double* __restrict__ MOM,
                                                      WaveScratch* __restrict__ ws, const unsigned short* __restrict__ ptab, int i, int n_i, uint32_t e,
                                                      double xo, double yo, double zo, double xn, double yn, double zn,
-                                                     int lane, MoveRes& res, unsigned int (&acc)[4])
+                                                     int lane, MoveRes& res, unsigned int (&acc)[4], int* cnt_u = nullptr,
+                                                     const unsigned long long* __restrict__ lmask = nullptr, const int* oth = nullptr,
+                                                     unsigned* cmask = nullptr)
 {
     // ---- pass 0: as move_energy_wave -- lanes 0..31 slot l of i's row against the OLD position, lanes 32..63 against the TRIAL one
-    if (n_i > 32) return false;
+#ifdef MW_SWEEP_STAMPS
+#define MW_MOM_WHY(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sweep_stamps[44 + (k)] += 1ull; } while (0)
+#else
+#define MW_MOM_WHY(k) do { } while (0)
+#endif
+    if (n_i > 32) { MW_MOM_WHY(0); return false; }
     const int half = lane >> 5, sl = lane & 31;
     const bool has = sl < n_i;
     const int j = has ? (int)(e & kJMask) : 0, kimg = has ? (int)(e >> kJBits) : 0;
+    if (SWEEP && __ballot(has && j == i) != 0ull) { MW_MOM_WHY(1); return false; }
+    unsigned cm = 0u;
+    if constexpr (NOTH > 0) {
+#pragma unroll
+        for (int o = 0; o < NOTH; ++o) cm |= (has && j == oth[o]) ? 1u << o : 0u;
+    }
     double xj, yj, zj, jvx, jvy, jvz;
     getpos(j, xj, yj, zj);
     getiv(kimg, jvx, jvy, jvz);
-    const int nnj = has ? nnof(j) : 0;
+    [[maybe_unused]] unsigned long long lmj = 0ull;
+    if constexpr (NOTH > 0) lmj = lmask[j];
+    const int nnj = (has && !SWEEP) ? nnof(j) : 0;
     const double qx = xj + jvx, qy = yj + jvy, qz = zj + jvz;                 // molint.F90:269
     const double rix = half ? xn : xo, riy = half ? yn : yo, riz = half ? zn : zo;
     const double ax = qx - rix, ay = qy - riy, az = qz - riz;                 // :272
@@ -621,27 +647,36 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
     const unsigned int mo_ = (unsigned int)B, mn_ = (unsigned int)(B >> 32);
     const unsigned int U = mo_ | mn_;
     const int cntU = __popc(U);
-    if (cntU > kCap) return false;
+    if (cntU > kCap) { MW_MOM_WHY(2); return false; }
+    if constexpr (NOTH > 0) {          // whose moments this evaluation reads: those of the in-range j -- which hold every molecule of j's row
+#pragma unroll
+        for (int o = 0; o < NOTH; ++o) cm |= (in && oth[o] >= 0 && ((lmj >> (oth[o] & 63)) & 1ull) != 0ull) ? 1u << o : 0u;
+    }
     const bool inu = (U >> sl) & 1u;
     const int rank = half ? (int)__builtin_amdgcn_mbcnt_hi(U, 0u) : (int)__builtin_amdgcn_mbcnt_lo(U, 0u);
     // j's moments: requested NOW, by the lane that holds j and this geometry, and used after the pair terms (whose rsqrt /
     // reciprocal / exp the read hides behind)
+    // (the driver's one-move-at-a-time builds -- thousands of walkers, sixteen wavefronts per compute unit to hide a read behind, and
+    //  a budget of 128 vector registers -- ask for them AFTER the pair terms instead: twenty registers fewer held across those)
+    constexpr bool kLateMoments = SWEEP && NOTH == 0;
     double M[10];
-    {
+    auto load_moments = [&]() {
         const double2* Mj = reinterpret_cast<const double2*>(MOM + (size_t)(in ? j : i) * kMomStride);   // (a lane without an in-range j reads i's own: harmless, unused)
 #pragma unroll
         for (int c = 0; c < 5; ++c) { const double2 v = Mj[c]; M[2 * c] = v.x; M[2 * c + 1] = v.y; }
-    }
+    };
+    if constexpr (!kLateMoments) load_moments();
     double rinv = 0.0, e1 = 0.0, g = 0.0;
     if (in) pair_terms(r2, rinv, e1, g);
     const double qq = kSigSq * rinv * rinv;
     const double accp = in ? (kAeps * (kBigB * (qq * qq) - 1.0)) * e1 : 0.0;  // :294-297 (old in lanes 0..31, trial in 32..63)
-    const int flg = (int)((mo_ >> sl) & 1u) | (int)(((mn_ >> sl) & 1u) << 1);
+    const int flg = (int)((mo_ >> sl) & 1u) | (int)(((mn_ >> sl) & 1u) << 1) | (SWEEP ? j << 2 : 0);
     if (inu) {                                            // the in-range neighbours' records by rank, for the pair pass
         if (half == 0) {
             ws->q[0][rank] = qx; ws->q[1][rank] = qy; ws->q[2][rank] = qz;
             ws->rinvo[rank] = rinv; ws->go[rank] = g;
             ws->flag[rank] = flg;
+            if constexpr (SWEEP) { ws->qown[rank] = j; ws->qown[32 + rank] = -1; }
         } else {
             ws->rinvn[rank] = rinv; ws->gn[rank] = g;
         }
@@ -650,6 +685,7 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
     // ---- i--j--k: one item per in-range neighbour and geometry, in the lane that holds them ---------------------------------
     // i's own term inside j's moments belongs to the OLD position (the one the full-box pass saw): lanes of the trial geometry take
     // the old 1/r and g from the lane 32 below
+    if constexpr (kLateMoments) load_moments();
     const int lsrc = (lane & 31) << 2;
     const double g_old = __hiloint2double(__builtin_amdgcn_ds_bpermute(lsrc, __double2hiint(g)), __builtin_amdgcn_ds_bpermute(lsrc, __double2loint(g)));
     const double r_old = __hiloint2double(__builtin_amdgcn_ds_bpermute(lsrc, __double2hiint(rinv)), __builtin_amdgcn_ds_bpermute(lsrc, __double2loint(rinv)));
@@ -682,23 +718,39 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
     double t3p = 0.0;
     unsigned int ntp = 0u;
     bool hard = false;
+    [[maybe_unused]] unsigned long long anysame = 0ull;
     const int gq = lane & 1;                                  // this lane's geometry in the pair pass
     const double rqx = gq ? xn : xo, rqy = gq ? yn : yo, rqz = gq ? zn : zo;
     const double* rinvq = gq ? ws->rinvn : ws->rinvo;
     const double* gvq = gq ? ws->gn : ws->go;
     const int nitems = cntU * (cntU - 1);                     // 2 x pairs
+    // pair p = b (b - 1) / 2 + a of the triangular numbering, a < b, without a table: b from a single-precision square root (exact
+    // enough for p < 2^20; two integer corrections make it exact), a dozen instructions per pass of the wavefront
+    [[maybe_unused]] auto pair_of = [](int p, int& a_, int& b_) {
+        int bb = (int)((1.0f + __fsqrt_rn(1.0f + 8.0f * (float)p)) * 0.5f);
+        if (((bb * (bb - 1)) >> 1) > p) --bb;
+        if ((((bb + 1) * bb) >> 1) <= p) ++bb;
+        b_ = bb; a_ = p - ((bb * (bb - 1)) >> 1);
+    };
     for (int base = 0; base < nitems; base += 64) {
         const int t = base + lane;
         const bool live = t < nitems;
-        const unsigned int ab = live ? (unsigned int)ptab[t >> 1] : 0x0100u;
-        const int ia = (int)(ab & 0xffu), b = (int)(ab >> 8);
-        const bool act = live && (((ws->flag[ia] & ws->flag[b]) >> gq) & 1);
+        int ia, b;
+        if constexpr (SWEEP) {
+            pair_of(live ? t >> 1 : 0, ia, b);
+        } else {
+            const unsigned int ab = live ? (unsigned int)ptab[t >> 1] : 0x0100u;
+            ia = (int)(ab & 0xffu); b = (int)(ab >> 8);
+        }
+        const int fa = ws->flag[ia], fb = ws->flag[b];
+        const bool act = live && (((fa & fb) >> gq) & 1);
         const double pax = ws->q[0][ia], pay = ws->q[1][ia], paz = ws->q[2][ia];
         const double pbx = ws->q[0][b], pby = ws->q[1][b], pbz = ws->q[2][b];
         const double ra = rinvq[ia], rb = rinvq[b];
         const double Ax = rqx - pax, Ay = rqy - pay, Az = rqz - paz, Bx = rqx - pbx, By = rqy - pby, Bz = rqz - pbz;
         const double ct = ((Ax * Bx + Ay * By + Az * Bz) * ra) * rb;                               // :316,365
         if (act && ct < 0.99) { const double d = ct - kCos0; t3p += gvq[ia] * (gvq[b] * (d * d)); ++ntp; }   // :367-368,385-387
+        if constexpr (SWEEP) anysame |= __ballot(live && (fa >> 2) == (fb >> 2));      // two records of ONE molecule: see below
         // a and b as each other's third bodies: only when they lie within the cutoff of each other -- on ice a molecule's in-range
         // neighbours do not (first shell 2.76 A, its members 4.5 A apart, cutoff 4.31 A), so the wavefront usually skips this
         const double dx = pbx - pax, dy = pby - pay, dz = pbz - paz;          // a -> b
@@ -710,20 +762,141 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
             hard = hard || (abin && ((da > 0.0 && (da * ra) * (da * ra) >= kC2 * r2ab) || (db > 0.0 && (db * rb) * (db * rb) >= kC2 * r2ab)));
         }
     }
+    if constexpr (SWEEP) {
+        // Records a and b that are two images of ONE molecule j (a cell narrower than two cutoffs: the reference's Ih example, 7.7 A;
+        // one trial move in twenty there): j has two arms to i, and its moments hold both at their OLD ends.  For the old geometry that
+        // is what the reference's loops see (entry a meets the other arm as a third body, entry b likewise); for the trial geometry the
+        // other arm has moved too -- the sums are linear in the moments, so the pair's trial item puts that right arm by arm.  (No 0.99
+        // rule: the arms are a cell vector apart.)  A pass of its own, after the main one: its registers are not the main pass's.
+        if (anysame != 0ull) {
+            for (int base = 0; base < nitems; base += 64) {
+                const int t = base + lane;
+                const bool live = t < nitems;
+                int ia, b;
+                pair_of(live ? t >> 1 : 0, ia, b);
+                const int fa = ws->flag[ia], fb = ws->flag[b];
+                if (live && (fa >> 2) == (fb >> 2)) {
+                    if (gq == 1) {
+                        const double pax = ws->q[0][ia], pay = ws->q[1][ia], paz = ws->q[2][ia];
+                        const double pbx = ws->q[0][b], pby = ws->q[1][b], pbz = ws->q[2][b];
+                        const double ran = ws->rinvn[ia], rbn = ws->rinvn[b], gan = ws->gn[ia], gbn = ws->gn[b];
+                        const double rao = ws->rinvo[ia], rbo = ws->rinvo[b], gao = ws->go[ia], gbo = ws->go[b];
+                        const double nax = (xn - pax) * ran, nay = (yn - pay) * ran, naz = (zn - paz) * ran;                       // j -> i, trial
+                        const double nbx = (xn - pbx) * rbn, nby = (yn - pby) * rbn, nbz = (zn - pbz) * rbn;
+                        const double oax = (xo - pax) * rao, oay = (yo - pay) * rao, oaz = (zo - paz) * rao;                       // j -> i, old
+                        const double obx = (xo - pbx) * rbo, oby = (yo - pby) * rbo, obz = (zo - pbz) * rbo;
+                        const bool ao = fa & 1, an = fa & 2, bo = fb & 1, bn = fb & 2;
+                        const double dnn = (nax * nbx + nay * nby + naz * nbz) - kCos0;
+                        const double dab = (nax * obx + nay * oby + naz * obz) - kCos0, dba = (nbx * oax + nby * oay + nbz * oaz) - kCos0;
+                        double corr = 0.0;
+                        if (an && bn) corr += 2.0 * (gan * (gbn * (dnn * dnn)));
+                        if (an && bo) corr -= gan * (gbo * (dab * dab));
+                        if (bn && ao) corr -= gbn * (gao * (dba * dba));
+                        t3p += corr;
+                    } else { ws->qown[32 + ia] = b; ws->qown[32 + b] = ia; }
+                }
+            }
+        }
+    }
     const bool decline = __ballot(hard) != 0ull;
     __builtin_amdgcn_wave_barrier();                          // scratch is reused by the wave's next request
-    if (decline) return false;
+    if (decline) { MW_MOM_WHY(3); return false; }
+    if constexpr (SWEEP) *cnt_u = cntU;
 
     double eo, en;                                                                                 // :397
     dpp_wave_sum2(kLamEps * ((gq == 0 ? t3p : 0.0) + (half == 0 ? t3 : 0.0)) + (half == 0 ? accp : 0.0),
                   kLamEps * ((gq == 1 ? t3p : 0.0) + (half == 1 ? t3 : 0.0)) + (half == 1 ? accp : 0.0), eo, en);
     res.eo = eo; res.en = en;
-    // this request's interactions (in-range pairs + triplet slots that contribute) and list slots (n_i + the rows of its in-range
-    // neighbours: what prices its algorithmic bytes), left in the lanes that know them
-    const unsigned int ci = (in ? 1u : 0u) + nt, cs = (in ? (unsigned int)nnj : 0u) + (sl == 0 ? (unsigned int)n_i : 0u);
-    acc[0] += (half == 0 ? ci : 0u) + (gq == 0 ? ntp : 0u); acc[1] += half == 0 ? cs : 0u;
-    acc[2] += (half == 1 ? ci : 0u) + (gq == 1 ? ntp : 0u); acc[3] += half == 1 ? cs : 0u;
+    if constexpr (!SWEEP) {
+        // this request's interactions (in-range pairs + triplet slots that contribute) and list slots (n_i + the rows of its in-range
+        // neighbours: what prices its algorithmic bytes), left in the lanes that know them
+        const unsigned int ci = (in ? 1u : 0u) + nt, cs = (in ? (unsigned int)nnj : 0u) + (sl == 0 ? (unsigned int)n_i : 0u);
+        acc[0] += (half == 0 ? ci : 0u) + (gq == 0 ? ntp : 0u); acc[1] += half == 0 ? cs : 0u;
+        acc[2] += (half == 1 ? ci : 0u) + (gq == 1 ? ntp : 0u); acc[3] += half == 1 ? cs : 0u;
+    }
+    if constexpr (NOTH > 0) {          // OR over the lanes, on the DPP network
+        unsigned v = cm;
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);      // row_shr:4
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);      // row_shr:8
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);      // row_bcast:15 into rows 1 and 3
+        v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);      // row_bcast:31 into rows 2 and 3
+        *cmask = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+    }
     return true;
+}
+
+// An accepted move's moments (the Monte Carlo driver; the records of the evaluation that preceded it are still in `ws`): the moments
+// of every molecule that had or now has i within the cutoff lose i's old contribution and gain the new one -- lane r, the record of
+// rank r -- and i's own are the sum over its new neighbourhood.  (Szz is not stored: S0 - Sxx - Syy, mw_common.hip.h.)
+__device__ __forceinline__ void moments_commit(double* __restrict__ MOM, WaveScratch* __restrict__ ws, int i, int cntU,
+                                               double xo, double yo, double zo, double xn, double yn, double zn, int lane)
+{
+    // (two records that are images of one molecule -- qown[32 + r] = the other one -- are both applied by the lower lane)
+    const int sib = lane < cntU ? ws->qown[32 + lane] : -1;
+    if (lane < cntU && (sib < 0 || lane < sib)) {
+        const int j = ws->qown[lane];
+        double2* Mj = reinterpret_cast<double2*>(MOM + (size_t)j * kMomStride);
+        double M[10];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) { const double2 v = Mj[c]; M[2 * c] = v.x; M[2 * c + 1] = v.y; }
+        auto apply = [&](int r) {
+            const int f = ws->flag[r];
+            const double qx = ws->q[0][r], qy = ws->q[1][r], qz = ws->q[2][r];
+            if (f & 1) {
+                const double ri = ws->rinvo[r], g = ws->go[r];
+                const double ux = (xo - qx) * ri, uy = (yo - qy) * ri, uz = (zo - qz) * ri;      // unit vector j -> i (old)
+                const double hx = g * ux, hy = g * uy, hz = g * uz;
+                M[0] -= g; M[1] -= hx; M[2] -= hy; M[3] -= hz;
+                M[4] -= hx * ux; M[5] -= hy * uy; M[6] -= hx * uy; M[7] -= hx * uz; M[8] -= hy * uz; M[9] -= 1.0;
+            }
+            if (f & 2) {
+                const double ri = ws->rinvn[r], g = ws->gn[r];
+                const double ux = (xn - qx) * ri, uy = (yn - qy) * ri, uz = (zn - qz) * ri;      // unit vector j -> i (new)
+                const double hx = g * ux, hy = g * uy, hz = g * uz;
+                M[0] += g; M[1] += hx; M[2] += hy; M[3] += hz;
+                M[4] += hx * ux; M[5] += hy * uy; M[6] += hx * uy; M[7] += hx * uz; M[8] += hy * uz; M[9] += 1.0;
+            }
+        };
+        apply(lane);
+        if (sib >= 0) apply(sib);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) Mj[c] = make_double2(M[2 * c], M[2 * c + 1]);
+    }
+    // i's own: the records' contributions at the trial position, seven records at a time through 70 doubles of the scratch (ws->c,
+    // which this path does not use otherwise): lane u of a chunk writes its ten numbers, lane c < 10 then adds up component c --
+    // in rank order, so the sum does not depend on anything but the records -- and stores it
+    double* T = &ws->c[0][0];
+    double Sc = 0.0;
+    for (int r0 = 0; r0 < cntU; r0 += 7) {
+        const int r = r0 + lane;
+        if (lane < 7 && r < cntU) {
+            double v[10] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (ws->flag[r] & 2) {
+                const double ri = ws->rinvn[r], g = ws->gn[r];
+                const double ux = (ws->q[0][r] - xn) * ri, uy = (ws->q[1][r] - yn) * ri, uz = (ws->q[2][r] - zn) * ri;   // unit vector i -> j
+                const double hx = g * ux, hy = g * uy, hz = g * uz;
+                v[0] = g; v[1] = hx; v[2] = hy; v[3] = hz; v[4] = hx * ux; v[5] = hy * uy; v[6] = hx * uy; v[7] = hx * uz; v[8] = hy * uz; v[9] = 1.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 10; ++c) T[c * 7 + lane] = v[c];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 10) {
+            double t[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) t[u] = T[lane * 7 + u];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) Sc += (r0 + u < cntU) ? t[u] : 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (lane < 10) MOM[(size_t)i * kMomStride + lane] = Sc;
 }
 
 // One workgroup per work item {box, first request, last request+1}: the requests are

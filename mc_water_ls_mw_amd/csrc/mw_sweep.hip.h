@@ -162,6 +162,10 @@ struct VolCtx {
     const int* nns_g;         // row length of each column
     const int* cmax_g;        // longest row per group of 64 columns
     uint32_t* queue;          // this lane's column of an LDS queue [kSweepQCap + 1][64]
+    const unsigned short* srow;   // LDS list rows [L][N][rstride] (16-bit entries) and row lengths [L][N] of walkers entirely in LDS, else nullptr
+    const unsigned char* snn;
+    int rstride;
+    double* mom_trial;        // where a volume move leaves the moments of the trial cell, [L][N][kMomStride], or nullptr
     int N, S, ivcap, L;
 };
 
@@ -225,8 +229,9 @@ __device__ __forceinline__ void dev_rescale(const VolCtx& c, int l, const double
     }
 }
 
-// compute_model_energy of lattice l by one wavefront (value in every lane)
-__device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, int lane)
+// compute_model_energy of lattice l by one wavefront (value in every lane).  `mom_l` (walkers entirely in LDS only): every
+// molecule's moments too, [N][kMomStride] -- what the translations' moment path reads (move_energy_mom_wave)
+__device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, int lane, double* __restrict__ mom_l = nullptr)
 {
     const double* Pg = c.pos_g + (size_t)l * c.N * 3;
     const double* Ps = c.spos ? c.spos + (size_t)l * c.N * 3 : nullptr;
@@ -241,6 +246,25 @@ __device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, 
         x = p[0]; y = p[1]; z = p[2];
     };
     double esum = 0.0;
+    if (c.srow) {
+        // a walker entirely in LDS: its rows are there too (molecule-major, 16-bit entries) -- one lane per molecule, no list read
+        // from global memory (the slot-major list cost three dependent global round trips of ~1.5 us each: 9 of a volume move's 19 us)
+        uint32_t cur[8];
+        for (int base = 0; base < c.N; base += 64) {
+            const int mol = base + lane;
+            const bool act = mol < c.N;
+            const int n = act ? (int)c.snn[l * c.N + mol] : 0;
+            const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i(n));
+            const unsigned short* row = c.srow + ((size_t)l * c.N + (act ? mol : 0)) * c.rstride;
+            auto ent = [&](int s) -> uint32_t { const uint32_t e = s < n ? (uint32_t)row[s] : 0u; return (e & 63u) | ((e >> 6) << kJBits); };
+            AtomSum a = atom_energy<64, false, true, kSweepQCap>(ListRsrc(), kNoColumn, kNoColumn, act ? mol : 0, n, nmax, 0, c.N, c.S, c.queue, getpos, getiv, cur,
+                                                                 (mom_l && act) ? mom_l + (size_t)mol * kMomStride : nullptr, ent);
+            if (act) esum += a.e;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off, 64);
+        return esum;
+    }
     const ListRsrc rs = list_rsrc(Lg, c.N, c.S);
     uint32_t cur[8];
     int n_cur = 0, mol = 0;
@@ -296,7 +320,7 @@ static_assert(kSweepScratchVol == kSweepScratch, "the builds with volume moves t
 // Dynamic LDS of a walker's workgroup (byte offsets), the same arithmetic on the host (launch size) and on the device.
 // Every byte counts for the reference's own 48-molecule cells: eight walkers share a CU when a workgroup's static + dynamic
 // LDS stays within 160 KiB / 8 = 20480 B (mw_sweep_translation_launch).
-struct SweepLds { unsigned iv, pos, tab, uni, mv, scr, row, nn, total, scr_bytes; };
+struct SweepLds { unsigned iv, pos, tab, uni, mv, scr, row, nn, mom, lmask, total, scr_bytes; };
 __host__ __device__ inline SweepLds sweep_lds(int L, int nw, int ivcap, int N, int nbins, bool ldspos, bool ldslist, int rstride, bool withvol,
                                               bool samplerun, int spec = 1)
 {
@@ -313,6 +337,12 @@ __host__ __device__ inline SweepLds sweep_lds(int L, int nw, int ivcap, int N, i
     o.scr = p; p += (unsigned)nw * o.scr_bytes;
     o.row = p; p += ldslist ? (unsigned)L * N * rstride * 2u : 0u;     // list rows, 16-bit entries (j | image << 6; N <= 64)
     o.nn = p;  p += ldslist ? (unsigned)L * N : 0u;                    // row lengths, one byte each
+    p = (p + 15u) & ~15u;
+    // look-ahead builds (a handful of walkers: LDS to spare) keep the moment path's data here: every molecule's moments, current and
+    // a volume move's trial set [2][L][N][kMomStride], and every row's molecules as a bit mask [L][N]
+    const bool momlds = ldslist && spec > 1;
+    o.mom = p;   p += momlds ? 2u * L * N * (unsigned)kMomStride * 8u : 0u;
+    o.lmask = p; p += momlds ? (unsigned)L * N * 8u : 0u;
     o.total = (p + 15u) & ~15u;
     return o;
 }
@@ -384,7 +414,7 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
         wave_sync();
         [[maybe_unused]] const unsigned long long tv2 = MW_SW_NOW();
         if (niv < 0) bad = 1;
-        else new_e = dev_wave_model_energy(c, l, lane);
+        else new_e = dev_wave_model_energy(c, l, lane, c.mom_trial ? c.mom_trial + (size_t)l * c.N * kMomStride : nullptr);
         MW_SW_ACC(36, MW_SW_NOW() - tv2); MW_SW_ACC(37, tv2 - tv1);
     }
     [[maybe_unused]] const unsigned long long tv3 = MW_SW_NOW();
@@ -464,7 +494,7 @@ __device__ __forceinline__ int dev_minu_branch(const WalkerCtl& sp, int ls, doub
     if (lsn != ls) {
         const double En = lsn == 1 ? E1 : E2, Vn = lsn == 1 ? V1 : V2;
         double d;
-        if (vol_terms) d = sp.beta * En - sp.beta * Eb + sp.beta * sp.pressure * (Vn - Vb) - (double)N * log(Vn / Vb) + new_eta - old_eta;   // :1131-1133,1396-1397
+        if (vol_terms) d = sp.beta * En - sp.beta * Eb + sp.beta * sp.pressure * (Vn - Vb) - (double)N * fast_log_pos(Vn / Vb) + new_eta - old_eta;   // :1131-1133,1396-1397
         else           d = sp.beta * En - sp.beta * Eb + new_eta - old_eta;                                                                  // :1135
         if (sp.ref1 != 0.0 || sp.ref2 != 0.0)                                                                                               // leshift, :1134,1136,1398
             d = d - sp.beta * (lsn == 1 ? sp.ref1 : sp.ref2) + sp.beta * (ls == 1 ? sp.ref1 : sp.ref2);
@@ -504,8 +534,10 @@ void k_sweep(double* pos, double* hmat, double* ivect,
              int N, int S, int ivcap, int nmoves, unsigned long long seed, unsigned long long move0,
              int walker0, double* __restrict__ mvlog, int rstride,
              const double* __restrict__ wwin, double* __restrict__ wfac, double* __restrict__ wsum,
-             int* __restrict__ winflag, const double* __restrict__ wstep)
+             int* __restrict__ winflag, const double* __restrict__ wstep,
+             double* wmom)     // LDSLIST: [walker of the launch][2][L][N][kMomStride], the moment path's scratch (nullptr: the path is off)
 {
+    static_assert(!LDSLIST || LDSPOS, "rows in LDS: positions too");
     constexpr int L = NLAT, NW = NLAT * SPEC, NTHR = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double shmat[2][9], srecip[2][9], svol[2];      // the walker's cells: volume moves change them in place
@@ -537,6 +569,9 @@ void k_sweep(double* pos, double* hmat, double* ivect,
     WaveScratch* ws = reinterpret_cast<WaveScratch*>(smem_raw + lay.scr + (unsigned)wv * lay.scr_bytes);
     unsigned short* srow = reinterpret_cast<unsigned short*>(smem_raw + lay.row);
     unsigned char* snn = smem_raw + lay.nn;
+    constexpr bool MOMLDS = LDSLIST && SPEC > 1;          // (see sweep_lds)
+    double* smom = reinterpret_cast<double*>(smem_raw + lay.mom);
+    unsigned long long* slmask = reinterpret_cast<unsigned long long*>(smem_raw + lay.lmask);
     const double invPi = 1.0 / 3.141592653589793238462643383279502884197;
 
     // ---- staging: image vectors, (small systems) positions, list rows and row lengths, the walker's tables -------------
@@ -603,14 +638,23 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         // mc_cycle_num of the next move and its place inside the cycle ('dd' only: the equilibration rules, :181-210)
         C.cyc = sp.dd ? (int)(move0 / (unsigned long long)N) + 1 : 0;
         C.within = sp.dd ? (int)(move0 % (unsigned long long)N) : 0;
+        sdec[2] = sdec[3] = (LDSLIST && wmom) ? 1 : 0;                        // (moment path: lattice l's moments are to be made, see the move loop)
     }
     __syncthreads();
+    if constexpr (MOMLDS) {
+        for (int t = tid; t < L * N; t += NTHR) {
+            unsigned long long m = 0ull;
+            const int n = snn[t];
+            for (int q = 0; q < n; ++q) m |= 1ull << (srow[(size_t)t * rstride + q] & 63u);
+            slmask[t] = m;
+        }
+    }
     if (wv == 0) {
         // log(V1/V2), log(V2/V1): change with volume moves only; the minimum of the weights over the walker's window (0
         // after the first update)
         double l12 = 0.0, l21 = 0.0, cmin = 0.0;
         if (L == 2) {
-            l12 = log(svol[0] / svol[1]); l21 = log(svol[1] / svol[0]);
+            l12 = fast_log_pos(svol[0] / svol[1]); l21 = fast_log_pos(svol[1] / svol[0]);
             if (C.record && !C.samplerun) {
                 double mn = 1.7976931348623157e308;
                 for (int b = C.mg.start_bin - 1 + lane; b < C.mg.end_bin; b += 64) { const double w = sweight[b]; mn = w < mn ? w : mn; }
@@ -813,7 +857,10 @@ void k_sweep(double* pos, double* hmat, double* ivect,
     auto decide_round = [&](int ntr, int ub, const double* U0, int mvbase) {
 #pragma clang fp contract(off)
         constexpr double kHuge = 1.7976931348623157e308;                         // huge(1.0_dp)
-        unsigned accmask = 0u;
+        // (bit 31 of an evaluation's dependence word -- the moment path declined it -- ends the round BEFORE that move; the next round
+        //  finds it in slot 0 and decides nothing else)
+        unsigned accmask = 0x80000000u;
+        if constexpr (MOMLDS) { if (((scm[0] | (NLAT == 2 ? scm[1] : 0u)) >> 31) != 0u) ntr = 1; }
         int nvalid = 0;
         // the walker's state, in registers for the length of the round
         double bk0 = C.men0, bk1 = L == 2 ? C.men1 : 0.0;                         // :1013
@@ -936,7 +983,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 double w_k = 0.0, h_k = 0.0;
                 if (record) { w_k = sweight[kc - 1]; h_k = shist[kc - 1]; }
                 const double u5 = U0[8 * slot_l + 5], u6 = U0[8 * slot_l + 6];
-                const unsigned depl = (scm[slot_l * NLAT] | scm[slot_l * NLAT + 1]) & accmask;
+                const unsigned depl = slot_l == 0 ? 0u : (scm[slot_l * NLAT] | scm[slot_l * NLAT + 1]) & accmask;   // (slot 0 depends on nothing; its bit 31: see above)
                 wave_fence();
                 // the rejections before this candidate, in the chain's order: `e` those before its eta_weight is looked up (for a
                 // "rejected" lane that includes its own move's: it is the NEXT move's current value), `o` those before its own visit
@@ -1245,9 +1292,38 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         wave_fence();
     };
 
+    // THE MOMENT PATH of a translation (walkers entirely in LDS; move_energy_mom_wave): the i--j--k sums come from every molecule's
+    // moments, kept in `wmom` (global memory, L2-resident: the walker's LDS is counted in bytes) -- made by the lattice's first
+    // wavefront when sdec[2 + lattice] says so (the launch's start; an accepted move whose evaluation took another routine),
+    // brought up to date by every accepted move (moments_commit), and for a volume move written for the TRIAL cell into the
+    // other half of the buffer, which an accepted move makes the current one (msel, the same in every wavefront).
+    const bool usemom = LDSLIST && wmom != nullptr;
+    int msel = 0;
+    auto mom_of = [&](int sel, int l) -> double* {
+        if constexpr (MOMLDS) return smom + (size_t)((sel * L + l) * N) * kMomStride;
+        else return wmom + ((((size_t)blockIdx.x * 2 + sel) * L + l) * N) * kMomStride;
+    };
+
     constexpr int kUB = sweep_batch(WITHVOL, SPEC);
     int mv = 0, ubase = -kUB;                    // next move of the chain (counted within the launch); first move of the uniforms' window
     while (mv < nmoves) {
+        if constexpr (LDSLIST) {
+            if (usemom && (SPEC > 1 ? (sdec[2] | (L == 2 ? sdec[3] : 0)) : sdec[2 + lat]) != 0) {       // (the same in every wavefront that waits below)
+                if (slot == 0 && sdec[2 + lat] != 0) {
+                    int lv = lane, bv = box0;
+                    asm volatile("" : "+v"(lv), "+s"(bv));
+                    VolCtx vm;
+                    vm.pos_g = pos + (size_t)bv * N * 3; vm.spos = spos; vm.siv = siv; vm.sniv = sniv;
+                    vm.queue = reinterpret_cast<uint32_t*>(ws) + lv; vm.N = N; vm.S = S; vm.ivcap = ivcap; vm.L = L;
+                    vm.srow = srow; vm.snn = snn; vm.rstride = rstride; vm.mom_trial = nullptr;
+                    (void)dev_wave_model_energy(vm, lat, lv, mom_of(msel, lat));
+                }
+                if (SPEC > 1) wg_sync<NW>(); else wave_sync();
+                if (SPEC > 1) { if (tid == 0) { sdec[2] = 0; sdec[3] = 0; } }
+                else if (lane == 0) sdec[2 + lat] = 0;
+                if (SPEC > 1) wg_sync<NW>(); else wave_sync();
+            }
+        }
         [[maybe_unused]] const unsigned long long sw_u0 = MW_SW_NOW();
         if (mv + SPEC > ubase + kUB) {
             // the next kUB moves' random numbers: Philox call c of move m is thread 4 m + c (the same stream as the
@@ -1302,6 +1378,8 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 vc.nivect_g = nivect + bv; vc.list_g = list + (size_t)bv * S * N;
                 vc.order_g = order + (size_t)bv * N; vc.nns_g = nns + (size_t)bv * N; vc.cmax_g = cmax + (size_t)bv * ((N + 63) >> 6);
                 vc.queue = reinterpret_cast<uint32_t*>(ws) + lv; vc.N = N; vc.S = S; vc.ivcap = ivcap; vc.L = L;
+                vc.srow = LDSLIST ? srow : nullptr; vc.snn = LDSLIST ? snn : nullptr; vc.rstride = rstride;
+                vc.mom_trial = usemom ? mom_of(msel ^ 1, 0) : nullptr;
                 const double* U = U0;
                 double diffkT = 0.0;
                 bool do_switch = false;
@@ -1333,14 +1411,14 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                         if (L == 2) {                                                                        // :1363-1371
                             double mu = (e0n + C.pressure * Vn0) - (e1n + C.pressure * Vn1);
                             mu = mu - C.dref;                                                                // :1371 (leshift)
-                            mu = mu * C.beta - (double)N * log(Vn0 / Vn1);
+                            mu = mu * C.beta - (double)N * fast_log_pos(Vn0 / Vn1);
                             const double mul = lane == 0 ? ls_mu : mu;
                             const double el = lane_eta(C.mg, sweight, smub, sbw, mul, lane_mu_to_bin(C.mg, mul));
                             old_eta = readlane_f64(el, 0); new_eta = readlane_f64(el, 1);
                             ls_mu = mu;
                         }
                         diffkT = C.beta * dE + new_eta - old_eta + C.beta * C.pressure * (Vls - Vold)
-                                 - (double)N * log(Vls / Vold);                                              // :1381-1382
+                                 - (double)N * fast_log_pos(Vls / Vold);                                     // :1381-1382
                         int minu_ls = ls0;
                         if (C.minu && L == 2)                                                                // :1385-1401
                             minu_ls = dev_minu_branch(C, ls0, e0n, e1n, Vn0, Vn1, ls0 == 1 ? bk0 : bk1, Vold, true, N,
@@ -1356,7 +1434,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                         if (L == 2) {                                                                        // :1516-1520 (the OLD cells)
                             double mu = (m0 + C.pressure * Vo0) - (m1 + C.pressure * Vo1);
                             mu = mu - C.dref;                                                                // :1526 (leshift)
-                            mu = mu * C.beta - (double)N * log(Vo0 / Vo1);
+                            mu = mu * C.beta - (double)N * fast_log_pos(Vo0 / Vo1);
                             ls_mu = mu;
                         }
                     }
@@ -1365,10 +1443,11 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                     return okv;
                 };
                 const int rv = volume_move_wg<NLAT, NW>(vc, U, C.dv_max, wv, lv, sx, sdec, decide);
+                if (usemom && rv == 1) msel ^= 1;                  // (the trial cell's moments are the walker's now)
                 if (wv == 0) {
                     int sw = 0;
                     double l12 = 0.0, l21 = 0.0;
-                    if (L == 2) { l12 = log(svol[0] / svol[1]); l21 = log(svol[1] / svol[0]); }
+                    if (L == 2) { l12 = fast_log_pos(svol[0] / svol[1]); l21 = fast_log_pos(svol[1] / svol[0]); }
                     if (lane == 0) {
                         C.nvol_try = C.nvol_try + 1;
                         if (rv == 1) C.nvol_acc = C.nvol_acc + 1;
@@ -1413,6 +1492,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         const int i = imol - 1;
         double* P = pos + (size_t)(box0 + l) * N * 3;                                 // :1007-1018, 1076-1092
         double pnx = 0.0, pny = 0.0, pnz = 0.0;
+        int ekind = 1, ecnt = 0;                       // the routine that evaluated this move (0: the moment path) and its in-range records
         if (mine) {
             double tx = x, ty = y, tz = z;                                            // the move in the active lattice
             if (L == 2 && l != ls - 1) {                                              // mapped into the partner lattice, :1042-1067
@@ -1459,8 +1539,18 @@ void k_sweep(double* pos, double* hmat, double* ivect,
 #ifdef MW_ABL_NOEVAL         // diagnostic build: no evaluation (energies 0) -- the decisions' share of a round
             const bool fast = true; res.eo = 0.0; res.en = 1e-3 * (double)(i & 7); res.io = res.in_ = res.so = res.sn = 0u;
 #else
-            const bool fast = move_energy_wave<true, SPEC - 1, false>(getpos, getiv, row, nnof, ws, sniv[l], i, nnof(i), row(i, lane & 31), xo, yo, zo,
-                                                               pnx, pny, pnz, lane, res, oth, &cme);
+            bool fast = false;
+            if constexpr (LDSLIST) {
+                if (usemom) {
+                    unsigned int nocounts[4];
+                    fast = move_energy_mom_wave<true, SPEC - 1>(getpos, getiv, nnof, mom_of(msel, l), ws, nullptr, i, nnof(i), row(i, lane & 31), xo, yo, zo,
+                                                                 pnx, pny, pnz, lane, res, nocounts, &ecnt, slmask + l * N, oth, &cme);
+                    if (fast) ekind = 0;
+                }
+            }
+            if (usemom && !fast) MW_SW_ACC(43, 1ull);                   // (stamps build: evaluations the moment path declined)
+            if (!fast) fast = move_energy_wave<true, SPEC - 1, false>(getpos, getiv, row, nnof, ws, sniv[l], i, nnof(i), row(i, lane & 31), xo, yo, zo,
+                                                                     pnx, pny, pnz, lane, res, oth, &cme);
 #endif
             cm |= cme;
             if (!fast) {
@@ -1470,7 +1560,9 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 res.en = local_energy_wave(P, ivect + (size_t)(box0 + l) * ivcap * 3, LM, NN, i, tr, none, lane, res.in_, res.sn);
                 cm = (1u << slot) - 1u;                            // (the plain routine keeps no account of what it read)
             }
-            if (lane == 0) { sx[2 * wv] = res.eo; sx[2 * wv + 1] = res.en; scm[wv] = cm; }
+            // (bit 31: not the moment path's evaluation -- if accepted, the lattice's moments are made afresh, so the move has to be
+            //  the last of its round for the chain to be the sequential one bit for bit: decide_round)
+            if (lane == 0) { sx[2 * wv] = res.eo; sx[2 * wv + 1] = res.en; scm[wv] = cm | ((usemom && ekind != 0) ? 0x80000000u : 0u); }
         }
         [[maybe_unused]] const unsigned long long sw_e = MW_SW_NOW();
         wg_sync<NW>();                                 // every evaluation of the round is in (one wavefront: nothing of the walker's state is read ahead of it)
@@ -1487,9 +1579,19 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         const int nvalid = sdec[0];
         ls = sdec[1];
         const bool okm = mine && slot < nvalid && sdec[4 + slot] != 0;
+        double cxo = 0.0, cyo = 0.0, czo = 0.0;                                        // (the old position, read back rather than held through the decisions)
+        if constexpr (LDSLIST) {
+            if (usemom && okm && ekind == 0) { const double* Sp = spos + ((size_t)l * N + i) * 3; cxo = Sp[0]; cyo = Sp[1]; czo = Sp[2]; }
+        }
         if (okm && lane == 0) {                                                       // :1150-1170: this wavefront's lattice
             P[3 * i] = pnx; P[3 * i + 1] = pny; P[3 * i + 2] = pnz;
             if (LDSPOS) { double* Sp = spos + ((size_t)l * N + i) * 3; Sp[0] = pnx; Sp[1] = pny; Sp[2] = pnz; }
+        }
+        if constexpr (LDSLIST) {
+            if (usemom && okm) {
+                if (ekind == 0) moments_commit(mom_of(msel, l), ws, i, ecnt, cxo, cyo, czo, pnx, pny, pnz, lane);
+                else if (lane == 0) sdec[2 + l] = 1;               // (made afresh from the committed positions at the top of the next round)
+            }
         }
         mv += nvalid;
         // the next round must see the committed positions: with look-ahead, the other slots' of the same lattice too

@@ -51,7 +51,10 @@ def test_sweep_kernels_keep_their_register_budget(tmp_path):
         seen += 1
         get = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1))     # noqa: E731
         three = m.group(1) == "2" and m.group(2) != "1"                           # two lattices + look-ahead
-        assert get("vgpr_spill_count") <= 8, (name, get("vgpr_spill_count"))
+        # (the builds that also carry mc_volume AND the moment path of the walkers in LDS -- scalar registers run out first there and
+        #  take vector lanes with them -- are allowed twice the handful: measured with 13 spilled, the NPT farm gained 17 % from the path)
+        withvol_lds = m.group(5) == "1" and m.group(4) == "1"
+        assert get("vgpr_spill_count") <= (16 if withvol_lds else 8), (name, get("vgpr_spill_count"))
         assert get("vgpr_count") <= (168 if three else 128), (name, get("vgpr_count"))
     assert seen == 40          # lattices x residency x with / without volume moves, + look-ahead 2 / 4 for walkers in global memory
                                # and for walkers entirely or partly in LDS, + 8 for one-lattice walkers in global memory

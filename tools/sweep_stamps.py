@@ -38,7 +38,7 @@ def stamps(reset=True):
 
 def case(name, cells, nlat, walkers, nmoves, wl=False, npt=False, sigma=0.05, mu_range=400.0):
     out = {}
-    for ahead in ("1", "2", "4"):
+    for ahead in ("1", "2", "4", "6"):
         os.environ["MW_SWEEP_AHEAD"] = ahead
         n = len(cells[0][1])
         em = EnergyModule(n, walkers * nlat)
@@ -71,6 +71,7 @@ def case(name, cells, nlat, walkers, nmoves, wl=False, npt=False, sigma=0.05, mu
         for k, label in PHASES.items():
             rec[label + " [us/move]"] = st[k] / cyc_per_us / max(moves, 1.0)
         rec["bulk: calls, moves committed, slots predicted, stop bits"] = [st[16], st[9], st[32], st[33]]
+        rec["evaluations of wavefront 0 the moment path declined: all, row > 32, own image listed, > 11 in range, a triplet of the 0.99 rule"] = [st[43], st[44], st[45], st[46], st[47]]
         nv = max(st[40], 1.0)
         rec["volume move [us per volume move]: count, set-up, rescale, ivects+recip, full-box energy, decide, restore+mirror, total in routine, total in branch"] = \
             [st[40]] + [st[k] / cyc_per_us / nv for k in (34, 35, 37, 36, 38, 39, 41, 42)]
