@@ -676,7 +676,7 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
             ws->q[0][rank] = qx; ws->q[1][rank] = qy; ws->q[2][rank] = qz;
             ws->rinvo[rank] = rinv; ws->go[rank] = g;
             ws->flag[rank] = flg;
-            if constexpr (SWEEP) { ws->qown[rank] = j; ws->qown[32 + rank] = -1; }
+            if constexpr (SWEEP) ws->qown[rank] = j;
         } else {
             ws->rinvn[rank] = rinv; ws->gn[rank] = g;
         }
@@ -793,7 +793,7 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
                         if (an && bo) corr -= gan * (gbo * (dab * dab));
                         if (bn && ao) corr -= gbn * (gao * (dba * dba));
                         t3p += corr;
-                    } else { ws->qown[32 + ia] = b; ws->qown[32 + b] = ia; }
+                    }
                 }
             }
         }
@@ -801,7 +801,7 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
     const bool decline = __ballot(hard) != 0ull;
     __builtin_amdgcn_wave_barrier();                          // scratch is reused by the wave's next request
     if (decline) { MW_MOM_WHY(3); return false; }
-    if constexpr (SWEEP) *cnt_u = cntU;
+    if constexpr (SWEEP) *cnt_u = anysame != 0ull ? -cntU : cntU;      // (negative: some molecule holds more than one record -- moments_commit)
 
     double eo, en;                                                                                 // :397
     dpp_wave_sum2(kLamEps * ((gq == 0 ? t3p : 0.0) + (half == 0 ? t3 : 0.0)) + (half == 0 ? accp : 0.0),
@@ -833,9 +833,12 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
 __device__ __forceinline__ void moments_commit(double* __restrict__ MOM, WaveScratch* __restrict__ ws, int i, int cntU,
                                                double xo, double yo, double zo, double xn, double yn, double zn, int lane)
 {
-    // (two records that are images of one molecule -- qown[32 + r] = the other one -- are both applied by the lower lane)
-    const int sib = lane < cntU ? ws->qown[32 + lane] : -1;
-    if (lane < cntU && (sib < 0 || lane < sib)) {
+    // Lane r applies record r to its molecule's moments.  When a molecule holds several records (cnt_u < 0: a cell so narrow that
+    // two -- or, narrow in two directions, up to four -- images of it are in range), the lane of its FIRST record applies them all,
+    // in rank order, and the others none: one read-modify-write per molecule.
+    const bool multi = cntU < 0;
+    cntU = multi ? -cntU : cntU;
+    if (lane < cntU) {
         const int j = ws->qown[lane];
         double2* Mj = reinterpret_cast<double2*>(MOM + (size_t)j * kMomStride);
         double M[10];
@@ -859,10 +862,20 @@ __device__ __forceinline__ void moments_commit(double* __restrict__ MOM, WaveScr
                 M[4] += hx * ux; M[5] += hy * uy; M[6] += hx * uy; M[7] += hx * uz; M[8] += hy * uz; M[9] += 1.0;
             }
         };
-        apply(lane);
-        if (sib >= 0) apply(sib);
+        bool first = true;
+        if (!multi) apply(lane);
+        else {
+            for (int r = 0; r < cntU; ++r) {
+                if (ws->qown[r] == j) {
+                    if (r < lane) first = false;
+                    if (first) apply(r);
+                }
+            }
+        }
+        if (first) {
 #pragma unroll
-        for (int c = 0; c < 5; ++c) Mj[c] = make_double2(M[2 * c], M[2 * c + 1]);
+            for (int c = 0; c < 5; ++c) Mj[c] = make_double2(M[2 * c], M[2 * c + 1]);
+        }
     }
     // i's own: the records' contributions at the trial position, seven records at a time through 70 doubles of the scratch (ws->c,
     // which this path does not use otherwise): lane u of a chunk writes its ten numbers, lane c < 10 then adds up component c --

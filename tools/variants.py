@@ -3,6 +3,7 @@
 
     python tools/variants.py stamps     # -DMW_SWEEP_STAMPS: cycle stamps inside k_sweep (tools/sweep_stamps.py)
     python tools/variants.py spill      # -DMW_SWEEP_WAVES_CAP=5: every k_sweep build capped at 96 vector registers, i.e. SPILLING
+    python tools/variants.py nodecide noeval dnobin ...   # several known variants at once (tools/sweep_ablate.sh)
     python tools/variants.py <name> -DFOO=1 ...   # any other set of flags
 """
 import os
@@ -13,7 +14,12 @@ sys.path.insert(0, ROOT)
 from mc_water_ls_mw_amd import build as mwbuild  # noqa: E402
 
 KNOWN = {"stamps": ["-DMW_SWEEP_STAMPS"], "spill": ["-DMW_SWEEP_WAVES_CAP=5"],
-         "nodecide": ["-DMW_ABL_NODECIDE"], "noeval": ["-DMW_ABL_NOEVAL"]}
+         "nodecide": ["-DMW_ABL_NODECIDE"], "noeval": ["-DMW_ABL_NOEVAL"],
+         # parts of a decision taken out (the numbers are then wrong: shares of the time only)
+         "dnobin": ["-DMW_ABL_D_NOBIN"], "dnoswexp": ["-DMW_ABL_D_NOSWEXP"], "dnoexp": ["-DMW_ABL_D_NOEXP"], "dnowl": ["-DMW_ABL_D_NOWL"],
+         "dnosw": ["-DMW_ABL_D_NOSW"],
+         "dnoall": ["-DMW_ABL_D_NOBIN", "-DMW_ABL_D_NOSWEXP", "-DMW_ABL_D_NOEXP", "-DMW_ABL_D_NOWL", "-DMW_ABL_D_NOSW"],
+         "frame": ["-DMW_ABL_NODECIDE", "-DMW_ABL_NOEVAL"]}
 
 
 def path(name):
@@ -29,6 +35,7 @@ def build(name, flags=None, force=False, save_temps=False):
 
 
 if __name__ == "__main__":
-    name = sys.argv[1]
+    names = [a for a in sys.argv[1:] if not a.startswith("-")]
     extra = [a for a in sys.argv[2:] if a.startswith("-") and a not in ("--force", "--save-temps")]
-    print(build(name, extra or None, force="--force" in sys.argv, save_temps="--save-temps" in sys.argv))
+    for name in names:        # (several known names at once; extra flags go with a single name)
+        print(build(name, (extra or None) if len(names) == 1 else None, force="--force" in sys.argv, save_temps="--save-temps" in sys.argv))
