@@ -636,6 +636,62 @@ def test_random_single_box_walkers_follow_the_oracle(seed, so):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["pair48_wl", "pair48_npt", "thin24", "ih64_npt"])
+@pytest.mark.parametrize("ahead", [1, 4])
+def test_moment_path_of_the_driver_is_the_row_scan(case, ahead, monkeypatch):
+    """Walkers entirely in LDS take the i--j--k sums of a translation from per-molecule moments (move_energy_mom_wave,
+    moments_commit; MW_SWEEP_MOMENTS=0: the row scan of molint.F90:320-389 as written).  Same chain: every move's molecule and
+    accept / reject / switch flags identical, its four local energies to 1e-10 relative, final positions to 1e-10 bohr -- on the
+    reference's Ic / Ih pair (the 7.7 A Ih cell puts a neighbour in range through two images one trial move in twenty), with
+    volume moves (the trial cell's moments), and on a cell 6 A wide in two directions (up to four images of a neighbour in range)."""
+    from mc_water_ls_mw_amd import lattice as lat
+    from mc_water_ls_mw_amd.sweep import MuGrid
+
+    def run(moments):
+        monkeypatch.setenv("MW_SWEEP_MOMENTS", moments)
+        monkeypatch.setenv("MW_SWEEP_AHEAD", str(ahead))
+        nlat = 2 if case.startswith("pair48") else 1
+        if nlat == 2:
+            z1, z2 = load_golden("ic48"), load_golden("ih48")
+            boxes = []
+            for w in range(3):
+                boxes += [(z1["h"], lat.thermalise(z1["xyz"], 0.05, 40 + w)), (z2["h"], lat.thermalise(z2["xyz"], 0.05, 60 + w))]
+            em, farm = _farm(boxes, 2, 200.0, 1.1, grid=MuGrid(101, -400.0, 400.0), weight=np.zeros(101))
+            farm.options(record=True, samplerun=False, always_switch=True, npt=case.endswith("_npt"), wl_factor=0.05)
+        else:
+            if case == "thin24":
+                h, x0 = lat.replicate(*lat.ice_ic_cell(2.63), (1, 3, 1))          # 6.07 x 18.2 x 6.07 A, 24 molecules
+            else:
+                h, x0 = lat.ice_box("ih", (2, 2, 2), 0.0)
+            boxes = [(h, lat.thermalise(x0, 0.1, 300 + w)) for w in range(3)]
+            em, farm = _farm(boxes, 1, 230.0, 1.1)
+        try:
+            if case.endswith("_npt"):
+                if nlat == 1:
+                    ct = __import__("ctypes")
+                    em._chk(em.L.mw_sweep_options(0, 1, 0, 1, ct.c_double(1.0), ct.c_double(0.0), ct.c_double(0.0), ct.c_double(1.0 / 2.90363081e8)))
+                farm.moves(trans_prob=0.5, vol_prob=0.05, dv_max_ang=0.3)
+            nw = len(boxes) // nlat
+            for w in range(1, nw + 1):
+                farm.set_state(w, 1, farm.initial_mu(w) if nlat == 2 else 0.0)
+            log = farm.sweep(600, seed=47, move0=2, log=True)
+            last = em.sweep_last_launch() if hasattr(em, "sweep_last_launch") else None
+            return log, [farm.positions(b) for b in range(1, len(boxes) + 1)], [farm.state(w) for w in range(1, nw + 1)], last
+        finally:
+            em.energy_deinit()
+
+    got, ref = run("1"), run("0")
+    assert 30 < (ref[0][0][:, 1].astype(int) & 1).sum() < 570                    # moves are accepted and rejected
+    for w in range(len(ref[0])):
+        assert np.array_equal(got[0][w][:, :2], ref[0][w][:, :2])                # molecule; accepted + 2 switched (+ 4 volume move)
+        for c in (2, 3, 4, 5):
+            assert np.all(np.abs(got[0][w][:, c] - ref[0][w][:, c]) <= RTOL * np.abs(ref[0][w][:, c]) + 1e-14), (w, c)
+        assert got[2][w]["accepted"] == ref[2][w]["accepted"] and got[2][w]["ls"] == ref[2][w]["ls"]
+    for a, b in zip(got[1], ref[1]):
+        assert np.abs(a - b).max() < 1e-10
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["ih1000", "pair1536_wl", "ih1000_npt", "ih64", "ih64_npt", "ih288", "ih288_npt"])
 def test_lookahead_is_the_sequential_chain(case, monkeypatch):
     """Look-ahead (several moves of a walker evaluated at once, decided in order; mw_sweep.hip.h) changes nothing: the move
