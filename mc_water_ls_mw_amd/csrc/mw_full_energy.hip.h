@@ -190,7 +190,7 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
         Sxy = __builtin_fma(hx, dy, Sxy); Sxz = __builtin_fma(hx, dz, Sxz); Syz = __builtin_fma(hy, dz, Syz);
     };
     const int nq = cnt < QCAP ? cnt : QCAP;
-    if constexpr (LEAN) {
+    if constexpr (LEAN && !BATCH4) {
         for (int q = 0; q < nq; ++q) { double v[6]; gather(queue[q * BLOCK], v); accumulate(v); }
     } else if (nq > 0) {
         double va[6], vb[6];

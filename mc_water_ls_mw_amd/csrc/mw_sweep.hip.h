@@ -207,13 +207,16 @@ __device__ __forceinline__ double dev_det3(const double* m)                     
 }
 
 // ljr += (H_new * (recip . ljr / 2 pi) - ljr), lanes over molecules (mc_moves.F90:1288-1316)
+// (LDSPOS at compile time: a pointer chosen at run time between LDS and global memory makes every access through it a FLAT one --
+//  the full-box energy's position gathers, hundreds per volume move, among them)
+template <bool LDSPOS>
 __device__ __forceinline__ void dev_rescale(const VolCtx& c, int l, const double* recip, const double* hnew, int lane)
 {
     const double invPi = 1.0 / 3.141592653589793238462643383279502884197;
     double* Pg = c.pos_g + (size_t)l * c.N * 3;
-    double* Ps = c.spos ? c.spos + (size_t)l * c.N * 3 : nullptr;
+    double* Ps = c.spos + (size_t)l * c.N * 3;
     for (int i = lane; i < c.N; i += 64) {
-        const double* p = Ps ? Ps + 3 * i : Pg + 3 * i;
+        const double* p = LDSPOS ? Ps + 3 * i : Pg + 3 * i;
         const double o0 = p[0], o1 = p[1], o2 = p[2];
         double s0 = MW_HM(recip,1,1) * o0 + MW_HM(recip,2,1) * o1 + MW_HM(recip,3,1) * o2;
         double s1 = MW_HM(recip,1,2) * o0 + MW_HM(recip,2,2) * o1 + MW_HM(recip,3,2) * o2;
@@ -225,16 +228,18 @@ __device__ __forceinline__ void dev_rescale(const VolCtx& c, int l, const double
         t0 = t0 - o0; t1 = t1 - o1; t2 = t2 - o2;
         const double n0 = o0 + t0, n1 = o1 + t1, n2 = o2 + t2;
         Pg[3 * i] = n0; Pg[3 * i + 1] = n1; Pg[3 * i + 2] = n2;
-        if (Ps) { Ps[3 * i] = n0; Ps[3 * i + 1] = n1; Ps[3 * i + 2] = n2; }
+        if constexpr (LDSPOS) { Ps[3 * i] = n0; Ps[3 * i + 1] = n1; Ps[3 * i + 2] = n2; }
     }
 }
 
 // compute_model_energy of lattice l by one wavefront (value in every lane).  `mom_l` (walkers entirely in LDS only): every
 // molecule's moments too, [N][kMomStride] -- what the translations' moment path reads (move_energy_mom_wave)
+// (BATCH4: the distance tests' gathers four at a time -- for the look-ahead builds, which have the registers)
+template <bool LDSPOS, bool BATCH4 = false>
 __device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, int lane, double* __restrict__ mom_l = nullptr)
 {
     const double* Pg = c.pos_g + (size_t)l * c.N * 3;
-    const double* Ps = c.spos ? c.spos + (size_t)l * c.N * 3 : nullptr;
+    const double* Ps = c.spos + (size_t)l * c.N * 3;
     const double* IVl = c.siv + (size_t)l * c.ivcap * 3;
     const uint32_t* Lg = c.list_g + (size_t)l * c.S * c.N;
     const int* ORD = c.order_g + (size_t)l * c.N;
@@ -242,7 +247,7 @@ __device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, 
     const int* CM = c.cmax_g + (size_t)l * ((c.N + 63) >> 6);
     auto getiv = [&](int k, double& x, double& y, double& z) { x = IVl[3 * k]; y = IVl[3 * k + 1]; z = IVl[3 * k + 2]; };
     auto getpos = [&](int j, double& x, double& y, double& z) {
-        const double* p = Ps ? Ps + 3 * (size_t)j : Pg + 3 * (size_t)j;
+        const double* p = LDSPOS ? Ps + 3 * (size_t)j : Pg + 3 * (size_t)j;
         x = p[0]; y = p[1]; z = p[2];
     };
     double esum = 0.0;
@@ -257,7 +262,7 @@ __device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, 
             const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i(n));
             const unsigned short* row = c.srow + ((size_t)l * c.N + (act ? mol : 0)) * c.rstride;
             auto ent = [&](int s) -> uint32_t { const uint32_t e = s < n ? (uint32_t)row[s] : 0u; return (e & 63u) | ((e >> 6) << kJBits); };
-            AtomSum a = atom_energy<64, false, true, kSweepQCap>(ListRsrc(), kNoColumn, kNoColumn, act ? mol : 0, n, nmax, 0, c.N, c.S, c.queue, getpos, getiv, cur,
+            AtomSum a = atom_energy<64, BATCH4, true, kSweepQCap>(ListRsrc(), kNoColumn, kNoColumn, act ? mol : 0, n, nmax, 0, c.N, c.S, c.queue, getpos, getiv, cur,
                                                                  (mom_l && act) ? mom_l + (size_t)mol * kMomStride : nullptr, ent);
             if (act) esum += a.e;
         }
@@ -356,7 +361,7 @@ __host__ __device__ inline SweepLds sweep_lds(int L, int nw, int ivcap, int N, i
 // Returns (every wavefront): 1 accepted, 0 rejected, -1 rejected because a cell needed more image vectors than ivcap.
 // With look-ahead (NW > NLAT wavefronts) the wavefronts beyond the first NLAT have no lattice of their own here: they keep
 // the workgroup's barriers company.
-template <int NLAT, int NW, typename DecideFn>
+template <int NLAT, int NW, bool LDSPOS, typename DecideFn>
 __device__ __forceinline__
 int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max, int wv, int lane,
                    double* __restrict__ sx, int* __restrict__ sdec, DecideFn decide)
@@ -397,7 +402,7 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
     [[maybe_unused]] const unsigned long long tv1 = MW_SW_NOW();
     MW_SW_ACC(34, tv1 - tv0);
     if (active && !bad0) {
-        dev_rescale(c, l, bk_r, c.shmat + 9 * l, lane);
+        dev_rescale<LDSPOS>(c, l, bk_r, c.shmat + 9 * l, lane);
         rescaled = true;
         wave_sync();
         MW_SW_ACC(35, MW_SW_NOW() - tv1);
@@ -414,7 +419,7 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
         wave_sync();
         [[maybe_unused]] const unsigned long long tv2 = MW_SW_NOW();
         if (niv < 0) bad = 1;
-        else new_e = dev_wave_model_energy(c, l, lane, c.mom_trial ? c.mom_trial + (size_t)l * c.N * kMomStride : nullptr);
+        else new_e = dev_wave_model_energy<LDSPOS, (NW > NLAT)>(c, l, lane, c.mom_trial ? c.mom_trial + (size_t)l * c.N * kMomStride : nullptr);
         MW_SW_ACC(36, MW_SW_NOW() - tv2); MW_SW_ACC(37, tv2 - tv1);
     }
     [[maybe_unused]] const unsigned long long tv3 = MW_SW_NOW();
@@ -437,7 +442,7 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
         if (lane == 0) c.svol[l] = old_vol_l;
         wave_sync();
         if (rescaled) {
-            dev_rescale(c, l, bk_n, c.shmat + 9 * l, lane);                                      // back through the NEW recip
+            dev_rescale<LDSPOS>(c, l, bk_n, c.shmat + 9 * l, lane);                                      // back through the NEW recip
             const int niv = dev_compute_ivects(c.shmat + 9 * l, c.siv + (size_t)l * c.ivcap * 3,
                                                c.ivect_g + (size_t)l * c.ivcap * 3, c.ivcap, lane);   // :1510-1512
             if (lane == 0 && niv > 0) { c.sniv[l] = niv; c.nivect_g[l] = niv; }
@@ -1316,7 +1321,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                     vm.pos_g = pos + (size_t)bv * N * 3; vm.spos = spos; vm.siv = siv; vm.sniv = sniv;
                     vm.queue = reinterpret_cast<uint32_t*>(ws) + lv; vm.N = N; vm.S = S; vm.ivcap = ivcap; vm.L = L;
                     vm.srow = srow; vm.snn = snn; vm.rstride = rstride; vm.mom_trial = nullptr;
-                    (void)dev_wave_model_energy(vm, lat, lv, mom_of(msel, lat));
+                    (void)dev_wave_model_energy<true>(vm, lat, lv, mom_of(msel, lat));
                 }
                 if (SPEC > 1) wg_sync<NW>(); else wave_sync();
                 if (SPEC > 1) { if (tid == 0) { sdec[2] = 0; sdec[3] = 0; } }
@@ -1372,7 +1377,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 int lv = lane, bv = box0;
                 asm volatile("" : "+v"(lv), "+s"(bv));
                 VolCtx vc;
-                vc.pos_g = pos + (size_t)bv * N * 3; vc.spos = LDSPOS ? spos : nullptr;
+                vc.pos_g = pos + (size_t)bv * N * 3; vc.spos = spos;
                 vc.shmat = &shmat[0][0]; vc.srecip = &srecip[0][0]; vc.svol = svol; vc.sbk = &sbk[0][0]; vc.siv = siv; vc.sniv = sniv;
                 vc.hmat_g = hmat + (size_t)bv * 9; vc.vol_g = volume + bv; vc.ivect_g = ivect + (size_t)bv * ivcap * 3;
                 vc.nivect_g = nivect + bv; vc.list_g = list + (size_t)bv * S * N;
@@ -1442,7 +1447,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                     wave_sync();
                     return okv;
                 };
-                const int rv = volume_move_wg<NLAT, NW>(vc, U, C.dv_max, wv, lv, sx, sdec, decide);
+                const int rv = volume_move_wg<NLAT, NW, LDSPOS>(vc, U, C.dv_max, wv, lv, sx, sdec, decide);
                 if (usemom && rv == 1) msel ^= 1;                  // (the trial cell's moments are the walker's now)
                 if (wv == 0) {
                     int sw = 0;
