@@ -48,6 +48,52 @@ constexpr int kQCap = 12;   // in-range entries per molecule parked in LDS betwe
 
 constexpr double kAepsBSig4 = kAeps * kBigB * kSigSq * kSigSq;   // A eps B sigma^4 (molint.F90:460)
 
+// A molecule's running sums over its in-range neighbours and what becomes of them: ONE piece of arithmetic for every routine that
+// adds a neighbour (atom_energy below; the Monte Carlo driver's volume moves spread over several wavefronts, mw_sweep.hip.h, whose
+// sum must be atom_energy's bit for bit).  add(): neighbour at d = r_j + ivect - r_i with 1/r, e1, g of pair_terms (:456-462).
+// |d|^2 with the multiply-adds spelled out: wherever a routine squares a separation that another routine squares too (the two must
+// agree to the bit -- see MomentSums), the fusion is not left to the compiler's contraction, which decides per inlined copy.
+__device__ __forceinline__ double dist2(double dx, double dy, double dz) { return __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx)); }
+
+struct MomentSums {
+    double e2 = 0.0, S0 = 0.0, Q = 0.0, S1x = 0.0, S1y = 0.0, S1z = 0.0;
+    double Sxx = 0.0, Syy = 0.0, Szz = 0.0, Sxy = 0.0, Sxz = 0.0, Syz = 0.0;
+    __device__ __forceinline__ void add(double dx, double dy, double dz, double rinv, double e1, double g)
+    {
+        // (no contraction in here: g arrives as the PRODUCT t^4 t^2 when pair_terms is inlined next to this, and "S0 += g" then fuses
+        //  into fma(t^4, t^2, S0) -- one rounding fewer than where g comes out of memory.  The driver's split volume move found it:
+        //  one ulp of a molecule's energy between two routines made of the same source lines.)
+#pragma clang fp contract(off)
+        const double ri2 = rinv * rinv, ri4 = ri2 * ri2;
+        e2 = __builtin_fma(fma_sc(ri4, kAepsBSig4, -kAeps), e1, e2);                  // A eps (B (sigma/r)^4 - 1) e1  :460-461
+        // moments of g u with u = d / r: S1 += (g/r) d, S2 += (g/r^2) d d^T
+        const double w1 = g * rinv, w2 = g * ri2;
+        const double hx = w2 * dx, hy = w2 * dy, hz = w2 * dz;
+        S0 += g;  Q = __builtin_fma(g, g, Q);
+        S1x = __builtin_fma(w1, dx, S1x); S1y = __builtin_fma(w1, dy, S1y); S1z = __builtin_fma(w1, dz, S1z);
+        Sxx = __builtin_fma(hx, dx, Sxx); Syy = __builtin_fma(hy, dy, Syy); Szz = __builtin_fma(hz, dz, Szz);
+        Sxy = __builtin_fma(hx, dy, Sxy); Sxz = __builtin_fma(hx, dz, Sxz); Syz = __builtin_fma(hy, dz, Syz);
+    }
+    // the molecule's energy (:464,483); its moments to mom_out (per lane, or nullptr; 16-byte stores: a divergent store costs its 64
+    // addresses, whatever their width)
+    __device__ __forceinline__ double finish(int cnt, double* __restrict__ mom_out) const
+    {
+#pragma clang fp contract(off)
+        // (every multiply-add explicit: one rounding sequence wherever this is inlined)
+        const double D2 = dist2(Sxx, Syy, Szz), O2 = dist2(Sxy, Sxz, Syz);
+        const double F2 = __builtin_fma(2.0, O2, D2);
+        const double F1 = dist2(S1x, S1y, S1z);
+        const double A = F2 - Q, B = F1 - Q, C = __builtin_fma(S0, S0, -Q);
+        const double T = 0.5 * __builtin_fma(kCos0 * kCos0, C, __builtin_fma(-2.0 * kCos0, B, A));
+        if (mom_out) {
+            double2* m2 = reinterpret_cast<double2*>(mom_out);
+            m2[0] = make_double2(S0, S1x); m2[1] = make_double2(S1y, S1z); m2[2] = make_double2(Sxx, Syy);
+            m2[3] = make_double2(Sxy, Sxz); m2[4] = make_double2(Syz, (double)cnt);
+        }
+        return __builtin_fma(0.5, e2, kLamEps * T);
+    }
+};
+
 // The list streams through buffer loads: the row of slot s is a scalar offset, the column a per-lane offset, and a
 // lane without a column (offset kNoColumn) reads 0 -- no address arithmetic in vector registers at all.
 using ListRsrc = __amdgpu_buffer_rsrc_t;
@@ -129,7 +175,7 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const double r2 = d[u][0] * d[u][0] + d[u][1] * d[u][1] + d[u][2] * d[u][2];
+                    const double r2 = dist2(d[u][0], d[u][1], d[u][2]);
                     if (sb + u < n && r2 < kRcSq) {                                           // :454
                         queue[(cnt < QCAP ? cnt : QCAP) * BLOCK] = cur[4 * h + u];
                         ++cnt;
@@ -152,7 +198,7 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
                     getiv((int)(e >> kJBits), ix, iy, iz);
                     dx = (xj + ix) - xi; dy = (yj + iy) - yi; dz = (zj + iz) - zi;            // molint.F90:447,450
                 }
-                const double r2 = dx * dx + dy * dy + dz * dz;
+                const double r2 = dist2(dx, dy, dz);
                 if (s0 + u < n && r2 < kRcSq) {                                               // :454
                     queue[(cnt < QCAP ? cnt : QCAP) * BLOCK] = e;
                     ++cnt;
@@ -167,8 +213,7 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
     }
 
     // phase 2: pair term and moments over the in-range entries only
-    double e2 = 0.0, S0 = 0.0, Q = 0.0, S1x = 0.0, S1y = 0.0, S1z = 0.0;
-    double Sxx = 0.0, Syy = 0.0, Szz = 0.0, Sxy = 0.0, Sxz = 0.0, Syz = 0.0;
+    MomentSums ms;
     // The gathers of entry q+1 are issued before entry q is evaluated (one LDS round trip hidden per entry).
     auto gather = [&](uint32_t e, double (&v)[6]) {
         getpos((int)(e & kJMask), v[0], v[1], v[2]);
@@ -176,18 +221,10 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
     };
     auto accumulate = [&](const double (&v)[6]) {
         const double dx = (v[0] + v[3]) - xi, dy = (v[1] + v[4]) - yi, dz = (v[2] + v[5]) - zi;
-        const double r2 = dx * dx + dy * dy + dz * dz;
+        const double r2 = dist2(dx, dy, dz);
         double rinv, e1, g;
         pair_terms(r2, rinv, e1, g);                                                  // :456-462
-        const double ri2 = rinv * rinv, ri4 = ri2 * ri2;
-        e2 = __builtin_fma(fma_sc(ri4, kAepsBSig4, -kAeps), e1, e2);                  // A eps (B (sigma/r)^4 - 1) e1  :460-461
-        // moments of g u with u = d / r: S1 += (g/r) d, S2 += (g/r^2) d d^T
-        const double w1 = g * rinv, w2 = g * ri2;
-        const double hx = w2 * dx, hy = w2 * dy, hz = w2 * dz;
-        S0 += g;  Q = __builtin_fma(g, g, Q);
-        S1x = __builtin_fma(w1, dx, S1x); S1y = __builtin_fma(w1, dy, S1y); S1z = __builtin_fma(w1, dz, S1z);
-        Sxx = __builtin_fma(hx, dx, Sxx); Syy = __builtin_fma(hy, dy, Syy); Szz = __builtin_fma(hz, dz, Szz);
-        Sxy = __builtin_fma(hx, dy, Sxy); Sxz = __builtin_fma(hx, dz, Sxz); Syz = __builtin_fma(hy, dz, Syz);
+        ms.add(dx, dy, dz, rinv, e1, g);
     };
     const int nq = cnt < QCAP ? cnt : QCAP;
     if constexpr (LEAN && !BATCH4) {
@@ -209,19 +246,11 @@ __device__ __forceinline__ AtomSum atom_energy(ListRsrc rs, uint32_t col, uint32
             double v[6];
             gather(entry(s), v);
             const double dx = (v[0] + v[3]) - xi, dy = (v[1] + v[4]) - yi, dz = (v[2] + v[5]) - zi;
-            if (dx * dx + dy * dy + dz * dz < kRcSq) { if (seen >= QCAP) accumulate(v); ++seen; }
+            if (dist2(dx, dy, dz) < kRcSq) { if (seen >= QCAP) accumulate(v); ++seen; }
         }
     }
-    const double F2 = Sxx * Sxx + Syy * Syy + Szz * Szz + 2.0 * (Sxy * Sxy + Sxz * Sxz + Syz * Syz);
-    const double F1 = S1x * S1x + S1y * S1y + S1z * S1z;
-    const double T = 0.5 * ((F2 - Q) - 2.0 * kCos0 * (F1 - Q) + kCos0 * kCos0 * (S0 * S0 - Q));
-    if (mom_out) {               // (per lane: this molecule's moments, or nullptr; 16-byte stores: a divergent store costs its 64 addresses, whatever their width)
-        double2* m2 = reinterpret_cast<double2*>(mom_out);
-        m2[0] = make_double2(S0, S1x); m2[1] = make_double2(S1y, S1z); m2[2] = make_double2(Sxx, Syy);
-        m2[3] = make_double2(Sxy, Sxz); m2[4] = make_double2(Syz, (double)cnt);
-    }
     AtomSum out;
-    out.e  = 0.5 * e2 + kLamEps * T;                                                   // :464,483
+    out.e  = ms.finish(cnt, mom_out);
     out.cnt = cnt;
     return out;
 }

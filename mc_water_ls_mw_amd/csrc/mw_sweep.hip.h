@@ -166,8 +166,11 @@ struct VolCtx {
     const unsigned char* snn;
     int rstride;
     double* mom_trial;        // where a volume move leaves the moments of the trial cell, [L][N][kMomStride], or nullptr
+    unsigned* inmask;         // SPLIT builds (volume_move_wg): per molecule the row slots in range, [L][N]
+    double* rec;              // ... and the in-range neighbours' {dx, dy, dz, 1/r, e1, g}, [L][N][kSplitQ][6]
     int N, S, ivcap, L;
 };
+constexpr int kSplitQ = 12;   // in-range neighbours per molecule the split evaluation has room for (more: the one-wavefront routine)
 
 // compute_ivects (molint.F90:174-217) for one lattice, lanes over vectors; returns nivect or -1
 __device__ __forceinline__ int dev_compute_ivects(const double* __restrict__ h, double* __restrict__ siv_l,
@@ -325,7 +328,9 @@ static_assert(kSweepScratchVol == kSweepScratch, "the builds with volume moves t
 // Dynamic LDS of a walker's workgroup (byte offsets), the same arithmetic on the host (launch size) and on the device.
 // Every byte counts for the reference's own 48-molecule cells: eight walkers share a CU when a workgroup's static + dynamic
 // LDS stays within 160 KiB / 8 = 20480 B (mw_sweep_translation_launch).
-struct SweepLds { unsigned iv, pos, tab, uni, mv, scr, row, nn, mom, lmask, total, scr_bytes; };
+struct SweepLds { unsigned iv, pos, tab, uni, mv, scr, row, nn, mom, lmask, inmask, rec, total, scr_bytes; };
+// (a volume move's full-box energy by all wavefronts of the workgroup: two lattices entirely in LDS, four or more moves in flight)
+__host__ __device__ constexpr bool sweep_split(int L, bool ldslist, bool withvol, int spec) { return ldslist && withvol && L == 2 && spec >= 4; }
 __host__ __device__ inline SweepLds sweep_lds(int L, int nw, int ivcap, int N, int nbins, bool ldspos, bool ldslist, int rstride, bool withvol,
                                               bool samplerun, int spec = 1)
 {
@@ -348,8 +353,97 @@ __host__ __device__ inline SweepLds sweep_lds(int L, int nw, int ivcap, int N, i
     const bool momlds = ldslist && spec > 1;
     o.mom = p;   p += momlds ? 2u * L * N * (unsigned)kMomStride * 8u : 0u;
     o.lmask = p; p += momlds ? (unsigned)L * N * 8u : 0u;
+    const bool split = sweep_split(L, ldslist, withvol, spec);
+    o.inmask = p; p += split ? (unsigned)L * N * 4u : 0u;
+    p = (p + 15u) & ~15u;
+    o.rec = p;    p += split ? (unsigned)L * N * 12u * 48u : 0u;              // [L][N][kSplitQ][6] doubles
     o.total = (p + 15u) & ~15u;
     return o;
+}
+
+// SPLIT: a volume move's full-box energy (compute_model_energy, molint.F90:407-499) spread over ALL wavefronts of a look-ahead
+// workgroup -- the builds of a handful of walkers, whose wavefronts beyond one per lattice have nothing else to do during a volume
+// move, and whose speed is one chain's: the one-wavefront routine above walks a molecule's row and its ~8 in-range neighbours' pair
+// terms (rsqrt, reciprocal, exp) one after the other, 7 of a volume move's 16 us.  Walkers entirely in LDS, lane = molecule,
+// wavefront `part` of `nparts` of the lattice:
+//   A  distance tests of row slots part, part + nparts, ...: the in-range slots are OR-ed into inmask[molecule];
+//   B  in-range neighbour q (in list order) of every molecule by wavefront q mod nparts: {d, 1/r, e1, g} into rec[molecule][q];
+//   C  the lattice's first wavefront adds the records up in list order with atom_energy's own arithmetic (MomentSums): the energy
+//      and the moments are atom_energy's bit for bit, so the chain does not depend on the look-ahead of the build that runs it.
+// Between the phases: the caller's workgroup barriers.  B reports a molecule with more than kSplitQ in-range neighbours (`overflow`):
+// the caller then takes the one-wavefront routine.
+__device__ __forceinline__ void dev_split_tests(const VolCtx& c, int l, int part, int nparts, int lane)
+{
+    const int mol = lane < c.N ? lane : 0;
+    const bool act = lane < c.N;
+    const double* Ps = c.spos + (size_t)l * c.N * 3;
+    const double* IVl = c.siv + (size_t)l * c.ivcap * 3;
+    const int n = act ? (int)c.snn[l * c.N + mol] : 0;
+    const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i(n));
+    const unsigned short* row = c.srow + ((size_t)l * c.N + mol) * c.rstride;
+    const double xi = Ps[3 * mol], yi = Ps[3 * mol + 1], zi = Ps[3 * mol + 2];
+    unsigned m = 0u;
+    for (int s = part; s < nmax; s += nparts) {
+        const uint32_t e = s < n ? (uint32_t)row[s] : 0u;
+        const double* pj = Ps + 3 * (size_t)(e & 63u);
+        const double* iv = IVl + 3 * (size_t)(e >> 6);
+        const double dx = (pj[0] + iv[0]) - xi, dy = (pj[1] + iv[1]) - yi, dz = (pj[2] + iv[2]) - zi;     // molint.F90:447,450
+        const double r2 = dist2(dx, dy, dz);
+        if (s < n && r2 < kRcSq) m |= 1u << s;                                                          // :454
+    }
+    if (m != 0u) atomicOr(&c.inmask[l * c.N + mol], m);
+}
+
+__device__ __forceinline__ bool dev_split_records(const VolCtx& c, int l, int part, int nparts, int lane)
+{
+    const int mol = lane < c.N ? lane : 0;
+    const bool act = lane < c.N;
+    const double* Ps = c.spos + (size_t)l * c.N * 3;
+    const double* IVl = c.siv + (size_t)l * c.ivcap * 3;
+    const unsigned short* row = c.srow + ((size_t)l * c.N + mol) * c.rstride;
+    const double xi = Ps[3 * mol], yi = Ps[3 * mol + 1], zi = Ps[3 * mol + 2];
+    const unsigned mask = act ? c.inmask[l * c.N + mol] : 0u;
+    const int cnt = __popc(mask);
+    double* R = c.rec + ((size_t)l * c.N + mol) * kSplitQ * 6;
+    for (int q = part; q < kSplitQ; q += nparts) {            // (uniform bounds; a lane with fewer in-range neighbours sits the step out)
+        if (q < cnt) {
+            unsigned mm = mask;
+            for (int t = 0; t < q; ++t) mm &= mm - 1u;        // the q-th in-range slot
+            const int s = __ffs((int)mm) - 1;
+            const uint32_t e = (uint32_t)row[s];
+            const double* pj = Ps + 3 * (size_t)(e & 63u);
+            const double* iv = IVl + 3 * (size_t)(e >> 6);
+            const double dx = (pj[0] + iv[0]) - xi, dy = (pj[1] + iv[1]) - yi, dz = (pj[2] + iv[2]) - zi;
+            const double r2 = dist2(dx, dy, dz);
+            double rinv, e1, g;
+            pair_terms(r2, rinv, e1, g);                                                  // :456-462
+            double2* r2p = reinterpret_cast<double2*>(R + 6 * q);
+            r2p[0] = make_double2(dx, dy); r2p[1] = make_double2(dz, rinv); r2p[2] = make_double2(e1, g);
+        }
+    }
+    return __ballot(cnt > kSplitQ) != 0ull;
+}
+
+// (value in every lane, like dev_wave_model_energy)
+__device__ __forceinline__ double dev_split_sum(const VolCtx& c, int l, int lane, double* __restrict__ mom_l, double* lane_e = nullptr)
+{
+    const int mol = lane < c.N ? lane : 0;
+    const bool act = lane < c.N;
+    const int cnt = act ? __popc(c.inmask[l * c.N + mol]) : 0;
+    const double* R = c.rec + ((size_t)l * c.N + mol) * kSplitQ * 6;
+    MomentSums ms;
+    for (int q = 0; q < cnt; ++q) {
+        const double2* r2p = reinterpret_cast<const double2*>(R + 6 * q);
+        const double2 a = r2p[0], b = r2p[1], d = r2p[2];
+        ms.add(a.x, a.y, b.x, b.y, d.x, d.y);
+    }
+    double esum = 0.0;
+    const double e = ms.finish(cnt, (mom_l && act) ? mom_l + (size_t)mol * kMomStride : nullptr);
+    if (lane_e) *lane_e = e;
+    if (act) esum += e;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) esum += __shfl_xor(esum, off, 64);
+    return esum;
 }
 
 // Volume move of one walker (mc_volume, mc_moves.F90:1216-1534; ref_ljr, which only chain synchronisation reads, is not
@@ -361,7 +455,7 @@ __host__ __device__ inline SweepLds sweep_lds(int L, int nw, int ivcap, int N, i
 // Returns (every wavefront): 1 accepted, 0 rejected, -1 rejected because a cell needed more image vectors than ivcap.
 // With look-ahead (NW > NLAT wavefronts) the wavefronts beyond the first NLAT have no lattice of their own here: they keep
 // the workgroup's barriers company.
-template <int NLAT, int NW, bool LDSPOS, typename DecideFn>
+template <int NLAT, int NW, bool LDSPOS, bool SPLIT, typename DecideFn>
 __device__ __forceinline__
 int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max, int wv, int lane,
                    double* __restrict__ sx, int* __restrict__ sdec, DecideFn decide)
@@ -419,8 +513,56 @@ int volume_move_wg(const VolCtx& c, const double* __restrict__ U, double dv_max,
         wave_sync();
         [[maybe_unused]] const unsigned long long tv2 = MW_SW_NOW();
         if (niv < 0) bad = 1;
-        else new_e = dev_wave_model_energy<LDSPOS, (NW > NLAT)>(c, l, lane, c.mom_trial ? c.mom_trial + (size_t)l * c.N * kMomStride : nullptr);
+        else if constexpr (!SPLIT) new_e = dev_wave_model_energy<LDSPOS, (NW > NLAT)>(c, l, lane, c.mom_trial ? c.mom_trial + (size_t)l * c.N * kMomStride : nullptr);
         MW_SW_ACC(36, MW_SW_NOW() - tv2); MW_SW_ACC(37, tv2 - tv1);
+    }
+    if constexpr (SPLIT) {
+        // the full-box energy by every wavefront of the workgroup (see dev_split_tests): sdec[2 + lattice] != 0 -- a cell that is
+        // not to be evaluated (bad, or lattice 2 after a bad lattice 1); sdec[0] -- a molecule with more in-range neighbours than
+        // the records hold
+        [[maybe_unused]] const unsigned long long tv2 = MW_SW_NOW();
+        constexpr int P = NW / NLAT;
+        const int lw = wv % NLAT, part = wv / NLAT;
+        if (active && lane == 0) sdec[2 + l] = bad | (bad0 ? 2 : 0);
+        if (part == 1 && lane < c.N) c.inmask[lw * c.N + lane] = 0u;                 // (a wavefront that is idle until here)
+        if (wv == NLAT && lane == 0) sdec[0] = 0;
+        wg_sync<NW>();                                  // the trial cell -- positions, image vectors -- is there for everybody
+        const bool run = sdec[2 + lw] == 0;
+        if (run) dev_split_tests(c, lw, part, P, lane);
+        wg_sync<NW>();
+        if (run && dev_split_records(c, lw, part, P, lane) && lane == 0) sdec[0] = 1;
+        wg_sync<NW>();
+        if (active && !bad0 && !bad) {
+            double* mom_l = c.mom_trial ? c.mom_trial + (size_t)l * c.N * kMomStride : nullptr;
+            new_e = sdec[0] != 0 ? dev_wave_model_energy<LDSPOS, true>(c, l, lane, mom_l) : dev_split_sum(c, l, lane, mom_l);
+#ifdef MW_SPLIT_CHECK     // diagnostic build (tools/variants.py splitcheck): the split sum against the one-wavefront routine, molecule by molecule
+                          // -- g_sweep_stamps[44] lattice energies checked, [45] of them with a molecule that differs, [43], [46], [47] the last such
+            if (sdec[0] == 0) {
+                double es = 0.0;
+                (void)dev_split_sum(c, l, lane, nullptr, &es);
+                const int mol = lane < c.N ? lane : 0;
+                const int n = lane < c.N ? (int)c.snn[l * c.N + mol] : 0;
+                const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i(n));
+                const unsigned short* row = c.srow + ((size_t)l * c.N + mol) * c.rstride;
+                const double* Ps = c.spos + (size_t)l * c.N * 3;
+                const double* IVl = c.siv + (size_t)l * c.ivcap * 3;
+                auto getiv = [&](int k, double& x, double& y, double& z) { x = IVl[3 * k]; y = IVl[3 * k + 1]; z = IVl[3 * k + 2]; };
+                auto getpos = [&](int j, double& x, double& y, double& z) { const double* p = Ps + 3 * (size_t)j; x = p[0]; y = p[1]; z = p[2]; };
+                auto ent = [&](int s) -> uint32_t { const uint32_t e = s < n ? (uint32_t)row[s] : 0u; return (e & 63u) | ((e >> 6) << kJBits); };
+                uint32_t cur[8];
+                AtomSum a = atom_energy<64, true, true, kSweepQCap>(ListRsrc(), kNoColumn, kNoColumn, mol, n, nmax, 0, c.N, c.S, c.queue, getpos, getiv, cur, nullptr, ent);
+                const bool bad_l = lane < c.N && a.e != es;
+                const unsigned long long bm = __ballot(bad_l);
+                if (blockIdx.x == 0 && lane == 0) atomicAdd(&g_sweep_stamps[44], 1ull);
+                if (bm != 0ull && blockIdx.x == 0 && lane == __ffsll((long long)bm) - 1) {
+                    atomicAdd(&g_sweep_stamps[45], 1ull);
+                    g_sweep_stamps[43] = (unsigned long long)(a.cnt | (__popc(c.inmask[l * c.N + mol]) << 8) | (lane << 16) | (n << 24));
+                    g_sweep_stamps[46] = (unsigned long long)__double_as_longlong(a.e); g_sweep_stamps[47] = (unsigned long long)__double_as_longlong(es);
+                }
+            }
+#endif
+        }
+        MW_SW_ACC(36, MW_SW_NOW() - tv2);
     }
     [[maybe_unused]] const unsigned long long tv3 = MW_SW_NOW();
     if (active && lane == 0) { sx[l] = new_e; sdec[2 + l] = bad; }
@@ -577,6 +719,8 @@ void k_sweep(double* pos, double* hmat, double* ivect,
     constexpr bool MOMLDS = LDSLIST && SPEC > 1;          // (see sweep_lds)
     double* smom = reinterpret_cast<double*>(smem_raw + lay.mom);
     unsigned long long* slmask = reinterpret_cast<unsigned long long*>(smem_raw + lay.lmask);
+    constexpr bool SPLIT = sweep_split(NLAT, LDSLIST, WITHVOL, SPEC);
+    static_assert(kSplitQ == 12, "sweep_lds sizes the records for twelve per molecule");
     const double invPi = 1.0 / 3.141592653589793238462643383279502884197;
 
     // ---- staging: image vectors, (small systems) positions, list rows and row lengths, the walker's tables -------------
@@ -1320,7 +1464,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                     VolCtx vm;
                     vm.pos_g = pos + (size_t)bv * N * 3; vm.spos = spos; vm.siv = siv; vm.sniv = sniv;
                     vm.queue = reinterpret_cast<uint32_t*>(ws) + lv; vm.N = N; vm.S = S; vm.ivcap = ivcap; vm.L = L;
-                    vm.srow = srow; vm.snn = snn; vm.rstride = rstride; vm.mom_trial = nullptr;
+                    vm.srow = srow; vm.snn = snn; vm.rstride = rstride; vm.mom_trial = nullptr; vm.inmask = nullptr; vm.rec = nullptr;
                     (void)dev_wave_model_energy<true>(vm, lat, lv, mom_of(msel, lat));
                 }
                 if (SPEC > 1) wg_sync<NW>(); else wave_sync();
@@ -1385,6 +1529,8 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 vc.queue = reinterpret_cast<uint32_t*>(ws) + lv; vc.N = N; vc.S = S; vc.ivcap = ivcap; vc.L = L;
                 vc.srow = LDSLIST ? srow : nullptr; vc.snn = LDSLIST ? snn : nullptr; vc.rstride = rstride;
                 vc.mom_trial = usemom ? mom_of(msel ^ 1, 0) : nullptr;
+                vc.inmask = SPLIT ? reinterpret_cast<unsigned*>(smem_raw + lay.inmask) : nullptr;
+                vc.rec = SPLIT ? reinterpret_cast<double*>(smem_raw + lay.rec) : nullptr;
                 const double* U = U0;
                 double diffkT = 0.0;
                 bool do_switch = false;
@@ -1447,7 +1593,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                     wave_sync();
                     return okv;
                 };
-                const int rv = volume_move_wg<NLAT, NW, LDSPOS>(vc, U, C.dv_max, wv, lv, sx, sdec, decide);
+                const int rv = volume_move_wg<NLAT, NW, LDSPOS, SPLIT>(vc, U, C.dv_max, wv, lv, sx, sdec, decide);
                 if (usemom && rv == 1) msel ^= 1;                  // (the trial cell's moments are the walker's now)
                 if (wv == 0) {
                     int sw = 0;

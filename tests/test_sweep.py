@@ -692,7 +692,7 @@ def test_moment_path_of_the_driver_is_the_row_scan(case, ahead, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["ih1000", "pair1536_wl", "ih1000_npt", "ih64", "ih64_npt", "ih288", "ih288_npt"])
+@pytest.mark.parametrize("case", ["ih1000", "pair1536_wl", "ih1000_npt", "ih64", "ih64_npt", "ih288", "ih288_npt", "pair48_wl", "pair48_wl_npt"])
 def test_lookahead_is_the_sequential_chain(case, monkeypatch):
     """Look-ahead (several moves of a walker evaluated at once, decided in order; mw_sweep.hip.h) changes nothing: the move
     log, the final positions and the tables of a run with 2 or 4 moves in flight are BITWISE those of the one-move-at-a-time
@@ -710,8 +710,12 @@ def test_lookahead_is_the_sequential_chain(case, monkeypatch):
             em, farm = _farm(boxes, 1, 230.0, 1.1)
             nlat = 1
         else:
-            z1, z2 = load_golden("ic1536"), load_golden("ih1536")
-            grid = MuGrid(101, -8000.0, 8000.0)
+            # two lattices: 1536 molecules (global memory), or the reference's 48-molecule pair (entirely in LDS: the moment path, and with
+            # volume moves at four or six in flight the full-box energy spread over the workgroup's wavefronts -- its sum must be the
+            # one-wavefront routine's to the bit; a thermalised pair reaches 10-13 in-range neighbours, i.e. the records' overflow too)
+            small = case.startswith("pair48")
+            z1, z2 = (load_golden("ic48"), load_golden("ih48")) if small else (load_golden("ic1536"), load_golden("ih1536"))
+            grid = MuGrid(101, -400.0, 400.0) if small else MuGrid(101, -8000.0, 8000.0)
             boxes = []
             for w in range(2):
                 boxes += [(z1["h"], lat.thermalise(z1["xyz"], 0.1, 7 + w)), (z2["h"], lat.thermalise(z2["xyz"], 0.1, 18 + w))]
@@ -720,8 +724,11 @@ def test_lookahead_is_the_sequential_chain(case, monkeypatch):
             nlat = 2
         try:
             if case.endswith("_npt"):
-                em._chk(em.L.mw_sweep_options(0, 1, 0, 1, __import__("ctypes").c_double(1.0), __import__("ctypes").c_double(0.0),
-                                              __import__("ctypes").c_double(0.0), __import__("ctypes").c_double(1.0 / 2.90363081e8)))
+                if nlat == 1:
+                    em._chk(em.L.mw_sweep_options(0, 1, 0, 1, __import__("ctypes").c_double(1.0), __import__("ctypes").c_double(0.0),
+                                                  __import__("ctypes").c_double(0.0), __import__("ctypes").c_double(1.0 / 2.90363081e8)))
+                else:
+                    farm.options(record=True, samplerun=False, always_switch=True, npt=True, wl_factor=0.05)
                 farm.moves(trans_prob=0.5, vol_prob=0.05, dv_max_ang=0.3)
             nw = len(boxes) // nlat
             for w in range(1, nw + 1):
@@ -736,7 +743,7 @@ def test_lookahead_is_the_sequential_chain(case, monkeypatch):
 
     ref = run(1)
     assert 20 < ref[0][0][:, 1].astype(int).__and__(1).sum() < 380         # moves are accepted and rejected
-    for ahead in (2, 4) + ((8,) if case.startswith("ih1000") else ()):     # (eight in flight: one-lattice walkers in global memory)
+    for ahead in (2, 4) + ((8,) if case.startswith("ih1000") else ()) + ((6,) if case.startswith("pair48") else ()):   # (eight in flight: one-lattice walkers in global memory; six: two-lattice walkers in LDS)
         got = run(ahead)
         assert np.array_equal(got[0], ref[0])
         for a, b in zip(got[1], ref[1]):

@@ -19,7 +19,9 @@ KNOWN = {"stamps": ["-DMW_SWEEP_STAMPS"], "spill": ["-DMW_SWEEP_WAVES_CAP=5"],
          "dnobin": ["-DMW_ABL_D_NOBIN"], "dnoswexp": ["-DMW_ABL_D_NOSWEXP"], "dnoexp": ["-DMW_ABL_D_NOEXP"], "dnowl": ["-DMW_ABL_D_NOWL"],
          "dnosw": ["-DMW_ABL_D_NOSW"],
          "dnoall": ["-DMW_ABL_D_NOBIN", "-DMW_ABL_D_NOSWEXP", "-DMW_ABL_D_NOEXP", "-DMW_ABL_D_NOWL", "-DMW_ABL_D_NOSW"],
-         "frame": ["-DMW_ABL_NODECIDE", "-DMW_ABL_NOEVAL"]}
+         "frame": ["-DMW_ABL_NODECIDE", "-DMW_ABL_NOEVAL"],
+         # a volume move's split full-box energy checked against the one-wavefront routine inside the kernel (stamps 43..47)
+         "splitcheck": ["-DMW_SWEEP_STAMPS", "-DMW_SPLIT_CHECK"]}
 
 
 def path(name):
