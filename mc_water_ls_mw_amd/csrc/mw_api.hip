@@ -119,6 +119,7 @@ struct Ctx {
     double *d_wfac = nullptr, *d_wsum = nullptr; // [walker] Wang-Landau increment, Swetnam's visit total
     int* d_winflag = nullptr;                    // [walker] walker_in_window
     double* d_wmom = nullptr; size_t wmom_cap = 0;   // the driver's moment scratch (doubles), grown on demand
+    double* d_pm = nullptr; int* d_srvmomok = nullptr;   // the resident server's moment path: the positions its moments were made from [nbox][N][3]; per box, still in step
     double* d_wstep = nullptr;                   // [walker][2] max_trans, dv_max (bohr) when the walkers' step sizes differ (mw_sweep_steps)
     bool has_steps = false;
     int sweep_log_ahead = 8;                     // look-ahead allowed when the move log is on (tests pin it to compare builds)
@@ -534,7 +535,7 @@ void release_all()
                     g.d_nivect, g.d_list, g.d_listm, g.d_nn, g.d_stats, g.d_order, g.d_nns, g.d_cmax, g.d_cin, g.d_grid,
                     g.d_usegrid, g.d_cellid, g.d_shift, g.d_sorted, g.d_wrel, g.d_wpos, g.d_wsh, g.d_ccount, g.d_cstart, g.d_ccursor, g.d_partial,
                     g.d_cpartial, g.d_energy, g.d_counts, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.d_mperm, g.d_mdecl,
-                    g.d_mwork, g.d_mom, g.d_mtot, g.d_wmom};
+                    g.d_mwork, g.d_mom, g.d_mtot, g.d_wmom, g.d_pm, g.d_srvmomok};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g.h_pin) (void)hipHostFree(g.h_pin);
     if (g.h_stage) (void)hipHostFree(g.h_stage);
@@ -1091,12 +1092,31 @@ static int server_start_locked()
     // a few tenths of a second of empty polls (one poll is a PCIe round trip, ~1 us) and the server leaves by itself
     static const bool stamps = std::getenv("MW_SERVER_STAMPS") != nullptr;
     static const bool plain = std::getenv("MW_SERVER_PLAIN_LOADS") != nullptr;      // experiment only: L1-cached position loads
+    // The server's moment path (k_local_server): every molecule's moments of every box, from the full-box kernel, and the positions
+    // they belong to -- made HERE, each time the server starts (every entry point that may move a molecule stops it first).  For the
+    // drop-in's handful of boxes (a farm's thousands are not served one call at a time); MW_SERVER_MOMENTS=0: off.
+    static const bool srvmom = !(std::getenv("MW_SERVER_MOMENTS") && std::getenv("MW_SERVER_MOMENTS")[0] == '0');
+    double* mom = nullptr;
+    if (srvmom && g.nbox <= 64 && model_geo(g.nbox).lds && g.list_version > 1) {
+        bool okm = launch_model_energy(1, g.nbox, true, false) == 0 && g.d_mom != nullptr;
+        if (okm && !g.d_pm) okm = hipMalloc(&g.d_pm, (size_t)g.nbox * g.N * 3 * sizeof(double)) == hipSuccess;
+        if (okm && !g.d_srvmomok) okm = hipMalloc(&g.d_srvmomok, (size_t)g.nbox * sizeof(int)) == hipSuccess;
+        if (okm) {
+            std::vector<int> ones((size_t)g.nbox, 1);
+            okm = hipMemcpyAsync(g.d_pm, g.d_pos, (size_t)g.nbox * g.N * 3 * sizeof(double), hipMemcpyDeviceToDevice, g.stream) == hipSuccess
+               && hipMemcpyAsync(g.d_srvmomok, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice, g.stream) == hipSuccess
+               && hipStreamSynchronize(g.stream) == hipSuccess;
+        }
+        if (okm) mom = g.d_mom;
+        else (void)hipGetLastError();
+        g.mom_count = 0;                 // (the server will change them under the batch kernels' feet: not theirs to reuse)
+    }
     if (plain)
         hipLaunchKernelGGL(mw::k_local_server<false>, dim3(g.nslots), dim3(64), 0, g.sstream, g.d_head, g.d_slots, g.d_req, g.d_pos, g.d_ivect,
-                           g.d_nivect, g.d_listm, g.d_nn, g.N, g.ivcap, 300000LL, stamps ? 1 : 0);
+                           g.d_nivect, g.d_listm, g.d_nn, g.N, g.ivcap, 300000LL, stamps ? 1 : 0, mom, g.d_pm, g.d_srvmomok);
     else
         hipLaunchKernelGGL(mw::k_local_server<true>, dim3(g.nslots), dim3(64), 0, g.sstream, g.d_head, g.d_slots, g.d_req, g.d_pos, g.d_ivect,
-                           g.d_nivect, g.d_listm, g.d_nn, g.N, g.ivcap, 300000LL, stamps ? 1 : 0);
+                           g.d_nivect, g.d_listm, g.d_nn, g.N, g.ivcap, 300000LL, stamps ? 1 : 0, mom, g.d_pm, g.d_srvmomok);
     const hipError_t err = hipGetLastError();
     if (sw) (void)hipSetDevice(prev);
     if (err != hipSuccess) return fail("mw: launching the local-energy server failed: %s", hipGetErrorString(err));

@@ -608,7 +608,7 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
 // moments_commit() brings the moments up to date from them when the move is accepted.  (5) Look-ahead (NOTH > 0, as
 // move_energy_wave): bit o of `cmask` comes back set when the evaluation read the position of oth[o] OR the moments of a molecule
 // that lists oth[o] -- `lmask[j]` = the molecules of j's row as a bit mask (N <= 64), fetched with j's position.
-template <bool SWEEP = false, int NOTH = 0, typename PosFn, typename IvFn, typename NnFn>
+template <bool SWEEP = false, int NOTH = 0, bool LATE = (SWEEP && NOTH == 0), typename PosFn, typename IvFn, typename NnFn>
 __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, NnFn nnof, const double* __restrict__ MOM,
                                                      WaveScratch* __restrict__ ws, const unsigned short* __restrict__ ptab, int i, int n_i, uint32_t e,
                                                      double xo, double yo, double zo, double xn, double yn, double zn,
@@ -658,7 +658,7 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
     // reciprocal / exp the read hides behind)
     // (the driver's one-move-at-a-time builds -- thousands of walkers, sixteen wavefronts per compute unit to hide a read behind, and
     //  a budget of 128 vector registers -- ask for them AFTER the pair terms instead: twenty registers fewer held across those)
-    constexpr bool kLateMoments = SWEEP && NOTH == 0;
+    constexpr bool kLateMoments = LATE;    // (the resident server -- one wavefront on its own -- asks early, like the look-ahead builds)
     double M[10];
     auto load_moments = [&]() {
         const double2* Mj = reinterpret_cast<const double2*>(MOM + (size_t)(in ? j : i) * kMomStride);   // (a lane without an in-range j reads i's own: harmless, unused)
@@ -1170,7 +1170,8 @@ __global__ __launch_bounds__(64)
 void k_local_server(MailHead* __restrict__ head, MailSlot* __restrict__ slots, const MailSlot* __restrict__ reqs,
                     double* __restrict__ pos, const double* __restrict__ ivect, const int* __restrict__ nivect,
                     const uint32_t* __restrict__ listm, const int* __restrict__ nn,
-                    int N, int ivcap, long long idle_limit, int stamps)
+                    int N, int ivcap, long long idle_limit, int stamps,
+                    double* mom, double* pm, int* momok)   // the moment path (below), or nullptr
 {
     __shared__ WaveScratch ws;
     const int lane = threadIdx.x & 63;
@@ -1214,7 +1215,54 @@ void k_local_server(MailHead* __restrict__ head, MailSlot* __restrict__ slots, c
             auto nnof = [&](int jx) { return NNb[jx]; };
             MoveRes res;
             double e;
-            if (move_energy_wave(getpos, getiv, row, nnof, &ws, nivect[b], i, nnof(i), row(i, lane & 31), xi, yi, zi, xi, yi, zi, lane, res)) {
+            // THE MOMENT PATH (round 4; move_energy_mom_wave<SWEEP>, as in the Monte Carlo driver): `mom` = every molecule's moments of
+            // the served boxes, made by the full-box kernel when the server starts, and `pm` = the positions they were made FROM.  The
+            // host changes positions only through the requests' own overrides -- the queried molecule and the one queried before it
+            // (anything else is an exclusive entry point, which stops the server) -- so at most `prev` can have moved since: if its
+            // committed position is no longer the one in `pm`, its neighbours' moments and its own are brought up to date first
+            // (moments_commit: an accepted move of the host's chain, one request in four at most), then the queried molecule is
+            // evaluated with pm[i] as the "old" position -- the arm the moments hold -- and the request's as the trial one.
+            // Every neighbour is read from `pm`.  A request this does not cover (an uncommitted override of prev, a decline) takes the
+            // routines below; one that leaves the moments behind (a declined update) switches the path off for the box.
+            bool served = false;
+            if (mom != nullptr) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (this wavefront's own earlier writes to mom / pm: past the L1)
+                double* MOMb = mom + (size_t)b * N * kMomStride;
+                double* PMb = pm + (size_t)b * N * 3;
+                auto getpm = [&](int jx, double& x, double& y, double& z) { const double* q = PMb + 3 * (size_t)jx; x = q[0]; y = q[1]; z = q[2]; };
+                bool ok = momok[b] != 0;
+                unsigned int nocounts[4];
+                int cnt = 0;
+                if (ok && o2.idx >= 0 && o2.idx != i) {
+                    double px, py, pz;
+                    getpm(prev, px, py, pz);
+                    if (px != o2.x || py != o2.y || pz != o2.z) {
+                        if (!(flags & 1)) ok = false;              // (an override that is not committed: the moments must not follow it)
+                        else {
+                            MoveRes r2;
+                            if (move_energy_mom_wave<true, 0, false>(getpm, getiv, nnof, MOMb, &ws, nullptr, prev, nnof(prev), row(prev, lane & 31),
+                                                                     px, py, pz, o2.x, o2.y, o2.z, lane, r2, nocounts, &cnt)) {
+                                moments_commit(MOMb, &ws, prev, cnt, px, py, pz, o2.x, o2.y, o2.z, lane);
+                                if (lane == 0) { PMb[3 * prev] = o2.x; PMb[3 * prev + 1] = o2.y; PMb[3 * prev + 2] = o2.z; }
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                            } else {
+                                ok = false;
+                                if (lane == 0) momok[b] = 0;       // (the moments no longer follow the positions: off for this box until the server restarts)
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                            }
+                        }
+                    }
+                }
+                if (ok) {
+                    double px, py, pz;
+                    getpm(i, px, py, pz);
+                    if (move_energy_mom_wave<true, 0, false>(getpm, getiv, nnof, MOMb, &ws, nullptr, i, nnof(i), row(i, lane & 31),
+                                                             px, py, pz, xi, yi, zi, lane, res, nocounts, &cnt)) { e = res.en; served = true; }
+                }
+            }
+            if (served) {
+            } else if (move_energy_wave(getpos, getiv, row, nnof, &ws, nivect[b], i, nnof(i), row(i, lane & 31), xi, yi, zi, xi, yi, zi, lane, res)) {
                 e = res.eo;
             } else {
                 unsigned int ni, ns;
