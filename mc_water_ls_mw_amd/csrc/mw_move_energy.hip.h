@@ -608,7 +608,10 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
 // moments_commit() brings the moments up to date from them when the move is accepted.  (5) Look-ahead (NOTH > 0, as
 // move_energy_wave): bit o of `cmask` comes back set when the evaluation read the position of oth[o] OR the moments of a molecule
 // that lists oth[o] -- `lmask[j]` = the molecules of j's row as a bit mask (N <= 64), fetched with j's position.
-template <bool SWEEP = false, int NOTH = 0, bool LATE = (SWEEP && NOTH == 0), typename PosFn, typename IvFn, typename NnFn>
+// WHEN the moments are asked for: 1 = once the in-range entries are known (a 96-byte read per in-range neighbour and geometry); 0 =
+// after the pair terms (see below); 2 = WITH the positions, for every row entry whether in range or not -- one dependent load level
+// fewer, which is what a lone wavefront reading global memory pays for (the resident server: ~0.5 us a level).
+template <bool SWEEP = false, int NOTH = 0, int WHEN = (SWEEP && NOTH == 0) ? 0 : 1, typename PosFn, typename IvFn, typename NnFn>
 __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, NnFn nnof, const double* __restrict__ MOM,
                                                      WaveScratch* __restrict__ ws, const unsigned short* __restrict__ ptab, int i, int n_i, uint32_t e,
                                                      double xo, double yo, double zo, double xn, double yn, double zn,
@@ -633,6 +636,12 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
         for (int o = 0; o < NOTH; ++o) cm |= (has && j == oth[o]) ? 1u << o : 0u;
     }
     double xj, yj, zj, jvx, jvy, jvz;
+    double M[10];
+    if constexpr (WHEN == 2) {
+        const double2* Mj = reinterpret_cast<const double2*>(MOM + (size_t)(has ? j : i) * kMomStride);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) { const double2 v = Mj[c]; M[2 * c] = v.x; M[2 * c + 1] = v.y; }
+    }
     getpos(j, xj, yj, zj);
     getiv(kimg, jvx, jvy, jvz);
     [[maybe_unused]] unsigned long long lmj = 0ull;
@@ -658,14 +667,13 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
     // reciprocal / exp the read hides behind)
     // (the driver's one-move-at-a-time builds -- thousands of walkers, sixteen wavefronts per compute unit to hide a read behind, and
     //  a budget of 128 vector registers -- ask for them AFTER the pair terms instead: twenty registers fewer held across those)
-    constexpr bool kLateMoments = LATE;    // (the resident server -- one wavefront on its own -- asks early, like the look-ahead builds)
-    double M[10];
+    constexpr bool kLateMoments = WHEN == 0;
     auto load_moments = [&]() {
         const double2* Mj = reinterpret_cast<const double2*>(MOM + (size_t)(in ? j : i) * kMomStride);   // (a lane without an in-range j reads i's own: harmless, unused)
 #pragma unroll
         for (int c = 0; c < 5; ++c) { const double2 v = Mj[c]; M[2 * c] = v.x; M[2 * c + 1] = v.y; }
     };
-    if constexpr (!kLateMoments) load_moments();
+    if constexpr (WHEN == 1) load_moments();
     double rinv = 0.0, e1 = 0.0, g = 0.0;
     if (in) pair_terms(r2, rinv, e1, g);
     const double qq = kSigSq * rinv * rinv;
@@ -1230,36 +1238,36 @@ void k_local_server(MailHead* __restrict__ head, MailSlot* __restrict__ slots, c
                 double* MOMb = mom + (size_t)b * N * kMomStride;
                 double* PMb = pm + (size_t)b * N * 3;
                 auto getpm = [&](int jx, double& x, double& y, double& z) { const double* q = PMb + 3 * (size_t)jx; x = q[0]; y = q[1]; z = q[2]; };
-                bool ok = momok[b] != 0;
+                // ONE round trip for everything the path needs to get going (a lone wavefront pays ~0.5 us per dependent load level)
+                const int pv = o2.idx >= 0 ? prev : i;
+                const int mk = momok[b];
+                double px, py, pz, qx, qy, qz;
+                getpm(pv, px, py, pz);
+                getpm(i, qx, qy, qz);
+                const uint32_t erow = row(i, lane & 31);
+                const int ni = nnof(i);
                 unsigned int nocounts[4];
                 int cnt = 0;
-                if (ok && o2.idx >= 0 && o2.idx != i) {
-                    double px, py, pz;
-                    getpm(prev, px, py, pz);
-                    if (px != o2.x || py != o2.y || pz != o2.z) {
-                        if (!(flags & 1)) ok = false;              // (an override that is not committed: the moments must not follow it)
-                        else {
-                            MoveRes r2;
-                            if (move_energy_mom_wave<true, 0, false>(getpm, getiv, nnof, MOMb, &ws, nullptr, prev, nnof(prev), row(prev, lane & 31),
-                                                                     px, py, pz, o2.x, o2.y, o2.z, lane, r2, nocounts, &cnt)) {
-                                moments_commit(MOMb, &ws, prev, cnt, px, py, pz, o2.x, o2.y, o2.z, lane);
-                                if (lane == 0) { PMb[3 * prev] = o2.x; PMb[3 * prev + 1] = o2.y; PMb[3 * prev + 2] = o2.z; }
-                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                            } else {
-                                ok = false;
-                                if (lane == 0) momok[b] = 0;       // (the moments no longer follow the positions: off for this box until the server restarts)
-                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                            }
+                bool ok = true;
+                if (o2.idx >= 0 && o2.idx != i && (px != o2.x || py != o2.y || pz != o2.z)) {       // prev has moved since its moments were made
+                    if (!(flags & 1) || mk == 0) ok = false;       // (an override that is not committed: the moments must not follow it)
+                    else {
+                        MoveRes r2;
+                        if (move_energy_mom_wave<true, 0, 2>(getpm, getiv, nnof, MOMb, &ws, nullptr, prev, nnof(prev), row(prev, lane & 31),
+                                                                 px, py, pz, o2.x, o2.y, o2.z, lane, r2, nocounts, &cnt)) {
+                            moments_commit(MOMb, &ws, prev, cnt, px, py, pz, o2.x, o2.y, o2.z, lane);
+                            if (lane == 0) { PMb[3 * prev] = o2.x; PMb[3 * prev + 1] = o2.y; PMb[3 * prev + 2] = o2.z; }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        } else {
+                            ok = false;
+                            if (lane == 0) momok[b] = 0;           // (the moments no longer follow the positions: off for this box until the server restarts)
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                         }
                     }
                 }
-                if (ok) {
-                    double px, py, pz;
-                    getpm(i, px, py, pz);
-                    if (move_energy_mom_wave<true, 0, false>(getpm, getiv, nnof, MOMb, &ws, nullptr, i, nnof(i), row(i, lane & 31),
-                                                             px, py, pz, xi, yi, zi, lane, res, nocounts, &cnt)) { e = res.en; served = true; }
-                }
+                if (ok && move_energy_mom_wave<true, 0, 2>(getpm, getiv, nnof, MOMb, &ws, nullptr, i, ni, erow,
+                                                               qx, qy, qz, xi, yi, zi, lane, res, nocounts, &cnt) && mk != 0) { e = res.en; served = true; }
             }
             if (served) {
             } else if (move_energy_wave(getpos, getiv, row, nnof, &ws, nivect[b], i, nnof(i), row(i, lane & 31), xi, yi, zi, xi, yi, zi, lane, res)) {
