@@ -336,8 +336,9 @@ def sweep_roofline(case, moves, kernel_ms, counters):
 def chain_self_check(device, name):
     """Walker 0's chain on the device against the ORACLE's (tests/golden/<name>.npz, tests/golden/make_chain_fixtures.py): same
     molecule, same outcome (accepted / lattice switch / volume move) move by move, energies to 1e-10 relative -- with one move at a
-    time (the build a farm of thousands runs) and with the look-ahead the launch would pick for a handful of walkers.  Raises
-    SystemExit on a mismatch, like the check of the timed move kernel."""
+    time (the build a farm of thousands runs) and with the look-ahead the launch would pick for a handful of walkers; for walkers in
+    global memory (chain_ih4096) also on the moment path a launch that fills the chip takes (MW_SWEEP_MOMENTS=2 forces it for the
+    two walkers here: what the timed 2048-walker launch runs).  Raises SystemExit on a mismatch, like the check of the timed move kernel."""
     from mc_water_ls_mw_amd import lattice as lat
     from mc_water_ls_mw_amd.energy import load_boxes
     from mc_water_ls_mw_amd.sweep import MuGrid, WalkerFarm
@@ -348,11 +349,16 @@ def chain_self_check(device, name):
     ref = g["log"]
     nmoves = len(ref)
     worst, checked = 0.0, 0
-    for ahead in ("1", None):
+    variants = [("1", None), (None, None)] + ([("1", "2"), ("2", "2")] if not name.startswith("chain_farm48") else [])
+    for ahead, moments in variants:
         if ahead is None:
             os.environ.pop("MW_SWEEP_AHEAD", None)
         else:
             os.environ["MW_SWEEP_AHEAD"] = ahead
+        if moments is None:
+            os.environ.pop("MW_SWEEP_MOMENTS", None)
+        else:
+            os.environ["MW_SWEEP_MOMENTS"] = moments
         if name.startswith("chain_farm48"):
             z1, z2 = (np.load(os.path.join(ROOT, "tests", "golden", f)) for f in ("ic48.npz", "ih48.npz"))
             nw, nlat = 4, 2
@@ -391,6 +397,7 @@ def chain_self_check(device, name):
             raise SystemExit(f"{name} (look-ahead {ahead or 'auto'}): walker 0's energies differ from the oracle's chain (max rel {err:.3e})")
         worst, checked = max(worst, err), checked + nmoves
     os.environ.pop("MW_SWEEP_AHEAD", None)
+    os.environ.pop("MW_SWEEP_MOMENTS", None)
     return {"fixture": f"tests/golden/{name}.npz", "moves_checked": checked, "max_rel_err_energies": worst,
             "accepted": int((ref[:, 1].astype(int) & 1).sum()), "lattice_switches": int(((ref[:, 1].astype(int) >> 1) & 1).sum()),
             "volume_moves": int(((ref[:, 1].astype(int) >> 2) & 1).sum())}

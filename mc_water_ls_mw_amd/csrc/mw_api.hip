@@ -68,6 +68,8 @@ struct Ctx {
     double* d_pos = nullptr;
     double* d_mom = nullptr;           // [box][N][kMomStride]: per-molecule moments (k_model_energy's by-product) for the single-move kernel's moment path
     int mom_first = 0, mom_count = 0;  // the boxes whose moments the LAST full-box launch left valid (cleared by everything that may move a molecule)
+    int swm_first = 0, swm_count = 0;  // the boxes (1-based first) whose moments in d_mom the Monte Carlo driver keeps current from launch to launch
+                                       // (walkers in global memory): cleared by every entry point that writes positions or cells behind the driver's back
     int m_boxlo = 0, m_boxhi = -1, m_minreq = 0;   // the uploaded requests: their boxes (0-based range) and the fewest requests any of them has
     double* d_ivect = nullptr;
     int* d_nivect = nullptr;
@@ -417,7 +419,7 @@ int launch_model_energy(int first, int count, bool with_mom = false, bool write_
                            g.d_nivect, g.d_list, g.d_order, g.d_nns, g.d_cmax, g.d_partial, g.d_cpartial, g.d_energy, g.d_counts, g.N, g.S, g.ivcap, box0, ge.nsplit, ge.chunk, count,
                            mom, wen);
     HIPCHK(hipGetLastError());
-    if (mom) { g.mom_first = first; g.mom_count = count; }
+    if (mom) { g.mom_first = first; g.mom_count = count; g.swm_count = 0; }   // (d_mom rewritten for these boxes: the driver's claim on it ends -- its launch renews it)
     if (ge.nsplit > 1 && write_energy) {           // split boxes: the partials of box b live at [b*nsplit .. b*nsplit+nsplit); unsplit boxes wrote their energy themselves
         hipLaunchKernelGGL(mw::k_sum_partials, dim3(count), dim3(64), 0, g.stream, g.d_partial, g.d_cpartial,
                            g.d_energy, g.d_counts, box0, count, ge.nsplit);
@@ -881,6 +883,7 @@ static int set_cells_impl(int first_ils, int count, const double* h, int* nivect
 
 int mw_set_cell(int ils, const double h[9], int* nivect_out)
 {
+    g.swm_count = 0;
     MW_LOCK;
     if (check_live() || check_box(ils)) return 1;
     if (!h) return fail("mw_set_cell: null pointer");
@@ -889,6 +892,7 @@ int mw_set_cell(int ils, const double h[9], int* nivect_out)
 
 int mw_set_cells_range(int first_ils, int count, const double* h, int* nivect_out)
 {
+    g.swm_count = 0;
     MW_LOCK;
     if (check_live() || check_range(first_ils, count)) return 1;
     if (!h) return fail("mw_set_cells_range: null pointer");
@@ -910,6 +914,7 @@ int mw_get_ivects(int ils, double* out, int max_vectors, int* nivect_out)
 
 int mw_upload_positions(int ils, const double* xyz)
 {
+    g.swm_count = 0;
     MW_LOCK;
     if (check_live() || check_box(ils)) return 1;
     if (!xyz) return fail("mw_upload_positions: null pointer");
@@ -931,6 +936,7 @@ int mw_download_positions(int ils, double* xyz)
 
 int mw_upload_positions_range(int first_ils, int count, const double* xyz)
 {
+    g.swm_count = 0;
     MW_LOCK;
     if (check_live() || check_range(first_ils, count)) return 1;
     if (!xyz) return fail("mw_upload_positions_range: null pointer");
@@ -952,6 +958,7 @@ int mw_download_positions_range(int first_ils, int count, double* xyz)
 
 int mw_patch_position(int ils, int imol, const double r[3])
 {
+    g.swm_count = 0;
     MW_LOCK;
     if (check_live() || check_box(ils) || check_mol(imol)) return 1;
     HIPCHK(hipMemcpyAsync(g.d_pos + ((size_t)(ils - 1) * g.N + (imol - 1)) * 3, r, 3 * sizeof(double), hipMemcpyHostToDevice, g.stream));
@@ -1056,6 +1063,7 @@ int mw_model_energy(int ils, double* e) { return mw_model_energy_batch(ils, 1, e
 // memory, one synchronisation at the end.
 int mw_model_energy_of(int ils, const double* xyz, double* e)
 {
+    g.swm_count = 0;
     MW_LOCK;
     if (check_live() || check_box(ils)) return 1;
     if (!xyz || !e) return fail("mw_model_energy_of: null pointer");
@@ -1095,6 +1103,7 @@ static int server_start_locked()
     // The server's moment path (k_local_server): every molecule's moments of every box, from the full-box kernel, and the positions
     // they belong to -- made HERE, each time the server starts (every entry point that may move a molecule stops it first).  For the
     // drop-in's handful of boxes (a farm's thousands are not served one call at a time); MW_SERVER_MOMENTS=0: off.
+    g.swm_count = 0;                     // (single calls patch positions)
     static const bool srvmom = !(std::getenv("MW_SERVER_MOMENTS") && std::getenv("MW_SERVER_MOMENTS")[0] == '0');
     double* mom = nullptr;
     if (srvmom && g.nbox <= 64 && model_geo(g.nbox).lds && g.list_version > 1) {
@@ -1250,6 +1259,7 @@ int mw_local_energy_patched(int ils, int imol, const double r_imol[3], int imol_
     MW_LOCK;
     if (check_live() || check_box(ils) || check_mol(imol)) return 1;
     if (o2.idx >= g.N) return fail("mw: molecule index %d outside 1..%d", o2.idx + 1, g.N);
+    g.swm_count = 0;                     // (the call commits its positions)
     const unsigned long long seq = ++g.pin_seq;
     hipLaunchKernelGGL(mw::k_local_energy_single, dim3(1), dim3(64), 0, g.stream, g.d_pos, g.d_ivect, g.d_listm, g.d_nn,
                        ils - 1, imol - 1, o1, o2, 1, g.d_pin, g.N, g.ivcap,
@@ -2169,6 +2179,25 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
     double* wmom = nullptr;
     {
         const char* e = getenv("MW_SWEEP_MOMENTS");
+        const int box_first = (first_walker - 1) * L + 1, nboxes = count * L;          // 1-based
+        // (for launches that fill the chip -- two lattices' worth of wavefronts per compute unit and up: +26 % on 2048 x 4096 molecules and
+        //  on 2048 x 1536 pairs; a handful of such walkers, whose speed is one chain's, lose 4-12 % to the moments' global round trips.
+        //  By the NUMBER of walkers, not by the look-ahead chosen for them: a launch's chain must not depend on its look-ahead.
+        //  MW_SWEEP_MOMENTS=2 forces the path -- the tests', to hold it to the oracle and to itself across look-aheads on a few walkers)
+        if (!ldslist && !withvol && !(e && e[0] == '0') && model_geo(nboxes).lds && g.N >= 128 && (nboxes >= 2 * g.cu || (e && e[0] == '2'))) {
+            // walkers in global memory, translations only: the engine's own moments, made by the full-box kernel where the driver's
+            // earlier launches have not kept them (its `MOMOUT` build: boxes that fit LDS), current afterwards for as long as nothing
+            // else writes positions or cells (swm_first / swm_count)
+            const bool current = g.d_mom && g.swm_count > 0 && g.swm_first <= box_first && box_first + nboxes <= g.swm_first + g.swm_count;
+            if (!current) {
+                if (launch_model_energy(box_first, nboxes, true, false)) return 1;
+                g.mom_count = 0;                                   // (about to change under the batch kernels' feet)
+            }
+            g.swm_first = current ? g.swm_first : box_first; g.swm_count = current ? g.swm_count : nboxes;
+            wmom = g.d_mom + (size_t)(box_first - 1) * g.N * mw::kMomStride;
+        } else {
+            g.swm_count = 0;                                       // (this launch moves molecules without keeping d_mom)
+        }
         if (ldslist && !(e && e[0] == '0')) {
             const size_t need = (size_t)count * 2 * L * g.N * mw::kMomStride;
             if (need > g.wmom_cap) {

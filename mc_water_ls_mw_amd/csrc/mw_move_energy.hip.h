@@ -2,6 +2,7 @@
 // compute_local_real_energy (molint.F90:220-404) and the fused old/new evaluation of a trial move:
 // local_energy_wave, move_energy_wave, k_move_energy, k_local_energy_single.
 #pragma once
+#include <type_traits>
 
 #include "mw_common.hip.h"
 
@@ -611,13 +612,18 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
 // WHEN the moments are asked for: 1 = once the in-range entries are known (a 96-byte read per in-range neighbour and geometry); 0 =
 // after the pair terms (see below); 2 = WITH the positions, for every row entry whether in range or not -- one dependent load level
 // fewer, which is what a lone wavefront reading global memory pays for (the resident server: ~0.5 us a level).
+// `geo_r2` > 0 (look-ahead of walkers with more than 64 molecules, where a row's molecules do not fit a bit mask): dependence by
+// DISTANCE -- this evaluation reads positions within the list radius of i and moments of molecules within the cutoff of i, which
+// hold molecules within the cutoff of THOSE: everything it reads lies within two cutoffs (+ the two displacements) of i.  An earlier
+// slot's molecule whose nearest image (lane = image vector, `niv` of them) is farther than sqrt(geo_r2) from i cannot matter; one
+// that is closer is taken to (a superset of the true dependences: in a 4096-molecule box one pair of moves in twelve).
 template <bool SWEEP = false, int NOTH = 0, int WHEN = (SWEEP && NOTH == 0) ? 0 : 1, typename PosFn, typename IvFn, typename NnFn>
 __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, NnFn nnof, const double* __restrict__ MOM,
                                                      WaveScratch* __restrict__ ws, const unsigned short* __restrict__ ptab, int i, int n_i, uint32_t e,
                                                      double xo, double yo, double zo, double xn, double yn, double zn,
                                                      int lane, MoveRes& res, unsigned int (&acc)[4], int* cnt_u = nullptr,
                                                      const unsigned long long* __restrict__ lmask = nullptr, const int* oth = nullptr,
-                                                     unsigned* cmask = nullptr)
+                                                     unsigned* cmask = nullptr, double geo_r2 = 0.0, int niv = 0)
 {
     // ---- pass 0: as move_energy_wave -- lanes 0..31 slot l of i's row against the OLD position, lanes 32..63 against the TRIAL one
 #ifdef MW_SWEEP_STAMPS
@@ -632,8 +638,20 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
     if (SWEEP && __ballot(has && j == i) != 0ull) { MW_MOM_WHY(1); return false; }
     unsigned cm = 0u;
     if constexpr (NOTH > 0) {
+        if (lmask != nullptr) {
 #pragma unroll
-        for (int o = 0; o < NOTH; ++o) cm |= (has && j == oth[o]) ? 1u << o : 0u;
+            for (int o = 0; o < NOTH; ++o) cm |= (has && j == oth[o]) ? 1u << o : 0u;
+        } else {
+            double ivx, ivy, ivz;
+            getiv(lane < niv ? lane : 0, ivx, ivy, ivz);
+#pragma unroll
+            for (int o = 0; o < NOTH; ++o) {
+                double ox, oy, oz;
+                getpos(oth[o] >= 0 ? oth[o] : i, ox, oy, oz);
+                const double dx = (ox + ivx) - xo, dy = (oy + ivy) - yo, dz = (oz + ivz) - zo;
+                cm |= (oth[o] >= 0 && lane < niv && dx * dx + dy * dy + dz * dz < geo_r2) ? 1u << o : 0u;
+            }
+        }
     }
     double xj, yj, zj, jvx, jvy, jvz;
     double M[10];
@@ -645,7 +663,7 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
     getpos(j, xj, yj, zj);
     getiv(kimg, jvx, jvy, jvz);
     [[maybe_unused]] unsigned long long lmj = 0ull;
-    if constexpr (NOTH > 0) lmj = lmask[j];
+    if constexpr (NOTH > 0) lmj = lmask != nullptr ? lmask[j] : 0ull;
     const int nnj = (has && !SWEEP) ? nnof(j) : 0;
     const double qx = xj + jvx, qy = yj + jvy, qz = zj + jvz;                 // molint.F90:269
     const double rix = half ? xn : xo, riy = half ? yn : yo, riz = half ? zn : zo;

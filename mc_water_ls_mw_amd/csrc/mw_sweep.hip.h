@@ -285,7 +285,8 @@ __device__ __forceinline__ double dev_wave_model_energy(const VolCtx& c, int l, 
         int n_next = 0, mol_next = 0;
         if (tn < c.N) { col_next = (uint32_t)tn * 4u; n_next = NNS[tn]; mol_next = ORD[tn]; }
         const int cm = __builtin_amdgcn_readfirstlane(CM[base >> 6]);
-        AtomSum a = atom_energy<64, false, true, kSweepQCap>(rs, col, col_next, mol, act ? (n_cur & 0xff) : 0, cm & 0xff, cm >> 8, c.N, c.S, c.queue, getpos, getiv, cur);
+        AtomSum a = atom_energy<64, false, true, kSweepQCap>(rs, col, col_next, mol, act ? (n_cur & 0xff) : 0, cm & 0xff, cm >> 8, c.N, c.S, c.queue, getpos, getiv, cur,
+                                                             (mom_l && act) ? mom_l + (size_t)mol * kMomStride : nullptr);
         if (act) esum += a.e;
         n_cur = n_next; mol = mol_next; col = col_next;
     }
@@ -787,7 +788,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         // mc_cycle_num of the next move and its place inside the cycle ('dd' only: the equilibration rules, :181-210)
         C.cyc = sp.dd ? (int)(move0 / (unsigned long long)N) + 1 : 0;
         C.within = sp.dd ? (int)(move0 % (unsigned long long)N) : 0;
-        sdec[2] = sdec[3] = (LDSLIST && wmom) ? 1 : 0;                        // (moment path: lattice l's moments are to be made, see the move loop)
+        sdec[2] = sdec[3] = (LDSLIST && wmom) ? 1 : 0;                        // (moment path of walkers in LDS: lattice l's moments are to be made, see the move loop)
     }
     __syncthreads();
     if constexpr (MOMLDS) {
@@ -1009,7 +1010,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         // (bit 31 of an evaluation's dependence word -- the moment path declined it -- ends the round BEFORE that move; the next round
         //  finds it in slot 0 and decides nothing else)
         unsigned accmask = 0x80000000u;
-        if constexpr (MOMLDS) { if (((scm[0] | (NLAT == 2 ? scm[1] : 0u)) >> 31) != 0u) ntr = 1; }
+        if constexpr (SPEC > 1) { if (((scm[0] | (NLAT == 2 ? scm[1] : 0u)) >> 31) != 0u) ntr = 1; }
         int nvalid = 0;
         // the walker's state, in registers for the length of the round
         double bk0 = C.men0, bk1 = L == 2 ? C.men1 : 0.0;                         // :1013
@@ -1446,17 +1447,22 @@ void k_sweep(double* pos, double* hmat, double* ivect,
     // wavefront when sdec[2 + lattice] says so (the launch's start; an accepted move whose evaluation took another routine),
     // brought up to date by every accepted move (moments_commit), and for a volume move written for the TRIAL cell into the
     // other half of the buffer, which an accepted move makes the current one (msel, the same in every wavefront).
-    const bool usemom = LDSLIST && wmom != nullptr;
+    // Walkers in global memory (N > 64), translations only: the moments are the engine's own array (`wmom` = its part for this
+    // launch's boxes, [box][N][kMomStride]: made by the full-box kernel before the launch where they are not current, kept current here
+    // and by nobody else -- mw_sweep_translation_launch); no trial set, no start-up pass.
+    constexpr bool MOMBIG = !LDSLIST && !WITHVOL;
+    const bool usemom = (LDSLIST || MOMBIG) && wmom != nullptr;
     int msel = 0;
     auto mom_of = [&](int sel, int l) -> double* {
         if constexpr (MOMLDS) return smom + (size_t)((sel * L + l) * N) * kMomStride;
-        else return wmom + ((((size_t)blockIdx.x * 2 + sel) * L + l) * N) * kMomStride;
+        else if constexpr (LDSLIST) return wmom + ((((size_t)blockIdx.x * 2 + sel) * L + l) * N) * kMomStride;
+        else return wmom + (((size_t)blockIdx.x * L + l) * N) * kMomStride;
     };
 
     constexpr int kUB = sweep_batch(WITHVOL, SPEC);
     int mv = 0, ubase = -kUB;                    // next move of the chain (counted within the launch); first move of the uniforms' window
     while (mv < nmoves) {
-        if constexpr (LDSLIST) {
+        if constexpr (LDSLIST || MOMBIG) {
             if (usemom && (SPEC > 1 ? (sdec[2] | (L == 2 ? sdec[3] : 0)) : sdec[2 + lat]) != 0) {       // (the same in every wavefront that waits below)
                 if (slot == 0 && sdec[2 + lat] != 0) {
                     int lv = lane, bv = box0;
@@ -1464,8 +1470,11 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                     VolCtx vm;
                     vm.pos_g = pos + (size_t)bv * N * 3; vm.spos = spos; vm.siv = siv; vm.sniv = sniv;
                     vm.queue = reinterpret_cast<uint32_t*>(ws) + lv; vm.N = N; vm.S = S; vm.ivcap = ivcap; vm.L = L;
-                    vm.srow = srow; vm.snn = snn; vm.rstride = rstride; vm.mom_trial = nullptr; vm.inmask = nullptr; vm.rec = nullptr;
-                    (void)dev_wave_model_energy<true>(vm, lat, lv, mom_of(msel, lat));
+                    vm.srow = LDSLIST ? srow : nullptr; vm.snn = LDSLIST ? snn : nullptr; vm.rstride = rstride;
+                    vm.list_g = list + (size_t)bv * S * N; vm.order_g = order + (size_t)bv * N; vm.nns_g = nns + (size_t)bv * N;
+                    vm.cmax_g = cmax + (size_t)bv * ((N + 63) >> 6);
+                    vm.mom_trial = nullptr; vm.inmask = nullptr; vm.rec = nullptr;
+                    (void)dev_wave_model_energy<LDSPOS>(vm, lat, lv, mom_of(msel, lat));       // (4096 molecules: half a millisecond -- for a move the moment path declined AND the chain accepted)
                 }
                 if (SPEC > 1) wg_sync<NW>(); else wave_sync();
                 if (SPEC > 1) { if (tid == 0) { sdec[2] = 0; sdec[3] = 0; } }
@@ -1698,6 +1707,17 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                                                                  pnx, pny, pnz, lane, res, nocounts, &ecnt, slmask + l * N, oth, &cme);
                     if (fast) ekind = 0;
                 }
+            } else if constexpr (MOMBIG) {
+                if (usemom) {
+                    unsigned int nocounts[4];
+                    // (two cutoffs + both molecules' largest displacement -- doubled: the partner lattice's image of a displacement,
+                    //  mapped through fractional coordinates, is longer or shorter by the ratio of the two cells)
+                    const double reach = 2.0 * (kSmallA * kSigma) + 4.0 * C.max_trans + 1e-6;
+                    const double geo_r2 = reach * reach;
+                    fast = move_energy_mom_wave<true, SPEC - 1>(getpos, getiv, nnof, mom_of(0, l), ws, nullptr, i, nnof(i), row(i, lane & 31), xo, yo, zo,
+                                                                 pnx, pny, pnz, lane, res, nocounts, &ecnt, nullptr, oth, &cme, geo_r2, sniv[l]);
+                    if (fast) ekind = 0;
+                }
             }
             if (usemom && !fast) MW_SW_ACC(43, 1ull);                   // (stamps build: evaluations the moment path declined)
             if (!fast) fast = move_energy_wave<true, SPEC - 1, false>(getpos, getiv, row, nnof, ws, sniv[l], i, nnof(i), row(i, lane & 31), xo, yo, zo,
@@ -1731,14 +1751,14 @@ void k_sweep(double* pos, double* hmat, double* ivect,
         ls = sdec[1];
         const bool okm = mine && slot < nvalid && sdec[4 + slot] != 0;
         double cxo = 0.0, cyo = 0.0, czo = 0.0;                                        // (the old position, read back rather than held through the decisions)
-        if constexpr (LDSLIST) {
-            if (usemom && okm && ekind == 0) { const double* Sp = spos + ((size_t)l * N + i) * 3; cxo = Sp[0]; cyo = Sp[1]; czo = Sp[2]; }
+        if constexpr (LDSLIST || MOMBIG) {
+            if (usemom && okm && ekind == 0) { const double* Sp = LDSPOS ? spos + ((size_t)l * N + i) * 3 : P + 3 * (size_t)i; cxo = Sp[0]; cyo = Sp[1]; czo = Sp[2]; }
         }
         if (okm && lane == 0) {                                                       // :1150-1170: this wavefront's lattice
             P[3 * i] = pnx; P[3 * i + 1] = pny; P[3 * i + 2] = pnz;
             if (LDSPOS) { double* Sp = spos + ((size_t)l * N + i) * 3; Sp[0] = pnx; Sp[1] = pny; Sp[2] = pnz; }
         }
-        if constexpr (LDSLIST) {
+        if constexpr (LDSLIST || MOMBIG) {
             if (usemom && okm) {
                 if (ekind == 0) moments_commit(mom_of(msel, l), ws, i, ecnt, cxo, cyo, czo, pnx, pny, pnz, lane);
                 else if (lane == 0) sdec[2 + l] = 1;               // (made afresh from the committed positions at the top of the next round)

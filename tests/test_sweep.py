@@ -636,7 +636,7 @@ def test_random_single_box_walkers_follow_the_oracle(seed, so):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["pair48_wl", "pair48_npt", "thin24", "ih64_npt"])
+@pytest.mark.parametrize("case", ["pair48_wl", "pair48_npt", "thin24", "ih64_npt", "ih288", "pair768_wl"])
 @pytest.mark.parametrize("ahead", [1, 4])
 def test_moment_path_of_the_driver_is_the_row_scan(case, ahead, monkeypatch):
     """Walkers entirely in LDS take the i--j--k sums of a translation from per-molecule moments (move_energy_mom_wave,
@@ -647,20 +647,29 @@ def test_moment_path_of_the_driver_is_the_row_scan(case, ahead, monkeypatch):
     from mc_water_ls_mw_amd import lattice as lat
     from mc_water_ls_mw_amd.sweep import MuGrid
 
+    big = case in ("ih288", "pair768_wl")       # walkers with their rows (and, 768, their positions) in global memory: translations only, the
+                                                # engine's own moment array kept current by the driver; forced on here ("2": a few walkers)
+
     def run(moments):
-        monkeypatch.setenv("MW_SWEEP_MOMENTS", moments)
+        monkeypatch.setenv("MW_SWEEP_MOMENTS", "2" if (big and moments == "1") else moments)
         monkeypatch.setenv("MW_SWEEP_AHEAD", str(ahead))
-        nlat = 2 if case.startswith("pair48") else 1
+        nlat = 2 if case.startswith("pair") else 1
         if nlat == 2:
             z1, z2 = load_golden("ic48"), load_golden("ih48")
+            reps = (2, 2, 4) if big else (1, 1, 1)
             boxes = []
             for w in range(3):
-                boxes += [(z1["h"], lat.thermalise(z1["xyz"], 0.05, 40 + w)), (z2["h"], lat.thermalise(z2["xyz"], 0.05, 60 + w))]
-            em, farm = _farm(boxes, 2, 200.0, 1.1, grid=MuGrid(101, -400.0, 400.0), weight=np.zeros(101))
+                for l, z in enumerate((z1, z2)):
+                    h, x = lat.replicate(z["h"], z["xyz"], reps)
+                    boxes.append((h, lat.thermalise(x, 0.05, 40 + 20 * l + w)))
+            mu = 6000.0 if big else 400.0
+            em, farm = _farm(boxes, 2, 200.0, 1.1, grid=MuGrid(101, -mu, mu), weight=np.zeros(101))
             farm.options(record=True, samplerun=False, always_switch=True, npt=case.endswith("_npt"), wl_factor=0.05)
         else:
             if case == "thin24":
                 h, x0 = lat.replicate(*lat.ice_ic_cell(2.63), (1, 3, 1))          # 6.07 x 18.2 x 6.07 A, 24 molecules
+            elif case == "ih288":
+                h, x0 = lat.ice_box("ih", (3, 4, 3), 0.0)
             else:
                 h, x0 = lat.ice_box("ih", (2, 2, 2), 0.0)
             boxes = [(h, lat.thermalise(x0, 0.1, 300 + w)) for w in range(3)]
@@ -700,6 +709,10 @@ def test_lookahead_is_the_sequential_chain(case, monkeypatch):
     switches and Wang-Landau updates in between, and with volume moves cutting the rounds short."""
     from mc_water_ls_mw_amd import lattice as lat
     from mc_water_ls_mw_amd.sweep import MuGrid
+
+    # (walkers in global memory take the moment path when the launch fills the chip: forced on for these few walkers -- the look-ahead's
+    #  dependence test by distance is then what is held to the sequential chain; with volume moves it is off by construction)
+    monkeypatch.setenv("MW_SWEEP_MOMENTS", "2")
 
     def run(ahead):
         monkeypatch.setenv("MW_SWEEP_AHEAD", str(ahead))
