@@ -95,6 +95,7 @@ struct Ctx {
     int cstride = 0;
     std::vector<mw::GridDesc> h_grid;
     std::vector<int> h_usegrid;
+    std::vector<char> h_listbuilt;     // per box: a neighbour list has been built (the full-box kernel may be run over it)
     int last_sweep[6] = {0, 0, 0, 0, 0, 0};   // what the last launch of the driver was: lattices, look-ahead, residency, volume moves, LDS bytes, row stride
     bool grid_on_device = false;   // some box of this context has (had) a cell grid: descriptors travel with mw_sweep_sync_cells
     bool force_brute = false;
@@ -434,6 +435,7 @@ int launch_build(int first, int count)
 {
     const int box0 = first - 1;
     ++g.list_version;
+    for (int b = box0; b < box0 + count; ++b) g.h_listbuilt[(size_t)b] = 1;
     int ngrid = 0;
     for (int b = box0; b < box0 + count; ++b) ngrid += g.h_usegrid[b] ? 1 : 0;
     const bool fused_sort = ngrid > 0 && g.sort_in_lds && !g.legacy_search;       // k_cell_sort_box resets the statistics itself
@@ -717,6 +719,7 @@ static int init_impl(int device, int nwater, int nboxes, int maxneigh)
     g.h_grid.assign(nb, mw::GridDesc());
     for (auto& G : g.h_grid) std::memset(&G, 0, sizeof G);
     g.h_usegrid.assign(nb, 0);
+    g.h_listbuilt.assign(nb, 0);
     { const char* fb = std::getenv("MW_FORCE_BRUTE_NEIGHBOURS"); g.force_brute = fb && *fb && *fb != '0'; }
     HIPCHK(hipMalloc(&g.d_partial, nb * g.nsplit_max * sizeof(double)));
     HIPCHK(hipMalloc(&g.d_cpartial, nb * g.nsplit_max * 2 * sizeof(unsigned long long)));
@@ -1106,7 +1109,9 @@ static int server_start_locked()
     g.swm_count = 0;                     // (single calls patch positions)
     static const bool srvmom = !(std::getenv("MW_SERVER_MOMENTS") && std::getenv("MW_SERVER_MOMENTS")[0] == '0');
     double* mom = nullptr;
-    if (srvmom && g.nbox <= 64 && model_geo(g.nbox).lds && g.list_version > 1) {
+    bool allbuilt = true;                // (the full-box kernel over a box that never had a list would follow whatever its arrays hold)
+    for (char c : g.h_listbuilt) allbuilt = allbuilt && c != 0;
+    if (srvmom && g.nbox <= 64 && model_geo(g.nbox).lds && allbuilt) {
         bool okm = launch_model_energy(1, g.nbox, true, false) == 0 && g.d_mom != nullptr;
         if (okm && !g.d_pm) okm = hipMalloc(&g.d_pm, (size_t)g.nbox * g.N * 3 * sizeof(double)) == hipSuccess;
         if (okm && !g.d_srvmomok) okm = hipMalloc(&g.d_srvmomok, (size_t)g.nbox * sizeof(int)) == hipSuccess;
