@@ -612,18 +612,15 @@ __device__ __forceinline__ bool move_energy_wave(PosFn getpos, IvFn getiv, RowFn
 // WHEN the moments are asked for: 1 = once the in-range entries are known (a 96-byte read per in-range neighbour and geometry); 0 =
 // after the pair terms (see below); 2 = WITH the positions, for every row entry whether in range or not -- one dependent load level
 // fewer, which is what a lone wavefront reading global memory pays for (the resident server: ~0.5 us a level).
-// `geo_r2` > 0 (look-ahead of walkers with more than 64 molecules, where a row's molecules do not fit a bit mask): dependence by
-// DISTANCE -- this evaluation reads positions within the list radius of i and moments of molecules within the cutoff of i, which
-// hold molecules within the cutoff of THOSE: everything it reads lies within two cutoffs (+ the two displacements) of i.  An earlier
-// slot's molecule whose nearest image (lane = image vector, `niv` of them) is farther than sqrt(geo_r2) from i cannot matter; one
-// that is closer is taken to (a superset of the true dependences: in a 4096-molecule box one pair of moves in twelve).
+// `lmask` == nullptr with NOTH > 0 (walkers with more than 64 molecules, where a row's molecules do not fit a bit mask): no dependence
+// test in here -- the caller decides by distance (mw_sweep.hip.h) and `cmask` comes back 0.
 template <bool SWEEP = false, int NOTH = 0, int WHEN = (SWEEP && NOTH == 0) ? 0 : 1, typename PosFn, typename IvFn, typename NnFn>
 __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, NnFn nnof, const double* __restrict__ MOM,
                                                      WaveScratch* __restrict__ ws, const unsigned short* __restrict__ ptab, int i, int n_i, uint32_t e,
                                                      double xo, double yo, double zo, double xn, double yn, double zn,
                                                      int lane, MoveRes& res, unsigned int (&acc)[4], int* cnt_u = nullptr,
                                                      const unsigned long long* __restrict__ lmask = nullptr, const int* oth = nullptr,
-                                                     unsigned* cmask = nullptr, double geo_r2 = 0.0, int niv = 0)
+                                                     unsigned* cmask = nullptr)
 {
     // ---- pass 0: as move_energy_wave -- lanes 0..31 slot l of i's row against the OLD position, lanes 32..63 against the TRIAL one
 #ifdef MW_SWEEP_STAMPS
@@ -641,16 +638,6 @@ __device__ __forceinline__ bool move_energy_mom_wave(PosFn getpos, IvFn getiv, N
         if (lmask != nullptr) {
 #pragma unroll
             for (int o = 0; o < NOTH; ++o) cm |= (has && j == oth[o]) ? 1u << o : 0u;
-        } else {
-            double ivx, ivy, ivz;
-            getiv(lane < niv ? lane : 0, ivx, ivy, ivz);
-#pragma unroll
-            for (int o = 0; o < NOTH; ++o) {
-                double ox, oy, oz;
-                getpos(oth[o] >= 0 ? oth[o] : i, ox, oy, oz);
-                const double dx = (ox + ivx) - xo, dy = (oy + ivy) - yo, dz = (oz + ivz) - zo;
-                cm |= (oth[o] >= 0 && lane < niv && dx * dx + dy * dy + dz * dz < geo_r2) ? 1u << o : 0u;
-            }
         }
     }
     double xj, yj, zj, jvx, jvy, jvz;

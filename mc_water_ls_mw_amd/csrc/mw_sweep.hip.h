@@ -1710,12 +1710,45 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             } else if constexpr (MOMBIG) {
                 if (usemom) {
                     unsigned int nocounts[4];
-                    // (two cutoffs + both molecules' largest displacement -- doubled: the partner lattice's image of a displacement,
-                    //  mapped through fractional coordinates, is longer or shorter by the ratio of the two cells)
-                    const double reach = 2.0 * (kSmallA * kSigma) + 4.0 * C.max_trans + 1e-6;
-                    const double geo_r2 = reach * reach;
+                    if constexpr (SPEC > 1) {
+                        // Look-ahead: which earlier moves of the round this evaluation depends on, by DISTANCE.  It reads positions within
+                        // the list radius of i and moments of molecules within the cutoff of i, which hold molecules within the cutoff of
+                        // THOSE: everything lies within two cutoffs + the displacements of i (doubled: the partner lattice's image of a
+                        // displacement, mapped through fractional coordinates, is longer or shorter by the ratio of the two cells).  The
+                        // NEAREST image of the earlier molecule, by rounding the fractional separation -- exact whenever that image is
+                        // closer than half the cell's narrowest width, however far the unwrapped positions have drifted apart; in a cell
+                        // narrower than twice the reach every earlier move counts.  A superset of the true dependences (in a
+                        // 4096-molecule box one pair of moves in twelve).
+                        const double reach = 2.0 * (kSmallA * kSigma) + 4.0 * C.max_trans + 1e-6;
+                        const double* rc = srecip[l];
+                        const double* hn = shmat[l];
+                        double wmin2i = 0.0;                                   // 1 / (narrowest width)^2 = max |column of recip|^2 / (2 pi)^2
+#pragma unroll
+                        for (int k = 1; k <= 3; ++k) {
+                            const double n2 = MW_HM(rc,1,k) * MW_HM(rc,1,k) + MW_HM(rc,2,k) * MW_HM(rc,2,k) + MW_HM(rc,3,k) * MW_HM(rc,3,k);
+                            wmin2i = n2 > wmin2i ? n2 : wmin2i;
+                        }
+                        wmin2i = wmin2i * (0.25 * invPi * invPi);
+                        const bool wide = 4.0 * reach * reach * wmin2i < 1.0;    // narrowest width > 2 reach
+#pragma unroll
+                        for (int o = 0; o < SPEC - 1; ++o) {
+                            if (oth[o] >= 0) {
+                                double ox, oy, oz;
+                                getpos(oth[o], ox, oy, oz);
+                                const double dx = ox - xo, dy = oy - yo, dz = oz - zo;
+                                double fx = (MW_HM(rc,1,1) * dx + MW_HM(rc,2,1) * dy + MW_HM(rc,3,1) * dz) * (0.5 * invPi);
+                                double fy = (MW_HM(rc,1,2) * dx + MW_HM(rc,2,2) * dy + MW_HM(rc,3,2) * dz) * (0.5 * invPi);
+                                double fz = (MW_HM(rc,1,3) * dx + MW_HM(rc,2,3) * dy + MW_HM(rc,3,3) * dz) * (0.5 * invPi);
+                                fx -= __builtin_rint(fx); fy -= __builtin_rint(fy); fz -= __builtin_rint(fz);
+                                const double mx = MW_HM(hn,1,1) * fx + MW_HM(hn,1,2) * fy + MW_HM(hn,1,3) * fz;
+                                const double my = MW_HM(hn,2,1) * fx + MW_HM(hn,2,2) * fy + MW_HM(hn,2,3) * fz;
+                                const double mz = MW_HM(hn,3,1) * fx + MW_HM(hn,3,2) * fy + MW_HM(hn,3,3) * fz;
+                                if (!wide || mx * mx + my * my + mz * mz < reach * reach) cm |= 1u << o;
+                            }
+                        }
+                    }
                     fast = move_energy_mom_wave<true, SPEC - 1>(getpos, getiv, nnof, mom_of(0, l), ws, nullptr, i, nnof(i), row(i, lane & 31), xo, yo, zo,
-                                                                 pnx, pny, pnz, lane, res, nocounts, &ecnt, nullptr, oth, &cme, geo_r2, sniv[l]);
+                                                                 pnx, pny, pnz, lane, res, nocounts, &ecnt, nullptr, oth, &cme);
                     if (fast) ekind = 0;
                 }
             }
