@@ -2185,11 +2185,12 @@ int mw_sweep_translation_launch(int first_walker, int count, int nmoves, unsigne
     {
         const char* e = getenv("MW_SWEEP_MOMENTS");
         const int box_first = (first_walker - 1) * L + 1, nboxes = count * L;          // 1-based
-        // (for launches that fill the chip -- two lattices' worth of wavefronts per compute unit and up: +26 % on 2048 x 4096 molecules and
-        //  on 2048 x 1536 pairs; a handful of such walkers, whose speed is one chain's, lose 4-12 % to the moments' global round trips.
+        // (for launches that fill the chip -- four lattices per compute unit and up: 4096-molecule boxes x 512 / 1024 / 2048 walkers
+        //  -12 / +4 / +25 %, 2048 x 1536 pairs +22 %; fewer walkers run their chains with look-ahead, where every moment is a global
+        //  round trip on a chain's critical path.
         //  By the NUMBER of walkers, not by the look-ahead chosen for them: a launch's chain must not depend on its look-ahead.
         //  MW_SWEEP_MOMENTS=2 forces the path -- the tests', to hold it to the oracle and to itself across look-aheads on a few walkers)
-        if (!ldslist && !withvol && !(e && e[0] == '0') && model_geo(nboxes).lds && g.N >= 128 && (nboxes >= 2 * g.cu || (e && e[0] == '2'))) {
+        if (!ldslist && !withvol && !(e && e[0] == '0') && model_geo(nboxes).lds && g.N >= 128 && (nboxes >= 4 * g.cu || (e && e[0] == '2'))) {
             // walkers in global memory, translations only: the engine's own moments, made by the full-box kernel where the driver's
             // earlier launches have not kept them (its `MOMOUT` build: boxes that fit LDS), current afterwards for as long as nothing
             // else writes positions or cells (swm_first / swm_count)

@@ -115,6 +115,8 @@ if only in ("few4096",):
     run("ih4096 x 64 walkers", [(h, x)], 1, 64, 600, out)
 if only in ("many4096",):   # more walkers than four wavefronts per SIMD hold: what a fifth (<= 96 VGPRs) is worth
     run("ih4096 x 6144 walkers", [(h, x)], 1, 6144, 200, out)
+if only is not None and only.startswith("n4096_"):          # n4096_<walkers>: where the moment path of walkers in global memory starts to pay
+    run(f"ih4096 x {int(only.split('_')[1])} walkers", [(h, x)], 1, int(only.split("_")[1]), 300, out)
 if only in ("one4096",):
     run("ih4096 x 1 walker", [(h, x)], 1, 1, 2000, out)
 if only in ("one1536",):
