@@ -134,6 +134,9 @@ __device__ __forceinline__ void dev_recipmatrix(const double* __restrict__ h, do
 #define MW_SW_ACC(k, d) do { } while (0)
 #endif
 
+#ifndef MW_BIG_WHEN
+#define MW_BIG_WHEN ((SPEC > 1) ? 1 : 0)      // when the moments of walkers in global memory are asked for (move_energy_mom_wave: WHEN)
+#endif
 constexpr int kSweepQCap = 9;                             // in-range queue of a volume move's full-box energy: sized to fit the scratch record
 // -------------------------------------------------------------------------------------
 // Volume move of one walker by its wavefront: mc_volume (mc_moves.F90:1216-1534; ref_ljr,
@@ -1747,7 +1750,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                             }
                         }
                     }
-                    fast = move_energy_mom_wave<true, SPEC - 1>(getpos, getiv, nnof, mom_of(0, l), ws, nullptr, i, nnof(i), row(i, lane & 31), xo, yo, zo,
+                    fast = move_energy_mom_wave<true, SPEC - 1, MW_BIG_WHEN>(getpos, getiv, nnof, mom_of(0, l), ws, nullptr, i, nnof(i), row(i, lane & 31), xo, yo, zo,
                                                                  pnx, pny, pnz, lane, res, nocounts, &ecnt, nullptr, oth, &cme);
                     if (fast) ekind = 0;
                 }
