@@ -934,6 +934,9 @@ constexpr int kMoveChunk = 2048;   // requests per work item when the box is sta
 // (LAYOUT: SoA measures 1.4 % faster than the paired layout here -- 1288 vs 1306 us, tools/kbench -- now that the scan
 // reads one vector less per slot; the full-box kernel keeps the paired layout, where it is the faster one)
 // MOMPATH = true (with LDSPOS, SELFIMG = false): the moment path above; `mom` = the box moments [box][N][kMomStride] of the launch's boxes.
+#ifndef MW_MOVE_WHEN
+#define MW_MOVE_WHEN 1     // when the batched kernel asks for the moments (move_energy_mom_wave: WHEN); 0 and 2 measured: see DESIGN 3.2
+#endif
 template <bool LDSPOS, int LAYOUT = kLayoutSoA, bool SELFIMG = true, bool MOMPATH = false>
 __global__ __launch_bounds__(1024)
 void k_move_energy(const double* __restrict__ pos, const double* __restrict__ ivect,
@@ -1043,7 +1046,7 @@ void k_move_energy(const double* __restrict__ pos, const double* __restrict__ iv
 
         MoveRes r;
         bool fast;
-        if constexpr (MOMPATH) fast = move_energy_mom_wave(getpos, getiv, nnof, mom + (size_t)b * N * kMomStride, ws, s_ptab, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r, acc);
+        if constexpr (MOMPATH) fast = move_energy_mom_wave<false, 0, MW_MOVE_WHEN>(getpos, getiv, nnof, mom + (size_t)b * N * kMomStride, ws, s_ptab, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r, acc);
         else fast = move_energy_wave<SELFIMG>(getpos, getiv, row, nnof, ws, niv, i, nnof(i), e, xo, yo, zo, xn, yn, zn, lane, r);
         if (!fast) {
             // a request the fused routine declines (a row longer than 32 entries, more than kCap in-range neighbours, a
