@@ -782,7 +782,7 @@ def main():
                                    "algorithmic_GBps": bytes_full / (ms_full * 1e-3) / 1e9,
                                    "atoms_per_s": W * N_MOL / (ms_full * 1e-3),
                                    "note": "inside the step: the evaluation + every molecule's moments for the step's move kernel "
-                                           "(96 B per molecule written); `plain_avg_ms` is the evaluation alone, timed after the step loop",
+                                           "(80 B per molecule written); `plain_avg_ms` is the evaluation alone, timed after the step loop",
                                    "plain_avg_ms": ms_full_plain, "plain_interactions_per_s": i_full / (ms_full_plain * 1e-3),
                                    "plain_algorithmic_GBps": bytes_full / (ms_full_plain * 1e-3) / 1e9},
                 "k_move_energy": {"avg_ms": ms_moves, "interactions_per_launch": i_moves,
