@@ -436,6 +436,9 @@ int launch_build(int first, int count)
     const int box0 = first - 1;
     ++g.list_version;
     for (int b = box0; b < box0 + count; ++b) g.h_listbuilt[(size_t)b] = 1;
+    g.swm_count = 0;                     // (the driver's moments of walkers in global memory are made afresh after every list build: what
+                                         //  the accepted moves' updates add in rounding stays bounded by a list interval, as the walkers in LDS
+                                         //  have it per launch)
     int ngrid = 0;
     for (int b = box0; b < box0 + count; ++b) ngrid += g.h_usegrid[b] ? 1 : 0;
     const bool fused_sort = ngrid > 0 && g.sort_in_lds && !g.legacy_search;       // k_cell_sort_box resets the statistics itself
