@@ -1007,6 +1007,11 @@ void k_sweep(double* pos, double* hmat, double* ivect,
     };
     __shared__ int bx_k[SPEC + 1];                // the run's exchange: bin, weight increment, histogram increment of every move's rejection
     __shared__ double bx_inc[SPEC + 1], bx_vis[SPEC + 1], bx_dump[2];
+#ifdef MW_RUN_SPEC1        // A/B only: the straight-line pass of the look-ahead builds also for one move at a time
+    constexpr bool kRunPass = true;
+#else
+    constexpr bool kRunPass = SPEC > 1;
+#endif
     auto decide_round = [&](int ntr, int ub, const double* U0, int mvbase) {
 #pragma clang fp contract(off)
         constexpr double kHuge = 1.7976931348623157e308;                         // huge(1.0_dp)
@@ -1106,7 +1111,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                     const double dk = newl ? switch_dk(mn0l, mn1l, ls_c) : switch_dk(bk0, bk1, ls_c);
                     // (one move at a time: every move takes the serial step, whose own exponential stream has lanes to spare -- the
                     //  argument waits there; with look-ahead the serial step is the exception and the exponential is taken here)
-                    exs = SPEC == 1 ? -dk : exp_any(-dk);
+                    exs = !kRunPass ? -dk : exp_any(-dk);
                 }
                 cur_lane = 2 * a;
                 MW_SW_ACC(10, MW_SW_NOW() - t0);
@@ -1122,7 +1127,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
             // (Look-ahead builds only -- the handful of walkers whose speed is one chain's.  The builds that take one move at a time serve
             //  thousands of walkers and are bound by the NUMBER of vector instructions issued: there the serial step, which skips what a
             //  move does not need, issues ~100 fewer per move than the straight-line pass.  Both produce the same numbers, bit for bit.)
-            const bool run_on = SPEC > 1 && !samplerun && !swet && !dd && !minu;
+            const bool run_on = kRunPass && !samplerun && !swet && !dd && !minu;
             bool need_pre = true;
             auto run_of_moves = [&](int a, bool& serial) -> int {
                 [[maybe_unused]] const unsigned long long t0 = MW_SW_NOW();
@@ -1234,7 +1239,7 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 // (an evaluation that no longer stands ends the round: the next one starts with that move)
                 if (s > 0 && (((scm[s * NLAT] | scm[s * NLAT + 1]) & accmask) != 0u || ls_c != ls)) break;
                 if (need_pre) { prephase(s); need_pre = false; }
-                if constexpr (SPEC > 1) {
+                if constexpr (kRunPass) {
                     if (run_on && (!record || (cur_min == 0.0 && tab_small))) {
                         bool serial = false;
                         const int f = run_of_moves(s, serial);
@@ -1269,13 +1274,13 @@ void k_sweep(double* pos, double* hmat, double* ivect,
                 // lane 0: the acceptance; lanes 61, 62: the unbiased histogram's factor after an accepted / a rejected move (:1627-1629);
                 // one move at a time: lanes 1, 2 the lattice switch's exponentials, whose arguments the pre-phase left there
                 double xarg = lane == 0 ? -diffkT : (lane == 61 ? eta_new - lun : eta_rev - lun);
-                if constexpr (SPEC == 1) xarg = (lane == 1 || lane == 2) ? exs : xarg;
+                if constexpr (!kRunPass) xarg = (lane == 1 || lane == 2) ? exs : xarg;
 #ifdef MW_ABL_D_NOEXP
                 const double ex = 0.1 + 0.01 * xarg;
 #else
                 const double ex = exp_any(xarg);
 #endif
-                if constexpr (SPEC == 1) exs = ex;
+                if constexpr (!kRunPass) exs = ex;
                 double pacc = readlane_f64(ex, 0);
                 pacc = pacc > 1.0 ? 1.0 : pacc;
                 const bool ok = U[5] < pacc;                                      // :1145-1146 (false for NaN)
