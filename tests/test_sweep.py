@@ -389,7 +389,11 @@ def _npt_against_oracle(so, c_oracle, boxes, nlat, nw, temperature=200.0, max_tr
                 assert (em.L.mw_sweep_check_flags(w + 1, 1) != 0) == ddst[1]
             if swet is not None:                                     # Swetnam's visit total and the increment it led to
                 f, sh, _ = farm.factors(w + 1, 1)
-                assert sh[0] == swet[0] and f[0] == pytest.approx(swet[1], rel=1e-9, abs=1e-12)
+                assert sh[0] == swet[0]
+                # (a walker that never visits a bin -- outside the order-parameter range from its first move to its last; three
+                #  seeds in five thousand of tools/fuzz_soak.py -- never recomputes its increment: it keeps the one it started with.
+                #  The oracle's single set of module variables still holds the previous walker's value then.)
+                assert f[0] == pytest.approx(swet[1] if swet[0] > 0.0 else wl_factor, rel=1e-9, abs=1e-12)
             dev = np.concatenate([log_a[w], log_b[w]])
             assert np.array_equal(dev[:, 0], ref[:, 0]) and np.array_equal(dev[:, 1], ref[:, 1])     # molecule, outcome flags
             nvol += int(st.nvol[0])
@@ -457,7 +461,7 @@ def test_npt_driver_on_random_lattice_pairs(so, c_oracle, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", list(range(12)) + [3544])      # (3544: a walker that never visits a bin, with Swetnam's rule on -- found by tools/fuzz_soak.py)
 def test_driver_run_options_on_random_pairs(so, c_oracle, seed):
     """The run options of mc_cycle in random combination on the 48-molecule Ic / Ih pair (scaled 0.85 .. 1.05): NVT or NPT, a
     weight table of random size (bumps of a few kT up to 10^8 kT, where the switch's eta terms absorb the energies), an order-
