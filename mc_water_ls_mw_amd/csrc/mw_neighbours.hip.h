@@ -30,7 +30,7 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
     if (use_grid[b]) return;              // this box goes through k_cell_search
     // (a wavefront without a molecule has nothing to do: with the reference's own 48-molecule cells three of a 256-thread
     // block's four wavefronts used to walk the whole 27 N^2 loop for nobody -- the launch uses blocks of one wavefront there)
-    if ((int)(blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) >= N) return;
+    const bool idle = (int)(blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) >= N;      // (leaves below, after the block's barrier)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const double* P  = pos + (size_t)b * N * 3;
     const double* IV = ivect + (size_t)b * ivcap * 3;
@@ -46,14 +46,29 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
     // the cutoff has).  Loaded one by one inside the test loop -- a scalar load and a wait per image, which no unrolling moved
     // across the loop's branches -- the ~200 cycles per test were the load's latency: 116 us for ONE 48-molecule box.
     constexpr int kIvBatch = 9;
+    // Small boxes (the replica farm's 48-molecule cells: one wavefront per box, 16 384 boxes per build): the box's positions and
+    // image vectors go through LDS once, and the loops read them back as broadcasts -- the scalar loads they were (three batches
+    // per j, each a wait of its own) left the vector unit half idle (0.68 ms per 16 384 boxes).
+    constexpr int kLdsN = 256, kLdsIv = 64;
+    __shared__ double s_p[3 * kLdsN], s_iv[3 * kLdsIv];
+    const bool staged = N <= kLdsN && niv <= kLdsIv;                        // (uniform)
+    if (staged) {
+        for (int t = threadIdx.x; t < 3 * N; t += blockDim.x) s_p[t] = P[t];
+        for (int t = threadIdx.x; t < 3 * niv; t += blockDim.x) s_iv[t] = IV[t];
+        __syncthreads();
+    }
+    if (idle) return;
+    // (two copies of the loops, one per address space: a pointer chosen at run time between LDS and global memory would make every
+    //  access through it a FLAT one)
+    auto tests = [&](const double* __restrict__ Pj, const double* __restrict__ IVk) {
     for (int j = 0; j < N; ++j) {                                           // :525
-        const double vx = P[3 * j] - xi, vy = P[3 * j + 1] - yi, vz = P[3 * j + 2] - zi;   // :529
+        const double vx = Pj[3 * j] - xi, vy = Pj[3 * j + 1] - yi, vz = Pj[3 * j + 2] - zi;   // :529
         for (int k0 = 0; k0 < niv; k0 += kIvBatch) {                        // :531
             double iv[kIvBatch][3];
 #pragma unroll
             for (int u = 0; u < kIvBatch; ++u) {
                 const int kk = k0 + u < niv ? k0 + u : niv - 1;             // (uniform; a slot past the table is not tested)
-                iv[u][0] = IV[3 * kk]; iv[u][1] = IV[3 * kk + 1]; iv[u][2] = IV[3 * kk + 2];
+                iv[u][0] = IVk[3 * kk]; iv[u][1] = IVk[3 * kk + 1]; iv[u][2] = IVk[3 * kk + 2];
             }
 #pragma unroll
             for (int u = 0; u < kIvBatch; ++u) {
@@ -71,6 +86,8 @@ void k_build_neighbours(const double* __restrict__ pos, const double* __restrict
             }
         }
     }
+    };
+    if (staged) tests(s_p, s_iv); else tests(P, IV);
     if (active) { nn[(size_t)b * N + i] = cnt < S ? cnt : S; cin[(size_t)b * N + i] = (unsigned char)((cin_ < 127 ? cin_ : 127) | (bnd_ << 7)); }
 
     // per-box statistics: min nn, max nn (max > S means overflow)
