@@ -523,6 +523,8 @@ int finish_build(int first, int count, int* min_nn, int* max_nn)
     }
     if (min_nn) *min_nn = mn;
     if (max_nn) *max_nn = mx;
+    if (first == 1 && count == g.nbox) { g.nnmax_cached = mx; g.nnmax_version = g.list_version; }   // (the driver's launch asks for the longest row
+                                                                                                   //  of any box: no second read-back of the same words)
     if (mx > g.S)
         return fail("mw: neighbour list overflow in box %d: a molecule has %d entries, maxneigh = %d", worst, mx, g.S);
     return 0;
