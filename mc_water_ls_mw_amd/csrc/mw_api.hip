@@ -122,6 +122,7 @@ struct Ctx {
     double *d_wfac = nullptr, *d_wsum = nullptr; // [walker] Wang-Landau increment, Swetnam's visit total
     int* d_winflag = nullptr;                    // [walker] walker_in_window
     double* d_wmom = nullptr; size_t wmom_cap = 0;   // the driver's moment scratch (doubles), grown on demand
+    hipEvent_t ev_srv = nullptr;                     // the server's stream waits on it for the moments made on the main stream
     double* d_pm = nullptr; int* d_srvmomok = nullptr;   // the resident server's moment path: the positions its moments were made from [nbox][N][3]; per box, still in step
     double* d_wstep = nullptr;                   // [walker][2] max_trans, dv_max (bohr) when the walkers' step sizes differ (mw_sweep_steps)
     bool has_steps = false;
@@ -546,6 +547,7 @@ void release_all()
                     g.d_cpartial, g.d_energy, g.d_counts, g.d_mimol, g.d_mtrial, g.d_meold, g.d_menew, g.d_mcnt, g.d_mperm, g.d_mdecl,
                     g.d_mwork, g.d_mom, g.d_mtot, g.d_wmom, g.d_pm, g.d_srvmomok};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (g.ev_srv) { (void)hipEventDestroy(g.ev_srv); g.ev_srv = nullptr; }
     if (g.h_pin) (void)hipHostFree(g.h_pin);
     if (g.h_stage) (void)hipHostFree(g.h_stage);
     for (int s = 0; s < kTimerSlots; ++s) {
@@ -1120,11 +1122,14 @@ static int server_start_locked()
         bool okm = launch_model_energy(1, g.nbox, true, false) == 0 && g.d_mom != nullptr;
         if (okm && !g.d_pm) okm = hipMalloc(&g.d_pm, (size_t)g.nbox * g.N * 3 * sizeof(double)) == hipSuccess;
         if (okm && !g.d_srvmomok) okm = hipMalloc(&g.d_srvmomok, (size_t)g.nbox * sizeof(int)) == hipSuccess;
+        if (okm && !g.ev_srv) okm = hipEventCreateWithFlags(&g.ev_srv, hipEventDisableTiming) == hipSuccess;
         if (okm) {
-            std::vector<int> ones((size_t)g.nbox, 1);
+            // (no host wait: the server's stream waits for the moments on the device -- 52 -> 20-odd us per server start, which a host
+            //  with volume moves pays every few dozen calls; "still in step" = any non-zero word)
             okm = hipMemcpyAsync(g.d_pm, g.d_pos, (size_t)g.nbox * g.N * 3 * sizeof(double), hipMemcpyDeviceToDevice, g.stream) == hipSuccess
-               && hipMemcpyAsync(g.d_srvmomok, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice, g.stream) == hipSuccess
-               && hipStreamSynchronize(g.stream) == hipSuccess;
+               && hipMemsetAsync(g.d_srvmomok, 1, (size_t)g.nbox * sizeof(int), g.stream) == hipSuccess
+               && hipEventRecord(g.ev_srv, g.stream) == hipSuccess
+               && hipStreamWaitEvent(g.sstream, g.ev_srv, 0) == hipSuccess;
         }
         if (okm) mom = g.d_mom;
         else (void)hipGetLastError();
